@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/hqq_oracle.c via ctypes) -- checker only, never the product path."""
+    from oracle import hqq_oracle
+    hqq_oracle.build()
+    return hqq_oracle
+
+
+CD_CODE = {"f32": 0, "f16": 1, "bf16": 2}

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself (mobiusml/hqq,
+imported read-only from /root/reference) on the CPU of the authoring container.
+
+    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/*.npz
+
+The reference's own tests hold no known-answer vectors for this path (only
+round-trip / view-invariance properties), so these files ARE the pin: every array below is an
+output of hqq/core/{quantize,optimize,bitpack}.py, untouched.  /root/reference does not exist on
+the GPU box, so nothing in tests/ imports it at run time; only this script does.
+
+`termcolor` (hard import at hqq/core/quantize.py:13) is absent from the image; a 2-line stub is
+put on sys.path for the import only.
+
+Fixture families
+  pack_<nbits>b.npz          BitPack.pack_*/unpack_* on random ints, ragged 3-bit row counts
+  quant_<tag>.npz            Quantizer.quantize (CPU => float32 solver) -> packed W_q, scale, zero;
+                             HQQLinear(...).dequantize() and .forward(x) for fp16 / bf16 / fp32
+  cfg1_1024_<nbits>b.npz     BASELINE.json configs[0]: nn.Linear(1024,1024) seed 0, gs=64 axis=1;
+                             W itself is regenerated from the seed by the tests (sha256 stored)
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("HQQ_REFERENCE", "/root/reference")
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        sys.exit(f"{REF} not found: golden vectors can only be regenerated where the reference is mounted")
+    stub = types.ModuleType("termcolor")
+    stub.colored = lambda t, *a, **k: t
+    sys.modules.setdefault("termcolor", stub)
+    sys.path.insert(0, REF)
+    from hqq.core.quantize import Quantizer, HQQLinear, BaseQuantizeConfig, HQQBackend  # noqa
+    from hqq.core.bitpack import BitPack  # noqa
+    HQQLinear.set_backend(HQQBackend.PYTORCH)
+    return Quantizer, HQQLinear, BaseQuantizeConfig, BitPack
+
+
+def raw(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous()
+    return t.view(torch.uint16).numpy() if t.dtype == torch.bfloat16 else t.numpy()
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+CD = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def main():
+    Quantizer, HQQLinear, BaseQuantizeConfig, BitPack = _import_reference()
+    torch.set_num_threads(os.cpu_count() or 1)
+    manifest = {"torch": torch.__version__, "reference": "mobiusml/hqq v0.2.8.post1 @ /root/reference", "files": {}}
+
+    # ---------------- BitPack (bitpack.py) ----------------
+    PACK = {8: (BitPack.pack_8bit_u8, BitPack.unpack_8bit_u8), 4: (BitPack.pack_4bit_u8, BitPack.unpack_4bit_u8),
+            3: (BitPack.pack_3bit_32, BitPack.unpack_3bit_32), 2: (BitPack.pack_2bit_u8, BitPack.unpack_2bit_u8),
+            1: (BitPack.pack_1bit_u8, BitPack.unpack_1bit_u8)}
+    torch.manual_seed(42)  # tests/test_bitpack.py:15
+    for nbits, (pk, upk) in PACK.items():
+        arrs = {}
+        shapes = [(32, 32), (128, 256), (1024, 64)] if nbits != 3 else [(32, 32), (37, 64), (1001, 8), (1024, 64)]
+        for i, shp in enumerate(shapes):
+            W = torch.randint(0, 2 ** nbits, shp)
+            P = pk(W)
+            U = upk(P)
+            arrs[f"U{i}"] = W.numpy().astype(np.uint8)
+            arrs[f"P{i}"] = P.numpy()
+            if nbits == 3:   # unpack returns the zero-padded 10*ceil(R/10) rows (bitpack.py:95-110)
+                arrs[f"UP{i}"] = U.numpy().astype(np.uint8)
+            else:
+                assert torch.equal(U.to(W.dtype), W)
+        save(f"pack_{nbits}b", **arrs)
+
+    # ---------------- Quantizer + HQQLinear, small shapes with W stored ----------------
+    def quant_case(tag, W, bias, nbits, gs, M, cds=("f16", "bf16", "f32")):
+        N, K = W.shape
+        arrs = {"W": W.numpy().astype(np.float32), "nbits": np.array(nbits), "gs": np.array(gs)}
+        # raw Quantizer output on CPU: float32 scale (=1/scale) and zero, packed W_q  (quantize.py:75-180)
+        Wq, meta = Quantizer.quantize(W.clone(), nbits=nbits, group_size=gs, axis=1, round_zero=(nbits == 4),
+                                      optimize=True, device="cpu", compute_dtype=torch.float16)
+        arrs["Wq_packed"] = Wq.numpy()
+        arrs["scale_f32"] = meta["scale"].numpy()
+        arrs["zero_f32"] = meta["zero"].numpy()
+        Wq_raw, _ = Quantizer.quantize(W.clone(), nbits=nbits, group_size=gs, axis=1, round_zero=(nbits == 4),
+                                       optimize=True, device="cpu", bitpack=False)
+        arrs["Wq_unpacked"] = Wq_raw.numpy().astype(np.uint8)
+        if bias is not None:
+            arrs["bias_f32"] = bias.numpy().astype(np.float32)
+        torch.manual_seed(1)
+        x32 = torch.randn(M, K)
+        arrs["x_f32"] = x32.numpy()
+        for cdn in cds:
+            cd = CD[cdn]
+            lin = torch.nn.Linear(K, N, bias=bias is not None)
+            lin.weight.data = W.clone()
+            if bias is not None:
+                lin.bias.data = bias.clone()
+            layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=gs, axis=1), compute_dtype=cd, device="cpu")
+            assert np.array_equal(layer.W_q.data.numpy(), arrs["Wq_packed"])
+            arrs[f"scale_{cdn}"] = raw(layer.meta["scale"])
+            arrs[f"zero_{cdn}"] = raw(layer.meta["zero"])
+            arrs[f"Wdeq_{cdn}"] = raw(layer.dequantize())
+            with torch.no_grad():
+                y = layer.forward(x32.to(cd))
+            arrs[f"y_{cdn}"] = raw(y)
+        save(tag, **arrs)
+
+    for nbits in (4, 3, 2, 8, 1):
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(256, 192, bias=True)   # kaiming-uniform weights, like tests/test_quantize.py:22-24
+        quant_case(f"quant_{nbits}b_192x256", lin.weight.data.clone(), lin.bias.data.clone(), nbits, 64, 3)
+
+    # N(0, 0.02^2) fp16-valued weights (BASELINE.md §3 inputs), K > 1024 so rows span several groups
+    torch.manual_seed(0)
+    Wn = (torch.randn(64, 2048) * 0.02).half().float()
+    for nbits in (4, 3, 2):
+        quant_case(f"quant_{nbits}b_64x2048_normal", Wn, None, nbits, 64, 2, cds=("f16",))
+
+    # edge cases: constant group (|max-min|<=1e-4 -> scale 1, quantize.py:128), tiny range (scale clamp 2e4, :129),
+    # all-zero rows, one huge outlier, exact .5 ties
+    torch.manual_seed(3)
+    We = torch.randn(16, 128) * 0.05
+    We[0, :64] = 0.125                 # constant group
+    We[1, :64] = 0.0                   # zero group
+    We[2, :64] = 1.0 + torch.arange(64) * 1e-6   # denom 6.3e-5 <= 1e-4 -> scale = 1
+    We[3, :64] = torch.linspace(0, 3e-4, 64)     # denom 3e-4 -> 15/3e-4 = 5e4 -> clamped to 2e4
+    We[4, 5] = 40.0                    # outlier
+    We[5, :64] = torch.arange(64) * 0.5           # many exact ties before rounding
+    for nbits in (4, 3, 2):
+        quant_case(f"quant_{nbits}b_16x128_edge", We, None, nbits, 64, 1, cds=("f16", "f32"))
+
+    # other group sizes the config accepts (multiples of 8, quantize.py:1088-1091)
+    torch.manual_seed(5)
+    Wg = torch.randn(32, 256) * 0.1
+    for gs in (32, 128, 256):
+        quant_case(f"quant_4b_32x256_gs{gs}", Wg, None, 4, gs, 1, cds=("f16",))
+
+    # ---------------- BASELINE.json configs[0]: 1024x1024 on CPU ----------------
+    for nbits in (4, 3, 2):
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(1024, 1024, bias=False)
+        W = lin.weight.data.clone()
+        arrs = {"W_sha256": np.frombuffer(sha(W.numpy()).encode(), np.uint8), "W_head": W.numpy()[:2, :8].copy()}
+        torch.manual_seed(1)
+        x32 = torch.randn(1, 1024)
+        arrs["x_f32"] = x32.numpy()
+        for cdn in ("f16", "f32"):
+            cd = CD[cdn]
+            torch.manual_seed(0)
+            lin = torch.nn.Linear(1024, 1024, bias=False)
+            layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=cd, device="cpu")
+            if cdn == "f16":
+                arrs["Wq_packed"] = layer.W_q.data.numpy()
+            else:
+                assert np.array_equal(arrs["Wq_packed"], layer.W_q.data.numpy())
+                arrs["scale_f32"] = raw(layer.meta["scale"])
+                arrs["zero_f32"] = raw(layer.meta["zero"])
+            arrs[f"scale_{cdn}"] = raw(layer.meta["scale"])
+            arrs[f"zero_{cdn}"] = raw(layer.meta["zero"])
+            with torch.no_grad():
+                arrs[f"y_{cdn}"] = raw(layer.forward(x32.to(cd)))
+            arrs[f"Wdeq_sha256_{cdn}"] = np.frombuffer(sha(raw(layer.dequantize())).encode(), np.uint8)
+        save(f"cfg1_1024_{nbits}b", **arrs)
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            manifest["files"][f] = hashlib.sha256(open(os.path.join(HERE, f), "rb").read()).hexdigest()
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print("wrote MANIFEST.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""CPU tests: the oracle (oracle/hqq_oracle.c) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  This is what pins the oracle; the -m gpu tests then compare
+the HIP kernels with the oracle and with the same golden files."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import CD_CODE, load_golden
+
+NB = [8, 4, 3, 2, 1]
+
+
+@pytest.mark.parametrize("nbits", NB)
+def test_bitpack_matches_reference(oracle, nbits):
+    g = load_golden(f"pack_{nbits}b")
+    i = 0
+    while f"U{i}" in g:
+        U, P = g[f"U{i}"], g[f"P{i}"]
+        mine = oracle.pack(nbits, U)
+        assert mine.dtype == P.dtype and np.array_equal(mine, P)           # bitpack.py pack_*: bit-exact
+        assert np.array_equal(oracle.pack_np(nbits, U), P)                  # independent numpy restatement
+        up = oracle.unpack(nbits, P)
+        assert np.array_equal(up, oracle.unpack_np(nbits, P))
+        if nbits == 3:
+            assert np.array_equal(up, g[f"UP{i}"])                           # padded rows included
+        assert np.array_equal(up[: len(U)], U)                               # tests/test_bitpack.py:24-34 property
+        i += 1
+    assert i >= 3
+
+
+def test_bitpack_rejects_ragged_rows(oracle):
+    # BitPack.pack_4bit_u8 on an odd row count raises in torch (slab shapes differ); the oracle reports it
+    assert oracle.packed_rows(4, 7) < 0 and oracle.packed_rows(2, 6) < 0 and oracle.packed_rows(3, 7) == 1
+    with pytest.raises(ValueError):
+        oracle.pack(4, np.zeros((7, 8), np.uint8))
+
+
+def test_aten_row_sum_order(oracle):
+    # order restated from ATen SumKernel.cpp; spot values computed with torch 2.10 (x.sum(1)) at generation time
+    g = load_golden("quant_4b_192x256")
+    # the solver's `zero` equality below is the real check; here only the degenerate properties
+    x = np.arange(64, dtype=np.float32)
+    assert oracle.row_sum(x) == 2016.0
+    x = np.zeros(64, np.float32); x[0] = 1e8; x[1] = 1.0; x[32] = -1e8
+    assert oracle.row_sum(x) == 1.0      # x[0]+x[32] cancel first (lane pairing 32 apart), then +1 survives
+
+
+QUANT_FILES = ([f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
+               [f"quant_{b}b_16x128_edge" for b in (4, 3, 2)] + [f"quant_4b_32x256_gs{g}" for g in (32, 128, 256)])
+
+
+@pytest.mark.parametrize("name", QUANT_FILES)
+def test_quantize_matches_reference(oracle, name):
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    W = g["W"]
+    N, K = W.shape
+    o = oracle.quantize(W, nbits=nbits, group_size=gs)
+    # solver output: the reference's CPU float32 path
+    assert np.array_equal(o["Wq"].reshape(-1), g["Wq_unpacked"].reshape(-1))
+    assert np.array_equal(o["zero"], g["zero_f32"].reshape(-1, 1))
+    assert np.array_equal(o["scale"], g["scale_f32"].reshape(-1, 1))
+    packed = oracle.pack(nbits, o["Wq"])
+    assert np.array_equal(packed, g["Wq_packed"])
+    for cdn, code in CD_CODE.items():
+        if f"Wdeq_{cdn}" not in g:
+            continue
+        s_cd, z_cd = oracle.to_cd(o["scale"], code), oracle.to_cd(o["zero"], code)
+        vt = np.float32 if code == 0 else np.uint16
+        assert np.array_equal(np.asarray(s_cd).view(vt).reshape(-1), g[f"scale_{cdn}"].view(vt).reshape(-1))
+        assert np.array_equal(np.asarray(z_cd).view(vt).reshape(-1), g[f"zero_{cdn}"].view(vt).reshape(-1))
+        Wd = oracle.dequantize(nbits, packed, s_cd, z_cd, N, K, gs, code)
+        assert np.array_equal(np.asarray(Wd).view(vt), g[f"Wdeq_{cdn}"].view(vt))      # bit-exact dequantised weights
+        x_cd = oracle.to_cd(g["x_f32"], code)
+        b_cd = oracle.to_cd(g["bias_f32"], code) if "bias_f32" in g else None
+        y, _ = oracle.matmul(x_cd, Wd, b_cd, code)
+        yo, yr = oracle.from_cd(y, code), oracle.from_cd(g[f"y_{cdn}"], code)
+        # BLAS accumulation order differs: 1e-3 (one fp16 ulp at |y|~1) absolute + relative
+        tol = {"f32": 2e-6, "f16": 1e-3, "bf16": 8e-3}[cdn]
+        np.testing.assert_allclose(yo, yr, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+def test_config1_1024(oracle, nbits):
+    """BASELINE.json configs[0]: nn.Linear(1024,1024) seed 0, gs=64 axis=1, quantised by the reference on CPU."""
+    torch = pytest.importorskip("torch")
+    g = load_golden(f"cfg1_1024_{nbits}b")
+    torch.manual_seed(0)
+    W = torch.nn.Linear(1024, 1024, bias=False).weight.data.numpy()
+    if hashlib.sha256(W.tobytes()).hexdigest().encode() != g["W_sha256"].tobytes():
+        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    o = oracle.quantize(W, nbits=nbits, group_size=64)
+    packed = oracle.pack(nbits, o["Wq"])
+    assert np.array_equal(packed, g["Wq_packed"])
+    assert np.array_equal(o["scale"].reshape(-1), g["scale_f32"].reshape(-1))
+    assert np.array_equal(o["zero"].reshape(-1), g["zero_f32"].reshape(-1))
+    for cdn in ("f16", "f32"):
+        code = CD_CODE[cdn]
+        s_cd, z_cd = oracle.to_cd(o["scale"], code), oracle.to_cd(o["zero"], code)
+        Wd = oracle.dequantize(nbits, packed, s_cd, z_cd, 1024, 1024, 64, code)
+        assert hashlib.sha256(np.ascontiguousarray(Wd).tobytes()).hexdigest().encode() == g[f"Wdeq_sha256_{cdn}"].tobytes()
+        y, _ = oracle.matmul(oracle.to_cd(g["x_f32"], code), Wd, None, code)
+        tol = 1e-3 if cdn == "f16" else 2e-6
+        np.testing.assert_allclose(oracle.from_cd(y, code), oracle.from_cd(g[f"y_{cdn}"], code), rtol=tol, atol=tol)
+
+
+def test_half_conversions(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1.0, 1e3, 7e4)])
+    x = np.concatenate([x, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 2.0 ** -24, 2.0 ** -25, 3 * 2.0 ** -26, np.inf, -np.inf], np.float32)])
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16)
+    got = oracle.to_cd(x, 1)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    torch = pytest.importorskip("torch")
+    wb = torch.from_numpy(x).to(torch.bfloat16).view(torch.uint16).numpy()
+    assert np.array_equal(oracle.to_cd(x, 2), wb)
