@@ -1,0 +1,283 @@
+// bitpack.hip — BitPack.pack_* / unpack_* and Quantizer.dequantize for gfx950.
+//
+// Reference semantics: hqq/core/bitpack.py:14-144, hqq/core/quantize.py:183-199; supersedes the
+// axis=0-only CUDA kernels hqq/kernels/hqq_aten_cuda_kernel.cu:35-428 (1 thread per packed byte, scalar
+// stores).  Here every lane moves 16 packed bytes (one global_load_dwordx4) and writes `per` dense
+// 16/32/64-byte runs, so both directions stream at HBM rate; both axes are covered.
+//
+// Layout fact used throughout: the packed tensor is flat.  With n = packed element count
+// (= step*cols), slab s of the unpacked matrix is the flat range [s*n, (s+1)*n), and packed element i
+// holds unpacked elements {s*n + i}.  No 2-D indexing is needed for pack/unpack.
+#include <type_traits>
+
+#include "hqq_common.h"
+
+namespace hqq {
+
+template <int NBITS> struct Pk {
+  static constexpr int per = (NBITS == 3) ? 10 : 8 / NBITS;
+  static constexpr uint32_t mask = (NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u);
+  // shift of slab s inside the container (slab 0 most significant)
+  static __device__ __forceinline__ int shift(int s) { return (NBITS == 3) ? (27 - 3 * s) : NBITS * (per - 1 - s); }
+};
+
+// ---- input element readers for pack (uint8 levels, or float32 holding integer levels) ------------
+__device__ __forceinline__ uint32_t level_of(uint8_t v) { return v; }
+__device__ __forceinline__ uint32_t level_of(float v) { return static_cast<uint32_t>(static_cast<uint8_t>(static_cast<int>(v))); }
+
+// =================================================================================================
+// pack: u8 containers, VEC packed bytes per thread (16 when the slab size allows, else 1)
+// =================================================================================================
+template <int NBITS, typename IN, int VEC>
+__global__ __launch_bounds__(256) void pack_u8_kernel(const IN* __restrict__ U, uint8_t* __restrict__ out, int64_t n) {
+  using P = Pk<NBITS>;
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * VEC;
+  if (i0 >= n) return;
+  uint8_t acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0;
+#pragma unroll
+  for (int s = 0; s < P::per; ++s) {
+    const IN* src = U + static_cast<int64_t>(s) * n + i0;
+    IN v[VEC];
+    if constexpr (VEC == 16 && sizeof(IN) == 1) {
+      *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(src);
+    } else if constexpr (VEC == 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(v)[q] = reinterpret_cast<const f32x4*>(src)[q];
+    } else {
+      v[0] = src[0];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)  // uint8 `<<` in torch wraps modulo 256; the cast reproduces it
+      acc[j] |= static_cast<uint8_t>(level_of(v[j]) << P::shift(s));
+  }
+  if constexpr (VEC == 16) *reinterpret_cast<u32x4*>(out + i0) = *reinterpret_cast<u32x4*>(acc);
+  else out[i0] = acc[0];
+}
+
+// pack: 3-bit into int32, VEC packed words per thread (4 or 1); slabs past `total` are the zero padding
+template <typename IN, int VEC>
+__global__ __launch_bounds__(256) void pack_3bit_kernel(const IN* __restrict__ U, int32_t* __restrict__ out, int64_t n, int64_t total) {
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * VEC;
+  if (i0 >= n) return;
+  uint32_t acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0;
+#pragma unroll
+  for (int s = 0; s < 10; ++s) {
+    const int64_t e0 = static_cast<int64_t>(s) * n + i0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const uint32_t v = (e0 + j < total) ? level_of(U[e0 + j]) : 0u;
+      acc[j] |= v << (27 - 3 * s);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) out[i0 + j] = static_cast<int32_t>(acc[j]);
+}
+
+// =================================================================================================
+// unpack / dequantize share one kernel: DEQ=false writes the integer levels converted to OUT,
+// DEQ=true applies ((q - zero) * scale) in the compute dtype.  VEC packed containers per thread.
+//   AXIS 1: meta index of unpacked element e is e / gs          (unpacked matrix [R, gs])
+//   AXIS 0: meta index is e % cols_u, cols_u = total / gs         (unpacked matrix [gs, R])
+// =================================================================================================
+template <typename OUT> struct Conv;
+template <> struct Conv<uint8_t> { static __device__ __forceinline__ uint8_t of(uint32_t q) { return static_cast<uint8_t>(q); } };
+template <> struct Conv<float> { static __device__ __forceinline__ float of(uint32_t q) { return static_cast<float>(q); } };
+template <> struct Conv<half_t> { static __device__ __forceinline__ half_t of(uint32_t q) { return static_cast<half_t>(static_cast<float>(q)); } };
+template <> struct Conv<bf16_t> { static __device__ __forceinline__ bf16_t of(uint32_t q) { return bf16_t{f32_to_bf16(static_cast<float>(q))}; } };
+
+template <typename OUT, int VEC>
+__device__ __forceinline__ void store_vec(OUT* dst, const OUT* v) {
+  constexpr int bytes = VEC * sizeof(OUT);
+  if constexpr (bytes % 16 == 0) {
+#pragma unroll
+    for (int q = 0; q < bytes / 16; ++q) reinterpret_cast<u32x4*>(dst)[q] = reinterpret_cast<const u32x4*>(v)[q];
+  } else if constexpr (bytes == 8) {
+    *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<const u32x2*>(v);
+  } else if constexpr (bytes == 4) {
+    *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dst[j] = v[j];
+  }
+}
+
+template <int NBITS, typename OUT, bool DEQ, int AXIS, int VEC>
+__global__ __launch_bounds__(256) void unpack_kernel(const void* __restrict__ packed, const OUT* __restrict__ scale,
+                                                     const OUT* __restrict__ zero, OUT* __restrict__ out,
+                                                     int64_t n, int64_t limit, int64_t gs, int64_t cols_u) {
+  using P = Pk<NBITS>;
+  using CT = typename std::conditional<NBITS == 3, uint32_t, uint8_t>::type;
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * VEC;
+  if (i0 >= n) return;
+  CT w[VEC];
+  if constexpr (VEC * sizeof(CT) == 16) *reinterpret_cast<u32x4*>(w) = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(packed) + i0);
+  else w[0] = static_cast<const CT*>(packed)[i0];
+  // sub-chunks over which the meta index is constant for AXIS 1: gs is a multiple of 8 (quantize.py:1088-1091)
+  constexpr int SUB = (VEC >= 8) ? 8 : VEC;
+#pragma unroll
+  for (int s = 0; s < P::per; ++s) {
+    const int64_t e0 = static_cast<int64_t>(s) * n + i0;
+    if (e0 >= limit) continue;   // 3-bit padding rows (quantize.py:190-195 slices them off) / unpack limit = per*n
+    OUT v[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; c += SUB) {
+      if constexpr (DEQ && AXIS == 1) {
+        const int64_t r = (e0 + c) / gs;
+        const OUT z = zero[r];
+        const OUT sc = scale[r];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+          const uint32_t q = (static_cast<uint32_t>(w[c + j]) >> P::shift(s)) & P::mask;
+          v[c + j] = CD<OUT>::dequant(static_cast<float>(q), z, sc);
+        }
+      } else if constexpr (DEQ) {
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+          const int64_t r = (e0 + c + j) % cols_u;
+          const uint32_t q = (static_cast<uint32_t>(w[c + j]) >> P::shift(s)) & P::mask;
+          v[c + j] = CD<OUT>::dequant(static_cast<float>(q), zero[r], scale[r]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SUB; ++j)
+          v[c + j] = Conv<OUT>::of((static_cast<uint32_t>(w[c + j]) >> P::shift(s)) & P::mask);
+      }
+    }
+    store_vec<OUT, VEC>(out + e0, v);
+  }
+}
+
+// ---- host launchers ------------------------------------------------------------------------------
+static inline dim3 grid_for(int64_t n, int vec) { return dim3(static_cast<unsigned>((n + 256LL * vec - 1) / (256LL * vec))); }
+
+template <int NBITS, typename IN>
+static int launch_pack_u8(const void* U, void* out, int64_t n, hipStream_t st) {
+  if (n % 16 == 0) hipLaunchKernelGGL((pack_u8_kernel<NBITS, IN, 16>), grid_for(n, 16), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<uint8_t*>(out), n);
+  else hipLaunchKernelGGL((pack_u8_kernel<NBITS, IN, 1>), grid_for(n, 1), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<uint8_t*>(out), n);
+  return check_launch("hqq_hip_pack");
+}
+template <typename IN>
+static int launch_pack_3(const void* U, void* out, int64_t n, int64_t total, hipStream_t st) {
+  if (n % 4 == 0) hipLaunchKernelGGL((pack_3bit_kernel<IN, 4>), grid_for(n, 4), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
+  else hipLaunchKernelGGL((pack_3bit_kernel<IN, 1>), grid_for(n, 1), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
+  return check_launch("hqq_hip_pack");
+}
+
+template <int NBITS, typename OUT, bool DEQ, int AXIS>
+static int launch_unpack(const void* packed, const void* scale, const void* zero, void* out, int64_t n, int64_t limit,
+                         int64_t gs, int64_t cols_u, hipStream_t st, const char* what) {
+  constexpr int V = (NBITS == 3) ? 4 : 16;
+  constexpr int SUB = (V >= 8) ? 8 : V;
+  // the vector path needs every slab start (s*n) to stay V-aligned and, for AXIS 1 dequant, each
+  // SUB-element sub-chunk to sit inside one group
+  const bool vec_ok = (n % V == 0) && (!(DEQ && AXIS == 1) || gs % SUB == 0);
+  if (vec_ok)
+    hipLaunchKernelGGL((unpack_kernel<NBITS, OUT, DEQ, AXIS, V>), grid_for(n, V), dim3(256), 0, st, packed,
+                       static_cast<const OUT*>(scale), static_cast<const OUT*>(zero), static_cast<OUT*>(out), n, limit, gs, cols_u);
+  else
+    hipLaunchKernelGGL((unpack_kernel<NBITS, OUT, DEQ, AXIS, 1>), grid_for(n, 1), dim3(256), 0, st, packed,
+                       static_cast<const OUT*>(scale), static_cast<const OUT*>(zero), static_cast<OUT*>(out), n, limit, gs, cols_u);
+  return check_launch(what);
+}
+
+template <typename OUT, bool DEQ, int AXIS>
+static int dispatch_bits(int nbits, const void* packed, const void* scale, const void* zero, void* out, int64_t n,
+                         int64_t limit, int64_t gs, int64_t cols_u, hipStream_t st, const char* what) {
+  switch (nbits) {
+    case 8: return launch_unpack<8, OUT, DEQ, AXIS>(packed, scale, zero, out, n, limit, gs, cols_u, st, what);
+    case 4: return launch_unpack<4, OUT, DEQ, AXIS>(packed, scale, zero, out, n, limit, gs, cols_u, st, what);
+    case 3: return launch_unpack<3, OUT, DEQ, AXIS>(packed, scale, zero, out, n, limit, gs, cols_u, st, what);
+    case 2: return launch_unpack<2, OUT, DEQ, AXIS>(packed, scale, zero, out, n, limit, gs, cols_u, st, what);
+    case 1: return launch_unpack<1, OUT, DEQ, AXIS>(packed, scale, zero, out, n, limit, gs, cols_u, st, what);
+  }
+  set_error("%s: nbits=%d not in {8,4,3,2,1}", what, nbits);
+  return HQQ_ERR_NBITS;
+}
+
+}  // namespace hqq
+
+using namespace hqq;
+
+extern "C" {
+
+int64_t hqq_hip_packed_rows(int nbits, int64_t rows) {
+  const int per = per_of(nbits);
+  if (!per) return HQQ_ERR_NBITS;
+  if (nbits == 3) return (rows + 9) / 10;
+  if (rows % per) return HQQ_ERR_SHAPE;
+  return rows / per;
+}
+
+int hqq_hip_pack(int nbits, const void* U, int in_dtype, int64_t rows, int64_t cols, void* out, void* stream) {
+  const int64_t prow = hqq_hip_packed_rows(nbits, rows);
+  if (prow < 0) { set_error("hqq_hip_pack: nbits=%d rows=%lld not packable", nbits, (long long)rows); return static_cast<int>(prow); }
+  if (in_dtype != HQQ_U8 && in_dtype != HQQ_F32) { set_error("hqq_hip_pack: in_dtype must be U8 or F32"); return HQQ_ERR_DTYPE; }
+  if (!aligned16(U) || !aligned16(out)) { set_error("hqq_hip_pack: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  const int64_t n = prow * cols, total = rows * cols;
+  if (n == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  const bool f = in_dtype == HQQ_F32;
+  switch (nbits) {
+    case 8: return f ? launch_pack_u8<8, float>(U, out, n, st) : launch_pack_u8<8, uint8_t>(U, out, n, st);
+    case 4: return f ? launch_pack_u8<4, float>(U, out, n, st) : launch_pack_u8<4, uint8_t>(U, out, n, st);
+    case 2: return f ? launch_pack_u8<2, float>(U, out, n, st) : launch_pack_u8<2, uint8_t>(U, out, n, st);
+    case 1: return f ? launch_pack_u8<1, float>(U, out, n, st) : launch_pack_u8<1, uint8_t>(U, out, n, st);
+    case 3: return f ? launch_pack_3<float>(U, out, n, total, st) : launch_pack_3<uint8_t>(U, out, n, total, st);
+  }
+  return HQQ_ERR_NBITS;
+}
+
+int hqq_hip_unpack(int nbits, const void* packed, int64_t packed_rows, int64_t cols, void* out, int out_dtype, void* stream) {
+  const int per = per_of(nbits);
+  if (!per) { set_error("hqq_hip_unpack: nbits=%d not in {8,4,3,2,1}", nbits); return HQQ_ERR_NBITS; }
+  if (!aligned16(packed) || !aligned16(out)) { set_error("hqq_hip_unpack: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  const int64_t n = packed_rows * cols, limit = n * per;
+  if (n == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  switch (out_dtype) {
+    case HQQ_U8: return dispatch_bits<uint8_t, false, 1>(nbits, packed, nullptr, nullptr, out, n, limit, 8, 1, st, "hqq_hip_unpack");
+    case HQQ_F32: return dispatch_bits<float, false, 1>(nbits, packed, nullptr, nullptr, out, n, limit, 8, 1, st, "hqq_hip_unpack");
+    case HQQ_F16: return dispatch_bits<half_t, false, 1>(nbits, packed, nullptr, nullptr, out, n, limit, 8, 1, st, "hqq_hip_unpack");
+    case HQQ_BF16: return dispatch_bits<bf16_t, false, 1>(nbits, packed, nullptr, nullptr, out, n, limit, 8, 1, st, "hqq_hip_unpack");
+  }
+  set_error("hqq_hip_unpack: bad out_dtype %d", out_dtype);
+  return HQQ_ERR_DTYPE;
+}
+
+int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void* zero, void* out,
+                       int64_t N, int64_t K, int64_t group_size, int axis, int dtype, void* stream) {
+  const int per = per_of(nbits);
+  if (!per) { set_error("hqq_hip_dequantize: nbits=%d not in {8,4,3,2,1}", nbits); return HQQ_ERR_NBITS; }
+  const int64_t total = N * K;
+  if (group_size <= 0 || total % group_size || (axis != 0 && axis != 1)) {
+    set_error("hqq_hip_dequantize: N*K=%lld not divisible by group_size=%lld, or bad axis %d", (long long)total, (long long)group_size, axis);
+    return HQQ_ERR_SHAPE;
+  }
+  if (!aligned16(Wq) || !aligned16(out)) { set_error("hqq_hip_dequantize: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  if (total == 0) return 0;
+  // unpacked matrix: axis 1 -> [R, gs], axis 0 -> [gs, R]; packing always slabs dim 0
+  const int64_t R = total / group_size;
+  const int64_t urows = (axis == 1) ? R : group_size, ucols = (axis == 1) ? group_size : R;
+  const int64_t prow = hqq_hip_packed_rows(nbits, urows);
+  if (prow < 0) { set_error("hqq_hip_dequantize: %lld unpacked rows not packable at %d bits", (long long)urows, nbits); return HQQ_ERR_SHAPE; }
+  const int64_t n = prow * ucols;
+  hipStream_t st = as_stream(stream);
+  const char* what = "hqq_hip_dequantize";
+#define HQQ_DQ(T)                                                                                               \
+  return (axis == 1) ? dispatch_bits<T, true, 1>(nbits, Wq, scale, zero, out, n, total, group_size, R, st, what) \
+                     : dispatch_bits<T, true, 0>(nbits, Wq, scale, zero, out, n, total, group_size, R, st, what)
+  switch (dtype) {
+    case HQQ_F32: HQQ_DQ(float);
+    case HQQ_F16: HQQ_DQ(half_t);
+    case HQQ_BF16: HQQ_DQ(bf16_t);
+  }
+#undef HQQ_DQ
+  set_error("hqq_hip_dequantize: bad dtype %d", dtype);
+  return HQQ_ERR_DTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""Tensor-level wrappers over the C ABI (include/hqq_hip.h).  PyTorch only supplies device memory and the
+current HIP stream; every function below enqueues hand-written gfx950 kernels from libhqq_hip.so.
+
+No fallbacks: tensors must live on a ROCm device ("cuda" in torch), and a missing library or an
+unsupported configuration raises (RuntimeError / NotImplementedError) instead of silently running
+eager PyTorch.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _C
+
+F32, F16, BF16, U8 = 0, 1, 2, 3
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.uint8: U8}
+PER = {8: 1, 4: 2, 2: 4, 1: 8, 3: 10}
+# Quantizer.bit_to_packing (hqq/core/quantize.py:40-49): container width per nbits
+PACK_BITS = {8: 8, 6: 8, 5: 8, 4: 4, 3: 3, 2: 2, 1.58: 2, 1: 1}
+GEMV_MAX_M = 8
+
+
+def is_available() -> bool:
+    """True when libhqq_hip.so loads and a ROCm GPU is visible."""
+    try:
+        _C.lib()
+    except (RuntimeError, OSError):
+        return False
+    return torch.cuda.is_available()
+
+
+def _dt(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise TypeError(f"hqq_amd: dtype {t} not supported by the HIP kernels") from None
+
+
+def _dev(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hqq_amd: HIP kernels need tensors on the GPU (device='cuda'); there is no CPU path")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def packed_rows(nbits: int, rows: int) -> int:
+    r = _C.lib().hqq_hip_packed_rows(int(nbits), int(rows))
+    if r < 0:
+        raise ValueError(f"hqq_amd: {rows} rows cannot be packed at {nbits} bits (rows must divide by {PER.get(nbits)})")
+    return int(r)
+
+
+def pack(nbits: int, W_q: Tensor) -> Tensor:
+    """BitPack.pack_{8,4,2,1}bit_u8 / pack_3bit_32 (hqq/core/bitpack.py).  W_q: [rows, cols] integer levels
+    (uint8, or float32 as produced by the reference solver)."""
+    _dev(W_q)
+    if W_q.dtype not in (torch.uint8, torch.float32):
+        W_q = W_q.to(torch.uint8)
+    W_q = W_q.contiguous()
+    rows, cols = W_q.shape
+    out = torch.empty((packed_rows(nbits, rows), cols), dtype=torch.int32 if nbits == 3 else torch.uint8, device=W_q.device)
+    with torch.cuda.device(W_q.device):
+        rc = _C.lib().hqq_hip_pack(nbits, _p(W_q), _dt(W_q.dtype), rows, cols, _p(out), _stream())
+    _C.check(rc, "hqq_hip_pack")
+    return out
+
+
+def unpack(nbits: int, W_q: Tensor, dtype: torch.dtype = torch.uint8) -> Tensor:
+    """BitPack.unpack_*(W_q, dtype) — returns [per*packed_rows, cols] (3-bit: including the padding rows)."""
+    _dev(W_q)
+    W_q = W_q.contiguous()
+    prow, cols = W_q.shape
+    out = torch.empty((PER[nbits] * prow, cols), dtype=dtype, device=W_q.device)
+    with torch.cuda.device(W_q.device):
+        rc = _C.lib().hqq_hip_unpack(nbits, _p(W_q), prow, cols, _p(out), _dt(dtype), _stream())
+    _C.check(rc, "hqq_hip_unpack")
+    return out
+
+
+def dequantize(W_q: Tensor, scale: Tensor, zero: Tensor, N: int, K: int, group_size: int, nbits: int, axis: int = 1) -> Tensor:
+    """Quantizer.dequantize / hqq_aten.dequantize: [N,K] in scale.dtype, bit-identical to the reference."""
+    _dev(W_q, scale, zero)
+    if scale.dtype != zero.dtype:
+        raise TypeError("hqq_amd: scale and zero must share the compute dtype")
+    out = torch.empty((N, K), dtype=scale.dtype, device=W_q.device)
+    with torch.cuda.device(W_q.device):
+        rc = _C.lib().hqq_hip_dequantize(nbits, _p(W_q.contiguous()), _p(scale.contiguous()), _p(zero.contiguous()), _p(out),
+                                         N, K, group_size, axis, _dt(scale.dtype), _stream())
+    _C.check(rc, "hqq_hip_dequantize")
+    return out
+
+
+def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias, N: int, K: int, group_size: int, nbits: int,
+         out: Tensor | None = None) -> Tensor:
+    _dev(x, W_q, scale, zero, bias)
+    if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
+        raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
+    if x.shape[-1] != K:
+        raise ValueError(f"hqq_amd: x has {x.shape[-1]} features, layer expects {K}")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M > 0:
+        with torch.cuda.device(x.device):
+            rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
+                                            _dt(x.dtype), _stream())
+        _C.check(rc, fn_name)
+    return out.reshape(*x.shape[:-1], N)
+
+
+def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
+    """fused unpack->dequant->GEMV, 1 <= M <= 8 (decode)."""
+    return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+
+
+def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
+    """fused unpack->dequant->MFMA GEMM (prefill)."""
+    return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+
+
+def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
+    """y = x @ dequantize(W_q)^T (+ bias): GEMV for M <= 8, MFMA GEMM otherwise."""
+    return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+
+
+def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False, optimize: bool = True,
+             iters: int = 20, beta: float = 10.0, lp_norm: float = 0.7, return_info: bool = False):
+    """Quantizer.quantize(axis=1, channel_wise=True, bitpack=True) with optimize_weights_proximal_legacy, fused with
+    packing.  Returns (W_q packed, scale [R,1] f32 (already inverted), zero [R,1] f32[, info int32[2] on device])."""
+    _dev(W)
+    if W.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        W = W.float()
+    W = W.contiguous()
+    numel = W.numel()
+    if group_size is None or numel % group_size:
+        raise ValueError("group_size should be divisble by the total tensor dimensions. shape: "
+                         f"{tuple(W.shape)}, group_size: {group_size}")   # quantize.py:94-100
+    pack_bits = PACK_BITS[nbits]
+    max_v = int(round(2 ** nbits - 1))
+    R = numel // group_size
+    prow = packed_rows(pack_bits, R)
+    dev = W.device
+    W_q = torch.empty((prow, group_size), dtype=torch.int32 if pack_bits == 3 else torch.uint8, device=dev)
+    scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    zero = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    info = torch.zeros((2,), dtype=torch.int32, device=dev)
+    L = _C.lib()
+    it = iters if optimize else 0
+    ws_bytes = L.hqq_hip_quantize_workspace_bytes(numel, group_size, it)
+    if ws_bytes == 0:
+        raise ValueError(f"hqq_amd: bad quantize arguments (numel={numel}, group_size={group_size}, iters={it})")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.hqq_hip_quantize(_p(W), _dt(W.dtype), numel, group_size, max_v, pack_bits, int(bool(round_zero)), int(bool(optimize)),
+                                it, float(beta), float(lp_norm), _p(W_q), _p(scale), _p(zero), _p(info), _p(ws), ws_bytes, _stream())
+    _C.check(rc, "hqq_hip_quantize")
+    if return_info:
+        return W_q, scale, zero, info
+    return W_q, scale, zero

@@ -1,0 +1,112 @@
+/*
+ * include/hqq_hip.h — C ABI of libhqq_hip.so, the MI355X (gfx950) implementation of HQQ's two hot paths.
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only; no torch / ATen types cross this ABI.
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or
+ *     frees device memory and keeps no pointer after a call returns.
+ *   - every function enqueues on the given hipStream_t (passed as void*; NULL = legacy default
+ *     stream) and returns immediately; there is no host synchronisation inside.
+ *   - return value: 0 on success; >0 a hipError_t from the launch; <0 an argument error
+ *     (HQQ_ERR_*).  hqq_hip_last_error() gives a thread-local message.  Nothing throws.
+ *   - device pointers must be 16-byte aligned and dense (contiguous).
+ *
+ * Each entry point cites the reference interface it replaces (mobiusml/hqq v0.2.8.post1):
+ * the pybind module `hqq_aten` (hqq/kernels/hqq_aten_cuda.cpp:57-73) and the PyTorch code of
+ * hqq/core/{bitpack,quantize,optimize}.py that HQQBackend.PYTORCH runs.
+ */
+#ifndef HQQ_HIP_H
+#define HQQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQQ_HIP_ABI_VERSION 1
+
+/* element types of activations / meta / outputs ("compute_dtype" in the reference) */
+enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
+
+/* argument errors */
+enum {
+  HQQ_ERR_NBITS = -1,      /* nbits not in {8,4,3,2,1}                                   */
+  HQQ_ERR_SHAPE = -2,      /* sizes inconsistent with the packing / group size            */
+  HQQ_ERR_DTYPE = -3,      /* dtype code not supported by this entry point                */
+  HQQ_ERR_UNSUPPORTED = -4,/* valid HQQ configuration this kernel does not cover (caller decides what to do) */
+  HQQ_ERR_WORKSPACE = -5,  /* workspace too small / NULL                                  */
+  HQQ_ERR_ALIGN = -6       /* pointer not 16-byte aligned                                 */
+};
+
+int hqq_hip_abi_version(void);
+const char* hqq_hip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * BitPack  — hqq/core/bitpack.py:14-144 ; hqq_aten.unpack_{8,4,3,2,1}bit_* (hqq_aten_cuda.cpp:57-73,
+ * kernels hqq_aten_cuda_kernel.cu:81-106,159-188,244-276,337-374).
+ * Layout: `per` row-slabs of the unpacked [rows, cols] matrix share one packed element, slab 0
+ * most significant: per = 1/2/4/8 for 8/4/2/1-bit into uint8, per = 10 for 3-bit into int32 with
+ * rows zero padded to 10*ceil(rows/10).
+ * ------------------------------------------------------------------------------------------- */
+/* rows of the packed tensor for `rows` unpacked rows; HQQ_ERR_SHAPE if rows % per != 0 (torch raises there) */
+int64_t hqq_hip_packed_rows(int nbits, int64_t rows);
+
+/* U [rows, cols] uint8 (in_dtype HQQ_U8) or float32 holding integers (HQQ_F32, the solver's W_q)
+ * -> out [packed_rows, cols] uint8 / int32(3-bit).  BitPack.pack_* */
+int hqq_hip_pack(int nbits, const void* U, int in_dtype, int64_t rows, int64_t cols, void* out, void* stream);
+
+/* packed [packed_rows, cols] -> out [per*packed_rows, cols] of out_dtype (HQQ_U8/F16/BF16/F32).
+ * BitPack.unpack_*(W_q, dtype) ; hqq_aten.unpack_* */
+int hqq_hip_unpack(int nbits, const void* packed, int64_t packed_rows, int64_t cols, void* out, int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quantizer.dequantize — hqq/core/quantize.py:183-199 ; hqq_aten.dequantize(W_q, scale, zero, N, K,
+ * group_size, nbits, axis, packing) (hqq_aten_cuda.cpp:32-54, axis=0 only there; both axes here).
+ *   out[N,K] = ((unpack(Wq)[:N*K/gs] - zero) * scale).reshape(N,K), two roundings in `dtype`.
+ * scale/zero: [N*K/group_size] elements of `dtype`.  group_size = elements per (scale,zero).
+ * axis=1: unpacked matrix is [N*K/gs, gs];  axis=0: [gs, N*K/gs].
+ * ------------------------------------------------------------------------------------------- */
+int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void* zero, void* out,
+                       int64_t N, int64_t K, int64_t group_size, int axis, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * HQQLinear.forward (quantize.py:880-898 forward_pytorch / matmul; patching.py:82-86) fused:
+ *   y[M,N] = x[M,K] @ dequantize(Wq)^T (+ bias[N]),  axis=1 layout, dequantised weights bit-identical
+ *   to hqq_hip_dequantize, fp32 accumulation, one rounding to `dtype` (+ one for the bias add).
+ * hqq_hip_gemv : small M (decode), HBM-bandwidth bound, no MFMA.            1 <= M <= HQQ_GEMV_MAX_M
+ * hqq_hip_gemm : large M (prefill), MFMA f16/bf16.                          any M >= 1
+ * hqq_hip_forward picks one of the two by M.
+ * Covered: nbits in {4,2} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0,
+ * dtype F16/BF16 -> otherwise HQQ_ERR_UNSUPPORTED (the caller may compose dequantize + its own GEMM).
+ * ------------------------------------------------------------------------------------------- */
+#define HQQ_GEMV_MAX_M 8
+int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
+                    void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Quantizer.quantize + optimize_weights_proximal_legacy + BitPack.pack_* in one call
+ * (quantize.py:75-180, optimize.py:96-108, 201-255), axis=1, channel_wise=True.
+ *   W          [N*K] of w_dtype (F32/F16/BF16); promoted to float32 (`tensor.float()`, quantize.py:102)
+ *   max_v      round(2^nbits - 1)  (quantize.py:121);  pack_bits the container width {8,4,3,2,1}
+ *   Wq_out     packed weights, layout of hqq_hip_pack
+ *   scale_out  [N*K/gs] float32 = 1/scale (quantize.py:154) ; zero_out [N*K/gs] float32
+ *   info_out   int32[2] on the device: {iterations run, stop iteration index}  (may be NULL)
+ * The solver runs in float32 — the reference's CPU precision (optimize.py:231); results equal the
+ * reference's CPU path (see DESIGN.md for the two documented rounding caveats).
+ * ------------------------------------------------------------------------------------------- */
+size_t hqq_hip_quantize_workspace_bytes(int64_t numel, int64_t group_size, int iters);
+int hqq_hip_quantize(const void* W, int w_dtype, int64_t numel, int64_t group_size, int max_v, int pack_bits,
+                     int round_zero, int optimize, int iters, float beta, float lp_norm,
+                     void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQQ_HIP_H */

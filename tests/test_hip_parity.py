@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP kernels (through the C ABI, hqq_amd.ops) against
+  (a) golden vectors produced by the reference itself (tests/golden), and
+  (b) the CPU oracle (oracle/hqq_oracle.c) on seeded inputs, and
+  (c) size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact for packed bytes and dequantised weights; forward within atol=rtol=1e-3 for fp16 (one fp16 ulp,
+BLAS-order noise in the reference itself); solver: see test_quantize_*.
+"""
+import numpy as np
+import pytest
+
+from conftest import CD_CODE, load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TD = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+NB = [8, 4, 3, 2, 1]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from hqq_amd import ops as o
+    assert o.is_available(), "libhqq_hip.so must load on the GPU box (no fallback)"
+    return o
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def cd_tensor(raw, cdn):
+    """golden raw array (np.float16 / uint16-bf16 / float32) -> cuda tensor of the compute dtype"""
+    t = torch.from_numpy(np.ascontiguousarray(raw))
+    if cdn == "bf16":
+        t = t.view(torch.bfloat16)
+    return t.cuda()
+
+
+def bits(t):
+    t = t.detach().contiguous().cpu()
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
+        return t.view(torch.int16).numpy()
+    if t.dtype == torch.float32:
+        return t.view(torch.int32).numpy()
+    return t.numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# BitPack
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nbits", NB)
+def test_pack_unpack_golden(ops, nbits):
+    g = load_golden(f"pack_{nbits}b")
+    i = 0
+    while f"U{i}" in g:
+        U, P = g[f"U{i}"], g[f"P{i}"]
+        got = ops.pack(nbits, dev(U))
+        assert got.dtype == (torch.int32 if nbits == 3 else torch.uint8)
+        assert np.array_equal(got.cpu().numpy(), P)
+        assert np.array_equal(ops.pack(nbits, dev(U).float()).cpu().numpy(), P)      # float levels, as the solver emits
+        up = ops.unpack(nbits, dev(P))
+        want = g[f"UP{i}"] if nbits == 3 else U
+        assert np.array_equal(up.cpu().numpy()[: len(want)], want)
+        for dt in (torch.float16, torch.bfloat16, torch.float32):                     # tests/test_bitpack.py:24-34
+            assert torch.equal(ops.unpack(nbits, dev(P), dt)[: len(U)].cpu(), torch.from_numpy(U).to(dt))
+        i += 1
+
+
+@pytest.mark.parametrize("nbits", NB)
+@pytest.mark.parametrize("shape", [(32, 32), (128, 256), (4096, 4096), (8192, 128), (32, 4096), (1001, 8), (70, 24)])
+def test_pack_unpack_roundtrip_and_oracle(ops, oracle, nbits, shape):
+    if nbits != 3 and shape[0] % ops.PER[nbits]:
+        with pytest.raises(ValueError):
+            ops.pack(nbits, torch.zeros(shape, dtype=torch.uint8, device="cuda"))
+        return
+    g = torch.Generator().manual_seed(42)
+    U = torch.randint(0, 2 ** nbits, shape, generator=g, dtype=torch.uint8)
+    P = ops.pack(nbits, U.cuda())
+    assert torch.equal(ops.unpack(nbits, P)[: shape[0]].cpu(), U)
+    if U.numel() <= 1 << 22:
+        assert np.array_equal(P.cpu().numpy(), oracle.pack(nbits, U.numpy()))
+
+
+def test_pack_empty(ops):
+    assert ops.pack(4, torch.zeros((0, 64), dtype=torch.uint8, device="cuda")).shape == (0, 64)
+    assert ops.unpack(4, torch.zeros((0, 64), dtype=torch.uint8, device="cuda")).shape == (0, 64)
+
+
+# ------------------------------------------------------------------------------------------------
+# Quantizer.dequantize
+# ------------------------------------------------------------------------------------------------
+QUANT_FILES = ([f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
+               [f"quant_{b}b_16x128_edge" for b in (4, 3, 2)] + [f"quant_4b_32x256_gs{g}" for g in (32, 128, 256)])
+
+
+@pytest.mark.parametrize("name", QUANT_FILES)
+def test_dequantize_golden_bit_exact(ops, name):
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    N, K = g["W"].shape
+    Wq = dev(g["Wq_packed"])
+    for cdn in CD_CODE:
+        if f"Wdeq_{cdn}" not in g:
+            continue
+        s, z = cd_tensor(g[f"scale_{cdn}"], cdn), cd_tensor(g[f"zero_{cdn}"], cdn)
+        Wd = ops.dequantize(Wq, s, z, N, K, gs, nbits, axis=1)
+        assert Wd.dtype == TD[cdn]
+        assert np.array_equal(bits(Wd), bits(cd_tensor(g[f"Wdeq_{cdn}"], cdn))), (name, cdn)
+
+
+@pytest.mark.parametrize("nbits", NB)
+def test_dequantize_axis0_matches_formula(ops, oracle, nbits):
+    # axis=0 (hqq_aten's only mode, hqq_aten_cuda.cpp:35): unpacked matrix is [gs, N*K/gs], meta is [1, N*K/gs]
+    N, K, gs = 48, 160, 64
+    g = torch.Generator().manual_seed(7)
+    R = N * K // gs
+    U = torch.randint(0, 2 ** nbits, (gs, R), generator=g, dtype=torch.uint8)
+    if nbits != 3 and gs % ops.PER[nbits]:
+        pytest.skip("not packable")
+    P = ops.pack(nbits, U.cuda())
+    for dt in (torch.float16, torch.float32, torch.bfloat16):
+        s = (torch.rand(1, R, generator=g) * 0.1 + 0.01).to(dt).cuda()
+        z = (torch.rand(1, R, generator=g) * (2 ** nbits - 1)).to(dt).cuda()
+        got = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, gs, nbits, axis=0)
+        want = ((U.cuda().to(dt) - z) * s).reshape(N, K)      # Quantizer.dequantize, quantize.py:198
+        assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused forward: GEMV (M<=8) and MFMA GEMM
+# ------------------------------------------------------------------------------------------------
+def _layer_from_golden(g, cdn):
+    return dev(g["Wq_packed"]), cd_tensor(g[f"scale_{cdn}"], cdn), cd_tensor(g[f"zero_{cdn}"], cdn)
+
+
+@pytest.mark.parametrize("name", ["quant_4b_192x256", "quant_2b_192x256", "quant_4b_64x2048_normal", "quant_2b_64x2048_normal",
+                                  "quant_4b_16x128_edge", "quant_2b_16x128_edge", "quant_4b_32x256_gs32", "quant_4b_32x256_gs128",
+                                  "quant_4b_32x256_gs256"])
+def test_forward_golden(ops, name):
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    N, K = g["W"].shape
+    Wq, s, z = _layer_from_golden(g, "f16")
+    x = dev(g["x_f32"]).half()
+    b = dev(g["bias_f32"]).half() if "bias_f32" in g else None
+    want = cd_tensor(g["y_f16"], "f16").float()
+    y = ops.gemv(x, Wq, s, z, b, N, K, gs, nbits)
+    torch.testing.assert_close(y.float(), want, rtol=1e-3, atol=1e-3)
+    if (N // ops.PER[nbits]) % 4 == 0 and K % 64 == 0:
+        y2 = ops.gemm(x, Wq, s, z, b, N, K, gs, nbits)
+        torch.testing.assert_close(y2.float(), want, rtol=1e-3, atol=1e-3)
+
+
+def _random_layer(N, K, gs, nbits, seed, dt=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    R = N * K // gs
+    U = torch.randint(0, 2 ** nbits, (R, gs), generator=g, dtype=torch.uint8)
+    s = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).to(dt)
+    z = (torch.rand(R, 1, generator=g) * (2 ** nbits - 1)).to(dt)
+    return U, s, z
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("NK", [(512, 1024), (256, 2048 + 768), (64, 11008)])
+def test_gemv_vs_oracle(ops, oracle, nbits, M, NK):
+    N, K = NK
+    gs = 64
+    U, s, z = _random_layer(N, K, gs, nbits, seed=N + K + nbits)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half() if M % 2 else None
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
+    yo, y32 = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
+    y = ops.gemv(x.cuda(), dev(P), s.cuda(), z.cuda(), None if bias is None else bias.cuda(), N, K, gs, nbits)
+    # fp32-accumulated result vs the double-accumulated oracle: 1e-3 absolute + one fp16 ulp relative
+    torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3)
+    # and the GEMV must agree with the dequant kernel bit-for-bit on a one-hot probe: y[n] = W[n,k]
+    k = (3 * K) // 7
+    e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, k] = 1.0
+    col = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0]
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    assert torch.equal(col, Wdev[:, k])
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (200, 384, 512), (16, 128, 1024), (9, 1024, 128), (1000, 512, 4096)])
+def test_gemm_vs_oracle(ops, oracle, nbits, M, N, K):
+    gs = 64
+    U, s, z = _random_layer(N, K, gs, nbits, seed=M + N + K)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half()
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
+    yo, _ = oracle.matmul(x.numpy(), Wd, bias.numpy(), 1)
+    y = ops.gemm(x.cuda(), dev(P), s.cuda(), z.cuda(), bias.cuda(), N, K, gs, nbits)
+    torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=2e-3)
+    # asymmetric probe (transpose-detecting): x = one-hot rows picks single weight columns exactly
+    e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+    ks = torch.arange(M, device="cuda") * 7 % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    Y = ops.gemm(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    assert torch.equal(Y, Wdev[:, ks].t().contiguous())
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_forward_full_size_properties(ops, nbits):
+    """Llama-2-7B shapes (BASELINE.json configs[1]): linearity and one-hot exactness, no oracle needed."""
+    for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008)]:
+        U, s, z = _random_layer(N, K, 64, nbits, seed=N ^ K)
+        P = ops.pack(nbits, U.cuda())
+        s, z = s.cuda(), z.cuda()
+        g = torch.Generator().manual_seed(5)
+        x1 = torch.randn(1, K, generator=g).half().cuda()
+        x2 = torch.randn(1, K, generator=g).half().cuda()
+        Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, nbits).float()
+        for xx in (x1, x2):
+            y = ops.forward(xx, P, s, z, None, N, K, 64, nbits).float()
+            torch.testing.assert_close(y, xx.float() @ Wd.t(), rtol=1e-3, atol=1e-3)
+        # GEMV (M=2) and GEMM (M=64) give the same rows as M=1
+        X = torch.cat([x1, x2]).contiguous()
+        y2 = ops.gemv(X, P, s, z, None, N, K, 64, nbits)
+        assert torch.equal(y2[0], ops.gemv(x1, P, s, z, None, N, K, 64, nbits)[0])
+        X64 = torch.randn(64, K, generator=g).half().cuda()
+        torch.testing.assert_close(ops.gemm(X64, P, s, z, None, N, K, 64, nbits).float(), X64.float() @ Wd.t(), rtol=1e-3, atol=2e-3)
+
+
+def test_forward_unsupported_is_loud(ops):
+    x = torch.zeros(1, 64, dtype=torch.float16, device="cuda")
+    W3 = torch.zeros(7, 64, dtype=torch.int32, device="cuda")
+    s = torch.ones(64, 1, dtype=torch.float16, device="cuda")
+    with pytest.raises(NotImplementedError):
+        ops.gemv(x, W3, s, s, None, 64, 64, 64, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# Quantizer.quantize (solver + pack)
+# ------------------------------------------------------------------------------------------------
+def _check_quant(ops, W, nbits, gs, want_packed, want_scale, want_zero, max_frac=2e-5):
+    Wq, s, z, info = ops.quantize(dev(W), nbits=nbits, group_size=gs, round_zero=(nbits == 4), return_info=True)
+    torch.cuda.synchronize()
+    want_u = None
+    # compare levels, not bytes, so a single differing level counts once
+    got_u = ops.unpack(ops.PACK_BITS[nbits], Wq).cpu().numpy()[: W.size // gs]
+    want_u = ops.unpack(ops.PACK_BITS[nbits], dev(want_packed)).cpu().numpy()[: W.size // gs]
+    diff = got_u.astype(np.int32) - want_u.astype(np.int32)
+    nbad = int((diff != 0).sum())
+    assert np.abs(diff).max() <= 1
+    # documented residual: |e|^(p-1) rounding (ATen Sleef powf <= 1 ulp vs correctly rounded here)
+    assert nbad <= max(2, int(max_frac * W.size)), f"{nbad} of {W.size} levels differ"
+    np.testing.assert_allclose(s.cpu().numpy().reshape(-1), want_scale.reshape(-1), rtol=0, atol=0)   # scale is never touched by the solver
+    np.testing.assert_allclose(z.cpu().numpy().reshape(-1), want_zero.reshape(-1), rtol=2e-6, atol=2e-6)
+    return nbad, info.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", QUANT_FILES)
+def test_quantize_golden(ops, name):
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    _check_quant(ops, g["W"], nbits, gs, g["Wq_packed"], g["scale_f32"], g["zero_f32"])
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+def test_quantize_config1_1024(ops, nbits):
+    import hashlib
+    g = load_golden(f"cfg1_1024_{nbits}b")
+    torch.manual_seed(0)
+    W = torch.nn.Linear(1024, 1024, bias=False).weight.data.numpy()
+    if hashlib.sha256(W.tobytes()).hexdigest().encode() != g["W_sha256"].tobytes():
+        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    _check_quant(ops, W, nbits, 64, g["Wq_packed"], g["scale_f32"], g["zero_f32"])
+    # end to end: quantise on the GPU, forward on the GPU, compare with the reference's CPU forward
+    Wq, s, z = ops.quantize(dev(W), nbits=nbits, group_size=64, round_zero=(nbits == 4))
+    if nbits in (4, 2):
+        x = dev(g["x_f32"]).half()
+        y = ops.forward(x, Wq, s.half(), z.half(), None, 1024, 1024, 64, nbits)
+        torch.testing.assert_close(y.float().cpu(), torch.from_numpy(g["y_f16"].astype(np.float32)), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+def test_quantize_vs_oracle_half_input(ops, oracle, nbits):
+    # fp16 weights (the usual checkpoint dtype): `tensor.float()` first (quantize.py:102)
+    W = (torch.randn(512, 1024, generator=torch.Generator().manual_seed(0)) * 0.02).half()
+    o = oracle.quantize(W.float().numpy(), nbits=nbits, group_size=64)
+    _check_quant(ops, W.numpy(), nbits, 64, oracle.pack(nbits, o["Wq"]), o["scale"], o["zero"])
+    assert True
+
+
+def test_quantize_full_size_properties(ops):
+    """4096x4096 N(0,0.02^2): levels in range, dequant error sane, round trip through pack."""
+    W = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(0)) * 0.02).half().cuda()
+    for nbits in (4, 3, 2):
+        Wq, s, z, info = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4), return_info=True)
+        U = ops.unpack(nbits, Wq)[: 4096 * 64]
+        assert int(U.max()) <= 2 ** nbits - 1
+        Wd = ops.dequantize(Wq, s.half().reshape(-1), z.half().reshape(-1), 4096, 4096, 64, nbits).float()
+        err = (Wd - W.float()).abs().mean().item()
+        assert err < {4: 0.0016, 3: 0.0035, 2: 0.008}[nbits], err
+        assert 1 <= int(info[0]) <= 20
+        # idempotence of packing: pack(unpack(Wq)) == Wq
+        assert torch.equal(ops.pack(nbits, U), Wq)
+        # no-optimize path = plain min/max rounding, and it must be worse or equal in L1 error
+        Wq0, s0, z0 = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4), optimize=False)
+        Wd0 = ops.dequantize(Wq0, s0.half().reshape(-1), z0.half().reshape(-1), 4096, 4096, 64, nbits).float()
+        assert (Wd0 - W.float()).abs().pow(0.7).mean() >= (Wd - W.float()).abs().pow(0.7).mean()
