@@ -25,6 +25,9 @@ SYMBOLS = {
     "hqq_hip_unpack": (_i32, [_i32, _vp, _i64, _i64, _vp, _i32, _vp]),
     "hqq_hip_dequantize": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "hqq_hip_set_gemv_mode": (_i32, [_i32]),
+    "hqq_hip_get_gemv_mode": (_i32, []),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_quantize_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -1,4 +1,6 @@
-// gemv.hip — fused unpack -> dequantize -> GEMV for decode-shaped HQQLinear.forward (M <= 8), gfx950.
+// gemv.hip — C entry points of the fused decode path (hqq_hip_gemv / hqq_hip_gemv_grouped) and the *factored* dot2 kernel
+// (mode HQQ_GEMV_FACTORED, and the fallback for K % 64 != 0).  The default kernel is the exact-weights MFMA one in
+// gemv_mfma.hip.
 //
 // Replaces, for axis=1 layers, the reference's per-call chain
 //   BitPack.unpack_*  -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
@@ -9,50 +11,134 @@
 //   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
 //   scale  [N*G] , zero [N*G] in the compute dtype, G = K/group_size; row n uses [n*G, (n+1)*G)
 //
-// Work decomposition: one wave streams one packed row (K bytes -> `per` output rows) with coalesced
-// 16-byte-per-lane non-temporal loads (1 KiB per wave instruction); x is staged once per workgroup in
-// LDS in the order the nibble extraction produces values; scale/zero are fetched per 16-element lane
-// chunk (4 lanes share a 64-wide group, the loads coalesce in the TA).  Each lane keeps per*M fp32
-// accumulators; one wave reduction per packed row at the end.  No inter-wave communication.
+// Launch shape: a *group* of up to GV_MAXL layers that read the same activation rows (q/k/v, gate/up, or
+// a single layer) is one launch.  Their packed rows form one concatenated row space that a persistent
+// grid (<= 2 workgroups per CU, 8 waves each) strides over; one wave owns one packed row (-> `per`
+// output rows) at a time and walks it in 4 KiB units (4 x global_load_dwordx4 per lane, non-temporal).
+// The loads of unit i+1 are issued before unit i is consumed, and the very first unit is requested
+// before x is staged, so every wave keeps 4-8 KiB of the weight stream in flight.
+//   x       staged once per workgroup in LDS, in the order the nibble extraction produces values
+//   meta    per unit the (zero, scale) of the <= 64 groups it spans are fetched with one coalesced
+//           2-byte load per lane and slab and handed to the consuming lanes with ds_bpermute
+//           (group_size 64; other group sizes fetch per lane)
+// Each lane keeps per*M fp32 accumulators; one wave reduction per packed row.  No inter-wave traffic.
 //
-// Numerics: the weight is rebuilt exactly as Quantizer.dequantize does it — w = round(round(q - z) * s)
-// in the compute dtype, two packed-fp16 instructions for two weights — then accumulated in fp32 with
-// v_dot2_f32_f16.  The dequantised weights are therefore bit-identical to hqq_hip_dequantize / the
-// reference; only the fp32 summation order differs from a BLAS.
+// Numerics.  gfx950 issues packed-fp16 / dot2 / three-operand VALU at half the v_fma_f32 rate (measured with
+// tools/instr_bench.hip), so rebuilding every weight as round(round(q - z) * s) (5 such ops per weight pair) is
+// VALU-bound at ~6 TB/s before any other instruction.  The kernel therefore factors the group affine map out of the
+// dot product:   sum_k x_k (q_k - z) s  =  (s/F) * ( sum_k x_k (1024 + F q_k)  -  (1024 + F z) * sum_k x_k )
+// where 1024 + F q_k is the fp16 number obtained by OR-ing the exponent 0x6400 onto the masked nibble (F = 2^shift of
+// the slab) — one v_and_or_b32 + one v_dot2 per weight pair — and sum_k x_k per 16-k lane chunk is precomputed when x is
+// staged.  Everything after the nibble is fp32.  The result equals the exact-arithmetic product of x with the
+// *unrounded* affine weights (q - z) s; it differs from HQQBackend.PYTORCH (which rounds each weight to fp16 twice
+// before an fp32-accumulating GEMM) by less than that backend's own weight-rounding noise (tests: rtol = atol = 1e-3
+// against the oracle; one-hot probes within 1 fp16 ulp of hqq_hip_dequantize).
+#include <type_traits>
+
 #include "hqq_common.h"
 
 namespace hqq {
 
-constexpr int GEMV_WAVES = 8;              // waves per workgroup (512 threads)
-constexpr int GEMV_KSTEP = 1024;           // k covered by one wave instruction: 64 lanes x 16 bytes
-constexpr int GEMV_LDS_HALFS = 32768;      // x staging budget per workgroup: 64 KiB
+#ifndef GV_WAVES_PER_WG
+#define GV_WAVES_PER_WG 8
+#endif
+#ifndef GV_WG_PER_CU
+#define GV_WG_PER_CU 2
+#endif
+constexpr int GV_WAVES = GV_WAVES_PER_WG;  // waves per workgroup (512 threads)
+constexpr int GV_KSTEP = 1024;            // k covered by one wave load instruction: 64 lanes x 16 bytes
+constexpr int GV_U = 4;                   // load instructions per unit
+constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
+constexpr int GV_MAXL = HQQ_GEMV_MAX_GROUP;
+constexpr int GV_LDS_MAX = 144 * 1024;    // x staging budget per workgroup
+constexpr int GV_EXACT_ROWWISE_MAX_M = 4;  // EXACT mode: 2*per MFMAs per x row and KiB; beyond this the tile kernel (gemv_mfma.hip) takes over
 
-__device__ __forceinline__ float wave_sum(float v) {
+// Kernel arguments, structure-of-arrays so that one batch of scalar loads fetches every layer's fields and the current
+// layer is picked with scalar selects (a dependent descriptor load costs ~500 cycles of pure latency per row otherwise).
+struct GvArgs {
+  const uint8_t* Wq[GV_MAXL];
+  const half_t* scale[GV_MAXL];
+  const half_t* zero[GV_MAXL];
+  const half_t* bias[GV_MAXL];
+  half_t* y[GV_MAXL];
+  int N[GV_MAXL];          // out_features
+  int prow_end[GV_MAXL];   // end (exclusive) of layer i's packed rows in the group's concatenated row space;
+                           // unused entries repeat the last layer
+  const half_t* x;
+  int K, gs, total_prow;
+#ifdef GV_LAB_TS
+  unsigned long long* ts;   // lab only: per-wave timestamps
+#endif
+};
+
+// the layer a wave is currently streaming (all wave-uniform -> SGPRs)
+struct LayerCtx {
+  const uint8_t* Wq;
+  const half_t* scale;
+  const half_t* zero;
+  const half_t* bias;
+  half_t* y;
+  int N, row0, end;
+};
+
+__device__ __forceinline__ LayerCtx select_layer(const GvArgs& a, int prow) {
+  LayerCtx c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], 0, a.prow_end[0]};
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  for (int i = 1; i < GV_MAXL; ++i) {
+    const bool in = prow >= a.prow_end[i - 1];   // entries past the last layer repeat it: never true for prow < total
+    c.Wq = in ? a.Wq[i] : c.Wq;
+    c.scale = in ? a.scale[i] : c.scale;
+    c.zero = in ? a.zero[i] : c.zero;
+    c.bias = in ? a.bias[i] : c.bias;
+    c.y = in ? a.y[i] : c.y;
+    c.N = in ? a.N[i] : c.N;
+    c.row0 = in ? a.prow_end[i - 1] : c.row0;
+    c.end = in ? a.prow_end[i] : c.end;
+  }
+  return c;
+}
+
+// sum over the 64 lanes, result valid in every lane: four DPP adds inside each row of 16, then the four row totals
+// through SGPRs.  No LDS traffic (a ds_bpermute butterfly costs ~100 cycles of latency per step).
+__device__ __forceinline__ float wave_sum(float v) {
+  auto dpp_add = [](float x, auto ctrl) {
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(float, y);
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 
-// integer levels of slab S for the byte pairs (b0,b2) [odd=0] / (b1,b3) [odd=1] of one packed dword,
-// returned as exact fp16 values.  (word & mask) | 0x6400 is the fp16 number 1024 + q*2^sh; one packed
-// fma removes the bias exactly.
+// biased levels of slab S for the byte pairs (b0,b2) [word] / (b1,b3) [word >> 8] of one packed dword: the fp16 pair
+// (1024 + F q, 1024 + F q'), F = 2^shift(S) — the masked nibbles OR-ed onto the exponent 0x6400, one VALU op.
 template <int NBITS, int S>
-__device__ __forceinline__ half2_t levels(uint32_t word_or_shifted) {
+__device__ __forceinline__ half2_t biased_levels(uint32_t word_or_shifted, uint32_t magic /* 0x64006400 held in a VGPR */) {
   constexpr int per = 8 / NBITS;
   constexpr int sh = NBITS * (per - 1 - S);
   constexpr uint32_t m1 = ((NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u)) << sh;
   constexpr uint32_t m = m1 | (m1 << 16);
-  const half2_t biased = as_h2((word_or_shifted & m) | 0x64006400u);
-  constexpr float inv = 1.0f / static_cast<float>(1 << sh);
-  const half2_t a = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
-  const half2_t b = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
-  return __builtin_elementwise_fma(biased, a, b);
+  uint32_t b;
+  // hipcc emits v_and + v_or for (w & m) | magic (GFX9 VOP3 takes no literals); the mask rides in an SGPR here
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(word_or_shifted), "s"(m), "v"(magic));
+  return as_h2(b);
 }
+template <int NBITS, int S> struct SlabF {   // F and 1/F of slab S
+  static constexpr int sh = NBITS * (8 / NBITS - 1 - S);
+  static constexpr float F = static_cast<float>(1 << sh);
+  static constexpr float invF = 1.0f / static_cast<float>(1 << sh);
+};
 
-// x staging order: lane chunk of 16 k-values is kept as two 16-byte planes (conflict-free ds_read_b128);
-// inside a plane the 8 halfs are (k0,k2,k1,k3,k4,k6,k5,k7) so that half2 j pairs with levels<>(.., odd=j&1).
+// x staging order: a lane's chunk of 16 k-values is kept as two 16-byte planes (conflict-free ds_read_b128);
+// inside a plane the 8 halfs are (k0,k2,k1,k3,k4,k6,k5,k7) so that half2 j pairs with the levels<> of byte pair j.
 __device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
   u32x4 r;
   r.x = (v.x & 0xFFFFu) | (v.y << 16);
@@ -62,183 +148,493 @@ __device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
   return r;
 }
 
+// one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
 template <int NBITS, int M, int S, int PER>
 struct SlabLoop {
-  static __device__ __forceinline__ void run(const u32x4& w, const half2_t (&zz)[PER], const half2_t (&ss)[PER],
-                                             const half2_t (&xr)[M][8], float (&acc)[M][PER]) {
+  static __device__ __forceinline__ void run(const u32x4& w, const float (&c1)[PER], const float (&c2)[PER], const half2_t (&xr)[M][8],
+                                             const float (&xsum)[M], float (&acc)[M][PER], uint32_t magic) {
+    float dot[M][2];   // two chains per row: v_dot2 results are needed ~8 cycles after issue
+#pragma unroll
+    for (int m = 0; m < M; ++m) dot[m][0] = dot[m][1] = 0.f;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const uint32_t word = w[d];
-      const half2_t q0 = levels<NBITS, S>(word);        // bytes (4d+0, 4d+2)
-      const half2_t q1 = levels<NBITS, S>(word >> 8);   // bytes (4d+1, 4d+3)
-      const half2_t w0 = (q0 - zz[S]) * ss[S];          // two roundings, as Quantizer.dequantize
-      const half2_t w1 = (q1 - zz[S]) * ss[S];
+      const half2_t q0 = biased_levels<NBITS, S>(word, magic);        // bytes (4d+0, 4d+2)
+      const half2_t q1 = biased_levels<NBITS, S>(word >> 8, magic);   // bytes (4d+1, 4d+3)
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        acc[m][S] = __builtin_amdgcn_fdot2(w0, xr[m][2 * d], acc[m][S], false);
-        acc[m][S] = __builtin_amdgcn_fdot2(w1, xr[m][2 * d + 1], acc[m][S], false);
+        dot[m][0] = __builtin_amdgcn_fdot2(q0, xr[m][2 * d], dot[m][0], false);
+        dot[m][1] = __builtin_amdgcn_fdot2(q1, xr[m][2 * d + 1], dot[m][1], false);
       }
     }
-    if constexpr (S + 1 < PER) SlabLoop<NBITS, M, S + 1, PER>::run(w, zz, ss, xr, acc);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      acc[m][S] = __builtin_fmaf(c1[S], __builtin_fmaf(-c2[S], xsum[m], dot[m][0] + dot[m][1]), acc[m][S]);
+    if constexpr (S + 1 < PER) SlabLoop<NBITS, M, S + 1, PER>::run(w, c1, c2, xr, xsum, acc, magic);
   }
 };
 
-template <int NBITS, int M>
-__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_f16_kernel(
-    const half_t* __restrict__ x, const uint8_t* __restrict__ Wq, const half_t* __restrict__ scale,
-    const half_t* __restrict__ zero, const half_t* __restrict__ bias, half_t* __restrict__ y,
-    int N, int K, int gs, int n_prow, int kc /* k staged per pass, multiple of GEMV_KSTEP */) {
+// EXACT mode: the lane's 16 weights of slab S are rebuilt exactly as Quantizer.dequantize does (two fp16 roundings, 4 packed
+// ops per pair) and contracted on the matrix core.  With all 64 lanes holding the SAME output row, lane l = (i = l & 15,
+// o = l >> 4) supplies row i / k-octet o of the A operand and column i / k-octet o of the B operand (its own 8 x-values):
+// D[i][i] is then the partial dot product of the four lanes {i + 16 o}, and the row's result is the sum of the diagonal.
+// 15/16 of the MFMA's flops are discarded — the matrix pipe is idle otherwise — but no VALU slot is spent on the dot
+// product, which keeps the kernel under the VALU ceiling (see gemv_mfma.hip for the rates).
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+template <int NBITS, int M, int S, int PER>
+struct SlabExact {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const h8_t (&b0)[M], const h8_t (&b1)[M],
+                                             f32x4 (&acc)[M][PER], uint32_t magic) {
+    constexpr int sh = NBITS * (PER - 1 - S);
+    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+    const half2_t k1 = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
+    const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
+    const half2_t pr = as_h2(zs[S]);
+    const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const half2_t q0 = __builtin_elementwise_fma(biased_levels<NBITS, S>(w[d], magic), k1, k2);        // bytes (4d+0, 4d+2)
+      const half2_t q1 = __builtin_elementwise_fma(biased_levels<NBITS, S>(w[d] >> 8, magic), k1, k2);   // bytes (4d+1, 4d+3)
+      o[2 * d] = __builtin_bit_cast(uint32_t, (q0 - zz) * ss);
+      o[2 * d + 1] = __builtin_bit_cast(uint32_t, (q1 - zz) * ss);
+    }
+    const h8_t a0 = __builtin_bit_cast(h8_t, u32x4{o[0], o[1], o[2], o[3]});
+    const h8_t a1 = __builtin_bit_cast(h8_t, u32x4{o[4], o[5], o[6], o[7]});
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[m], acc[m][S], 0, 0, 0);
+      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[m], acc[m][S], 0, 0, 0);
+    }
+    if constexpr (S + 1 < PER) SlabExact<NBITS, M, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
+  }
+};
+
+template <int NBITS, int S, int PER>
+struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the raw fp16 bit patterns
+  static __device__ __forceinline__ void run(const uint16_t* z, const uint16_t* sc, float (&c1)[PER], float (&c2)[PER]) {
+    const float zf = static_cast<float>(__builtin_bit_cast(half_t, z[S]));
+    const float sf = static_cast<float>(__builtin_bit_cast(half_t, sc[S]));
+    c1[S] = sf * SlabF<NBITS, S>::invF;
+    c2[S] = __builtin_fmaf(zf, SlabF<NBITS, S>::F, 1024.0f);
+    if constexpr (S + 1 < PER) GroupConst<NBITS, S + 1, PER>::run(z, sc, c1, c2);
+  }
+};
+
+// everything a wave has in flight for one unit: GV_U x 16 bytes of packed weights per lane + the unit's meta
+template <int PER, bool GS64>
+struct Unit {
+  u32x4 w[GV_U];
+  // raw 2-byte loads, combined only when consumed (combining at issue time would wait on the loads)
+  // GS64: z[s], sc[s] = zero / scale of group (unit's first group + lane) of slab s
+  // else: z[u * PER + s], sc[..] = those of the group the lane's own 16 k-values of load u fall into
+  uint16_t z[GS64 ? PER : GV_U * PER];
+  uint16_t sc[GS64 ? PER : GV_U * PER];
+};
+
+template <int NBITS, int M, bool GS64, bool EXACT>
+__global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a) {
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][kc/1024][2 planes][64 lanes] x 16 B
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = K / gs;
-  const int rows_per_slab = N / PER;
-  const int tiles = (n_prow + GEMV_WAVES - 1) / GEMV_WAVES;
-  const int nchunk = (K + kc - 1) / kc;
-  const int planes_per_m = (kc / GEMV_KSTEP) * 2 * 64;
+#ifdef GV_LAB_TS
+  unsigned long long t_[8];
+  t_[0] = __builtin_readcyclecounter();
+#define GV_TS(i) t_[i] = __builtin_readcyclecounter();
+#else
+#define GV_TS(i)
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the row bookkeeping in SGPRs
+  const int K = a.K, gs = a.gs, G = K / gs;
+  const int nsteps = (K + GV_KSTEP - 1) / GV_KSTEP;   // wave load instructions per row
+  const int nunits = (nsteps + GV_U - 1) / GV_U;
+  const int planes_per_m = nsteps * 2 * 64;
+  const int stride = gridDim.x * GV_WAVES;
+  const int total = a.total_prow;
 
-  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int pr = tile * GEMV_WAVES + wave;
-    const bool row_ok = pr < n_prow;
-    float acc[M][PER];
+  // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
+  // them: the wait for one unit is then an exact s_waitcnt vmcnt(<loads of the following unit>), never vmcnt(0).
+  // Past the end of the row space the loads are redirected to the first bytes of the wave's last row (cache hits).
+  auto issue = [&](Unit<PER, GS64>& un, const LayerCtx& c, int prow, int unit, bool live) {
+    const int p = prow - c.row0;                               // packed row inside the layer
+    const int rows_per_slab = c.N / PER;
+    const uint8_t* wrow = c.Wq + static_cast<int64_t>(p) * K;
+    // meta first: the consumer needs it before the first weight vector (loads return in issue order)
+    if constexpr (GS64) {
+      int g = unit * (GV_UNIT / 64) + lane;
+      g = (live && g < G) ? g : 0;
 #pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int s = 0; s < PER; ++s) acc[m][s] = 0.f;
-
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const int kb = ch * kc;
-      // ---- stage x[:, kb : kb+kc] into LDS (once per workgroup when K fits one chunk) ----
-      if (nchunk > 1 || tile == static_cast<int>(blockIdx.x)) {
-        if (nchunk > 1) __syncthreads();   // previous chunk fully consumed
-        const int vec_per_m = kc / 8;
-        for (int v = tid; v < M * vec_per_m; v += GEMV_WAVES * 64) {
-          const int m = v / vec_per_m, j = v - m * vec_per_m;
-          const int k = kb + j * 8;
-          u32x4 val = {0u, 0u, 0u, 0u};
-          if (k < K) val = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(m) * K + k);
-          const int it = j >> 7, rem = j & 127, ln = rem >> 1, h = rem & 1;
-          xs[m * planes_per_m + (it * 2 + h) * 64 + ln] = permute_x8(val);
-        }
-        __syncthreads();
+      for (int s = 0; s < PER; ++s) {
+        const int64_t r = static_cast<int64_t>(p + s * rows_per_slab) * G + g;
+        un.z[s] = __builtin_bit_cast(uint16_t, c.zero[r]);
+        un.sc[s] = __builtin_bit_cast(uint16_t, c.scale[r]);
       }
-      if (!row_ok) continue;
-      const uint8_t* wrow = Wq + static_cast<int64_t>(pr) * K;
-      const int nit = (min(K - kb, kc) + GEMV_KSTEP - 1) / GEMV_KSTEP;
-      constexpr int U = 4;
-      for (int it0 = 0; it0 < nit; it0 += U) {
-        u32x4 w[U];
-        half_t zr[U][PER], sc[U][PER];
-        bool ok[U];
+    } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k0 = kb + (it0 + u) * GEMV_KSTEP + lane * 16;
-          ok[u] = (it0 + u < nit) && (k0 < K);
-          if (ok[u]) {
-            w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0));
-            const int g = k0 / gs;
+      for (int u = 0; u < GV_U; ++u) {
+        int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
+        k0 = (live && k0 < K) ? k0 : 0;
+        const int g = k0 / gs;
 #pragma unroll
-            for (int s = 0; s < PER; ++s) {
-              const int64_t r = static_cast<int64_t>(pr + s * rows_per_slab) * G + g;
-              zr[u][s] = zero[r];
-              sc[u][s] = scale[r];
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!ok[u]) continue;
-          half2_t xr[M][8];
-#pragma unroll
-          for (int m = 0; m < M; ++m) {
-            const u32x4 a = xs[m * planes_per_m + ((it0 + u) * 2 + 0) * 64 + lane];
-            const u32x4 b = xs[m * planes_per_m + ((it0 + u) * 2 + 1) * 64 + lane];
-            xr[m][0] = as_h2(a.x); xr[m][1] = as_h2(a.y); xr[m][2] = as_h2(a.z); xr[m][3] = as_h2(a.w);
-            xr[m][4] = as_h2(b.x); xr[m][5] = as_h2(b.y); xr[m][6] = as_h2(b.z); xr[m][7] = as_h2(b.w);
-          }
-          half2_t zz[PER], ss[PER];
-#pragma unroll
-          for (int s = 0; s < PER; ++s) { zz[s] = half2_t{zr[u][s], zr[u][s]}; ss[s] = half2_t{sc[u][s], sc[u][s]}; }
-          SlabLoop<NBITS, M, 0, PER>::run(w[u], zz, ss, xr, acc);
+        for (int s = 0; s < PER; ++s) {
+          const int64_t r = static_cast<int64_t>(p + s * rows_per_slab) * G + g;
+          un.z[u * PER + s] = __builtin_bit_cast(uint16_t, c.zero[r]);
+          un.sc[u * PER + s] = __builtin_bit_cast(uint16_t, c.scale[r]);
         }
       }
     }
-    // ---- one wave reduction per output row; lane 0 writes ----
 #pragma unroll
-    for (int m = 0; m < M; ++m)
+    for (int u = 0; u < GV_U; ++u) {
+      // lanes past K (last step of a row) and whole steps past the row re-read the row start: their x is zero in LDS
+      // (and its chunk sum), so they add exactly 0
+      int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
+      k0 = (live && k0 < K) ? k0 : 0;
+      un.w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0));
+    }
+  };
+
+  // ---- first unit of this wave's first row goes out before anything else ----
+  int prow = blockIdx.x * GV_WAVES + wave;
+  int unit = 0;
+  // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
+  LayerCtx lc = select_layer(a, prow < total ? prow : total - 1);
+  Unit<PER, GS64> ua, ub;
+  issue(ua, lc, prow < total ? prow : total - 1, 0, prow < total);
+  GV_TS(1)
+
+  // ---- stage x[M, K] into LDS once per workgroup: two permuted 16-byte planes + the fp32 sum per 16-k lane chunk ----
+  float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64]
+  {
+    const int chunks_per_m = nsteps * 64;
+    for (int c = tid; c < M * chunks_per_m; c += GV_WAVES * 64) {
+      const int m = c / chunks_per_m, j = c - m * chunks_per_m;   // j = step * 64 + lane
+      const int k = j * 16;
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+      if (k < K) {   // K % 16 == 0
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + k);
+        v0 = src[0];
+        v1 = src[1];
+      }
+      float sum = 0.f;
 #pragma unroll
-      for (int s = 0; s < PER; ++s) {
-        const float v = wave_sum(acc[m][s]);
-        if (lane == 0 && row_ok) {
-          const int n = pr + s * rows_per_slab;
-          half_t o = static_cast<half_t>(v);
-          if (bias) o = o + bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-          y[static_cast<int64_t>(m) * N + n] = o;
+      for (int i = 0; i < 4; ++i) {
+        const half2_t h0 = as_h2(v0[i]), h1 = as_h2(v1[i]);
+        sum += (static_cast<float>(h0.x) + static_cast<float>(h0.y)) + (static_cast<float>(h1.x) + static_cast<float>(h1.y));
+      }
+      const int it = j >> 6, ln = j & 63;
+      xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
+      xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
+      xsum_lds[m * chunks_per_m + j] = sum;
+    }
+    GV_TS(2)
+    __syncthreads();
+    GV_TS(3)
+  }
+
+  // FACTORED: one fp32 partial per (x row, slab); EXACT: one 16x16 MFMA tile (4 VGPRs) per (x row, slab)
+  using acc_t = std::conditional_t<EXACT, f32x4, float>;
+  acc_t acc[M][PER];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int s = 0; s < PER; ++s) {
+      if constexpr (EXACT) acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else acc[m][s] = 0.f;
+    }
+  uint32_t magic;
+  asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));   // opaque to the optimiser: stays in a VGPR
+
+  // `oc` is the layer context the unit was issued under (the issuing side may already have moved to the next layer)
+  auto consume = [&](const Unit<PER, GS64>& cur, const LayerCtx& oc, int prow, int unit) {
+    if constexpr (EXACT) {
+#pragma unroll
+      for (int u = 0; u < GV_U; ++u) {
+        const int step = unit * GV_U + u;
+        uint32_t zs[PER];
+#pragma unroll
+        for (int s = 0; s < PER; ++s) {
+          if constexpr (GS64) {
+            const uint32_t mine = static_cast<uint32_t>(cur.z[s]) | (static_cast<uint32_t>(cur.sc[s]) << 16);
+            zs[s] = __builtin_amdgcn_ds_bpermute((u * 16 + (lane >> 2)) << 2, mine);
+          } else {
+            zs[s] = static_cast<uint32_t>(cur.z[u * PER + s]) | (static_cast<uint32_t>(cur.sc[u * PER + s]) << 16);
+          }
+        }
+        if (step < nsteps) {
+          h8_t b0[M], b1[M];
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            b0[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (step * 2 + 0) * 64 + lane]);
+            b1[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (step * 2 + 1) * 64 + lane]);
+          }
+          // lanes past K see zero x (padded in LDS) and a finite re-read weight: they add exactly 0
+          SlabExact<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
         }
       }
+    } else {
+    float c1o[PER], c2o[PER];   // GS64: constants of the group this lane fetched (unit's first group + lane)
+    if constexpr (GS64) GroupConst<NBITS, 0, PER>::run(cur.z, cur.sc, c1o, c2o);
+#pragma unroll
+    for (int u = 0; u < GV_U; ++u) {
+      const int step = unit * GV_U + u;
+      float c1[PER], c2[PER];
+      if constexpr (GS64) {
+        const int src = (u * 16 + (lane >> 2)) << 2;   // the lane that fetched this lane's group
+#pragma unroll
+        for (int s = 0; s < PER; ++s) {
+          c1[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c1o[s])));
+          c2[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c2o[s])));
+        }
+      } else {
+        GroupConst<NBITS, 0, PER>::run(cur.z + u * PER, cur.sc + u * PER, c1, c2);
+      }
+      if (step < nsteps) {
+        half2_t xr[M][8];
+        float xsum[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const u32x4 p0 = xs[m * planes_per_m + (step * 2 + 0) * 64 + lane];
+          const u32x4 p1 = xs[m * planes_per_m + (step * 2 + 1) * 64 + lane];
+          xsum[m] = xsum_lds[(m * nsteps + step) * 64 + lane];
+          xr[m][0] = as_h2(p0.x); xr[m][1] = as_h2(p0.y); xr[m][2] = as_h2(p0.z); xr[m][3] = as_h2(p0.w);
+          xr[m][4] = as_h2(p1.x); xr[m][5] = as_h2(p1.y); xr[m][6] = as_h2(p1.z); xr[m][7] = as_h2(p1.w);
+        }
+        // lanes past K see zero x and zero xsum (padded in LDS) and finite constants: they add exactly 0
+        SlabLoop<NBITS, M, 0, PER>::run(cur.w[u], c1, c2, xr, xsum, acc, magic);
+      }
+    }
+    }
+    // ---- row finished: one wave reduction per output row; lane (m * PER + s) writes its value ----
+    if (unit == nunits - 1) {
+      const int p = prow - oc.row0;
+      const int rows_per_slab = oc.N / PER;
+      float mine = 0.f;
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int s = 0; s < PER; ++s) {
+          float part;
+          if constexpr (EXACT) {
+            // D layout: lane (col j = lane & 15, rows 4 * (lane >> 4) + i); keep the diagonal element, if this lane has one
+            const int i = (lane & 15) - 4 * (lane >> 4);
+            part = i == 0 ? acc[m][s][0] : i == 1 ? acc[m][s][1] : i == 2 ? acc[m][s][2] : i == 3 ? acc[m][s][3] : 0.f;
+            acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            part = acc[m][s];
+            acc[m][s] = 0.f;
+          }
+          const float v = wave_sum(part);
+          mine = (lane == m * PER + s) ? v : mine;
+        }
+      if (lane < M * PER) {
+        const int m = lane / PER, s = lane - m * PER;
+        const int n = p + s * rows_per_slab;
+        half_t o = static_cast<half_t>(mine);
+        if (oc.bias) o = o + oc.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+        oc.y[static_cast<int64_t>(m) * oc.N + n] = o;
+      }
+    }
+  };
+
+  // next unit of this wave: same row, or the wave's next row (re-selecting the layer when the row leaves it)
+  auto advance = [&](int& p, int& u, LayerCtx& c) {
+    if (++u == nunits) {
+      u = 0;
+      p += stride;
+      if (p >= c.end && p < total) c = select_layer(a, p);
+    }
+  };
+
+  // ---- ping-pong over the wave's units: request unit i+1, then consume unit i; no register copies.  The last unit of
+  //      a wave is consumed on its own code path with nothing issued behind it (its wait is then a plain vmcnt(0)). ----
+  LayerCtx la = lc;           // context unit A was issued under
+  if (prow < total) {
+    for (;;) {
+      int p1 = prow, u1 = unit;
+      advance(p1, u1, lc);
+      if (p1 >= total) { consume(ua, la, prow, unit); break; }
+      const LayerCtx lb = lc;   // context unit B is issued under
+      issue(ub, lb, p1, u1, true);
+      GV_TS(4)
+      consume(ua, la, prow, unit);
+      GV_TS(5)
+      int p2 = p1, u2 = u1;
+      advance(p2, u2, lc);
+      if (p2 >= total) { consume(ub, lb, p1, u1); break; }
+      la = lc;
+      issue(ua, la, p2, u2, true);
+      consume(ub, lb, p1, u1);
+      prow = p2;
+      unit = u2;
+    }
   }
+#ifdef GV_LAB_TS
+  GV_TS(6)
+  if (lane == 0 && a.ts) { const int wg = blockIdx.x * GV_WAVES + wave; for (int i = 0; i < 7; ++i) a.ts[wg * 8 + i] = t_[i]; }
+#endif
 }
 
-template <int NBITS, int M>
-static int launch_gemv_f16(const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
-                           int N, int K, int gs, hipStream_t st) {
-  constexpr int PER = 8 / NBITS;
-  const int n_prow = N / PER;
-  const int kpad = (K + GEMV_KSTEP - 1) / GEMV_KSTEP * GEMV_KSTEP;
-  const int kc_max = GEMV_LDS_HALFS / M / GEMV_KSTEP * GEMV_KSTEP;
-  const int kc = kpad < kc_max ? kpad : kc_max;
-  const size_t lds = static_cast<size_t>(M) * kc * 2;
-  const int tiles = (n_prow + GEMV_WAVES - 1) / GEMV_WAVES;
-  const int grid = tiles < 512 ? tiles : 512;
-  hipLaunchKernelGGL((gemv_f16_kernel<NBITS, M>), dim3(grid), dim3(GEMV_WAVES * 64), lds, st,
-                     static_cast<const half_t*>(x), static_cast<const uint8_t*>(Wq), static_cast<const half_t*>(scale),
-                     static_cast<const half_t*>(zero), static_cast<const half_t*>(bias), static_cast<half_t*>(y),
-                     N, K, gs, n_prow, kc);
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) g_num_cus = n;
+    else g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+template <int NBITS, int M, bool GS64, bool EXACT>
+static int launch_gemv_f16(const GvArgs& a, hipStream_t st) {
+  const int nsteps = (a.K + GV_KSTEP - 1) / GV_KSTEP;
+  const size_t lds = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
+  const int tiles = (a.total_prow + GV_WAVES - 1) / GV_WAVES;
+  const int per_cu = lds <= 64 * 1024 ? GV_WG_PER_CU : 1;
+  const int cap = num_cus() * per_cu;
+  const int grid = tiles < cap ? tiles : cap;
+  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;   // per instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GV_LDS_MAX);
+      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(GV_WAVES * 64), lds, st, a);
   return check_launch("hqq_hip_gemv");
 }
 
-template <int NBITS>
-static int dispatch_m(int M, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
-                      int N, int K, int gs, hipStream_t st) {
+template <int NBITS, bool GS64, bool EXACT>
+static int dispatch_m(int M, const GvArgs& a, hipStream_t st) {
   switch (M) {
-    case 1: return launch_gemv_f16<NBITS, 1>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 2: return launch_gemv_f16<NBITS, 2>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 3: return launch_gemv_f16<NBITS, 3>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 4: return launch_gemv_f16<NBITS, 4>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 5: return launch_gemv_f16<NBITS, 5>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 6: return launch_gemv_f16<NBITS, 6>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 7: return launch_gemv_f16<NBITS, 7>(x, Wq, scale, zero, bias, y, N, K, gs, st);
-    case 8: return launch_gemv_f16<NBITS, 8>(x, Wq, scale, zero, bias, y, N, K, gs, st);
+    case 1: return launch_gemv_f16<NBITS, 1, GS64, EXACT>(a, st);
+    case 2: return launch_gemv_f16<NBITS, 2, GS64, EXACT>(a, st);
+    case 3: return launch_gemv_f16<NBITS, 3, GS64, EXACT>(a, st);
+    case 4: return launch_gemv_f16<NBITS, 4, GS64, EXACT>(a, st);
+  }
+  if constexpr (!EXACT) {
+    switch (M) {
+      case 5: return launch_gemv_f16<NBITS, 5, GS64, false>(a, st);
+      case 6: return launch_gemv_f16<NBITS, 6, GS64, false>(a, st);
+      case 7: return launch_gemv_f16<NBITS, 7, GS64, false>(a, st);
+      case 8: return launch_gemv_f16<NBITS, 8, GS64, false>(a, st);
+    }
   }
   return HQQ_ERR_SHAPE;
 }
 
+template <bool EXACT>
+static int dispatch(int nbits, int M, const GvArgs& a, hipStream_t st) {
+  const bool gs64 = a.gs == 64;
+  switch (nbits) {
+    case 8: return dispatch_m<8, false, EXACT>(M, a, st);
+    case 4: return gs64 ? dispatch_m<4, true, EXACT>(M, a, st) : dispatch_m<4, false, EXACT>(M, a, st);
+    case 2: return gs64 ? dispatch_m<2, true, EXACT>(M, a, st) : dispatch_m<2, false, EXACT>(M, a, st);
+    case 1: return dispatch_m<1, false, EXACT>(M, a, st);
+  }
+  return HQQ_ERR_NBITS;
+}
+
+// rows of x one launch can stage (LDS budget); larger M is served by several launches over row blocks of x
+static int max_m_per_launch(int64_t K) {
+  const int64_t nsteps = (K + GV_KSTEP - 1) / GV_KSTEP;
+  const int64_t m = GV_LDS_MAX / (nsteps * (GV_KSTEP * 2 + 64 * 4));
+  return static_cast<int>(m < 1 ? 0 : (m > 8 ? 8 : m));
+}
+
+}  // namespace hqq
+
+namespace hqq {
+int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+                  const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
+static int g_gemv_mode = HQQ_GEMV_EXACT;
 }  // namespace hqq
 
 using namespace hqq;
+#ifdef GV_LAB_TS
+extern unsigned long long* g_lab_ts;
+#endif
+
+extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
+                                    const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
+                                    int64_t M, int64_t K, int64_t group_size, int dtype, void* stream) {
+  if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
+  if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
+  if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
+  if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
+  if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
+  const int per = 8 / nbits;
+  if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
+  if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+  const bool exact = g_gemv_mode == HQQ_GEMV_EXACT;
+  if (exact && M > GV_EXACT_ROWWISE_MAX_M) {
+    // more activation rows than the row-per-wave kernel contracts cheaply: the 16-row-tile MFMA kernel (needs K % 64 == 0)
+    if (K % 64) { set_error("hqq_hip_gemv: M=%lld > %d needs K %% 64 == 0 (got K=%lld)", (long long)M, GV_EXACT_ROWWISE_MAX_M, (long long)K); return HQQ_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n_layers; ++i) {
+      if (N[i] <= 0 || N[i] % per) { set_error("hqq_hip_gemv: needs N %% %d == 0 (got N=%lld)", per, (long long)N[i]); return N[i] <= 0 ? HQQ_ERR_SHAPE : HQQ_ERR_UNSUPPORTED; }
+      if (N[i] * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+      if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
+      if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    }
+    return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
+  }
+  int m_max = max_m_per_launch(K);
+  m_max = m_max > (exact ? GV_EXACT_ROWWISE_MAX_M : 8) ? (exact ? GV_EXACT_ROWWISE_MAX_M : 8) : m_max;
+  if (m_max < 1) { set_error("hqq_hip_gemv: K=%lld too large to stage one row of x in LDS", (long long)K); return HQQ_ERR_UNSUPPORTED; }
+  if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  GvArgs a;
+  int64_t total = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    if (N[i] <= 0 || N[i] % per) { set_error("hqq_hip_gemv: needs N %% %d == 0 (got N=%lld)", per, (long long)N[i]); return N[i] <= 0 ? HQQ_ERR_SHAPE : HQQ_ERR_UNSUPPORTED; }
+    if (N[i] * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
+    if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    total += N[i] / per;
+    if (total > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    a.Wq[i] = static_cast<const uint8_t*>(Wq[i]);
+    a.scale[i] = static_cast<const half_t*>(scale[i]);
+    a.zero[i] = static_cast<const half_t*>(zero[i]);
+    a.bias[i] = bias ? static_cast<const half_t*>(bias[i]) : nullptr;
+    a.y[i] = static_cast<half_t*>(y[i]);
+    a.N[i] = static_cast<int>(N[i]);
+    a.prow_end[i] = static_cast<int>(total);
+  }
+  for (int i = n_layers; i < GV_MAXL; ++i) {
+    a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
+    a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.prow_end[i] = a.prow_end[n_layers - 1];
+  }
+  a.K = static_cast<int>(K);
+  a.gs = static_cast<int>(group_size);
+  a.total_prow = static_cast<int>(total);
+#ifdef GV_LAB_TS
+  a.ts = g_lab_ts;
+#endif
+  hipStream_t st = as_stream(stream);
+  // x rows beyond the LDS budget of one launch are served by further launches over row blocks of x / y
+  for (int64_t m0 = 0; m0 < M; m0 += m_max) {
+    const int mm = static_cast<int>(M - m0 < m_max ? M - m0 : m_max);
+    GvArgs b = a;
+    b.x = static_cast<const half_t*>(x) + m0 * K;
+    for (int i = 0; i < GV_MAXL; ++i) b.y[i] = a.y[i] + m0 * a.N[i];
+    const int rc = exact ? dispatch<true>(nbits, mm, b, st) : dispatch<false>(nbits, mm, b, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int hqq_hip_set_gemv_mode(int mode) {
+  if (mode != HQQ_GEMV_EXACT && mode != HQQ_GEMV_FACTORED) { set_error("hqq_hip_set_gemv_mode: unknown mode %d", mode); return HQQ_ERR_SHAPE; }
+  g_gemv_mode = mode;
+  return 0;
+}
+extern "C" int hqq_hip_get_gemv_mode(void) { return g_gemv_mode; }
 
 extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                             void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream) {
-  if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
-  if (N <= 0 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad N/K/group_size"); return HQQ_ERR_SHAPE; }
-  if (N > INT32_MAX || K > INT32_MAX || N * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
-  if (!aligned16(x) || !aligned16(Wq) || !aligned16(y)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-  if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
-  const int per = 8 / nbits;
-  if (N % per || group_size % 16 || K % 16) {
-    set_error("hqq_hip_gemv: needs N %% %d == 0, group_size %% 16 == 0 (got N=%lld gs=%lld)", per, (long long)N, (long long)group_size);
-    return HQQ_ERR_UNSUPPORTED;
-  }
-  if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
-  hipStream_t st = as_stream(stream);
-  const int n = static_cast<int>(N), k = static_cast<int>(K), gs = static_cast<int>(group_size), m = static_cast<int>(M);
-  switch (nbits) {
-    case 8: return dispatch_m<8>(m, x, Wq, scale, zero, bias, y, n, k, gs, st);
-    case 4: return dispatch_m<4>(m, x, Wq, scale, zero, bias, y, n, k, gs, st);
-    case 2: return dispatch_m<2>(m, x, Wq, scale, zero, bias, y, n, k, gs, st);
-    case 1: return dispatch_m<1>(m, x, Wq, scale, zero, bias, y, n, k, gs, st);
-  }
-  return HQQ_ERR_NBITS;
+  const void* b1[1] = {bias};
+  return hqq_hip_gemv_grouped(nbits, 1, x, &Wq, &scale, &zero, bias ? b1 : nullptr, &y, &N, M, K, group_size, dtype, stream);
 }

@@ -17,7 +17,9 @@ _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.uint8
 PER = {8: 1, 4: 2, 2: 4, 1: 8, 3: 10}
 # Quantizer.bit_to_packing (hqq/core/quantize.py:40-49): container width per nbits
 PACK_BITS = {8: 8, 6: 8, 5: 8, 4: 4, 3: 3, 2: 2, 1.58: 2, 1: 1}
-GEMV_MAX_M = 8
+GEMV_MAX_M = 16
+GEMV_EXACT, GEMV_FACTORED = 0, 1
+GEMV_MAX_GROUP = 4
 
 
 def is_available() -> bool:
@@ -48,6 +50,15 @@ def _stream() -> int:
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def set_gemv_mode(mode: int) -> None:
+    """GEMV_EXACT (default): reference-identical weights on the MFMA path; GEMV_FACTORED: fp32-factored dot2 path."""
+    _C.check(_C.lib().hqq_hip_set_gemv_mode(int(mode)), "hqq_hip_set_gemv_mode")
+
+
+def get_gemv_mode() -> int:
+    return int(_C.lib().hqq_hip_get_gemv_mode())
 
 
 def packed_rows(nbits: int, rows: int) -> int:
@@ -121,6 +132,37 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
 def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
     """fused unpack->dequant->GEMV, 1 <= M <= 8 (decode)."""
     return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+
+
+def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=None):
+    """Horizontal fusion: one launch for up to GEMV_MAX_GROUP layers that consume the same x (q/k/v, gate/up, ...).
+    layers: sequence of (W_q, scale, zero, bias_or_None, N).  Returns the list of outputs [*, N_i]."""
+    import ctypes
+    n = len(layers)
+    if not 1 <= n <= GEMV_MAX_GROUP:
+        raise ValueError(f"hqq_amd: a GEMV group holds 1..{GEMV_MAX_GROUP} layers, got {n}")
+    if x.shape[-1] != K:
+        raise ValueError(f"hqq_amd: x has {x.shape[-1]} features, layers expect {K}")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    for (W_q, s, z, b, N) in layers:
+        _dev(x, W_q, s, z, b)
+        if x.dtype != s.dtype or z.dtype != s.dtype or (b is not None and b.dtype != s.dtype):
+            raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
+    if outs is None:
+        outs = [torch.empty((M, L[4]), dtype=x.dtype, device=x.device) for L in layers]
+    if M > 0:
+        VP = ctypes.c_void_p * n
+        has_bias = any(L[3] is not None for L in layers)
+        with torch.cuda.device(x.device):
+            rc = _C.lib().hqq_hip_gemv_grouped(
+                nbits, n, _p(x2), VP(*[_p(L[0]) for L in layers]), VP(*[_p(L[1]) for L in layers]), VP(*[_p(L[2]) for L in layers]),
+                VP(*[_p(L[3]) for L in layers]) if has_bias else None, VP(*[_p(o) for o in outs]),
+                (ctypes.c_int64 * n)(*[int(L[4]) for L in layers]), M, K, group_size, _dt(x.dtype), _stream())
+        _C.check(rc, "hqq_hip_gemv_grouped")
+    return [o.reshape(*x.shape[:-1], L[4]) for o, L in zip(outs, layers)]
 
 
 def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:

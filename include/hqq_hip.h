@@ -81,9 +81,26 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * Covered: nbits in {4,2} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0,
  * dtype F16/BF16 -> otherwise HQQ_ERR_UNSUPPORTED (the caller may compose dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
-#define HQQ_GEMV_MAX_M 8
+#define HQQ_GEMV_MAX_M 16
+#define HQQ_GEMV_MAX_GROUP 4
 int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+/* Horizontal fusion of up to HQQ_GEMV_MAX_GROUP layers that consume the SAME activation rows x[M,K] (q/k/v, gate/up,
+ * experts of one token ...): one launch streams all their packed rows; layer i writes y[i][M, N[i]].  Every per-layer
+ * argument is a host array of n_layers device pointers / sizes (read during the call, not kept); bias may be NULL or
+ * hold NULL entries.  All layers share K, group_size, nbits and dtype.  hqq_hip_gemv is the n_layers = 1 case.
+ * (The reference has no counterpart: HQQLinear.forward is per layer, quantize.py:880-898.) */
+int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
+                         const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
+                         int64_t M, int64_t K, int64_t group_size, int dtype, void* stream);
+/* Arithmetic of the decode path (process-wide, not thread-safe; set it before launching work):
+ *   HQQ_GEMV_EXACT    (default) every weight is rebuilt as round16(round16(q - z) * s) — bit-identical to
+ *                     hqq_hip_dequantize / Quantizer.dequantize — and contracted on the matrix cores with fp32 accumulation.
+ *   HQQ_GEMV_FACTORED the group affine map is factored out of the dot product and applied in fp32 (no per-weight fp16
+ *                     rounding; results differ from the reference by less than its own weight-rounding noise). M <= 8. */
+enum { HQQ_GEMV_EXACT = 0, HQQ_GEMV_FACTORED = 1 };
+int hqq_hip_set_gemv_mode(int mode);
+int hqq_hip_get_gemv_mode(void);
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,

@@ -48,26 +48,63 @@ def gemv_bytes(N, K, nbits, M=1, gs=64):
     return wq + 4 * (N * K // gs) + 2 * K * M + 2 * N * M
 
 
-def bench_gemv():
-    print("== fused dequant-GEMV, fp16, gs=64 (pool > 256 MiB, back-to-back on one stream) ==")
-    for nbits in (4, 2):
-        for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096), (8192, 8192), (28672, 8192)]:
-            for M in (1, 4):
+def graph_time(fn_sweep, n_calls, reps=5):
+    """device time per call of a sweep captured in one hipGraph (no host launch overhead in the number)"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn_sweep()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn_sweep()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / (reps * n_calls)
+
+
+def bench_gemv(nbits_list=(4, 2), shapes=None, Ms=(1, 4)):
+    print("== fused dequant-GEMV, fp16, gs=64 (pool > 256 MiB, back-to-back in one hipGraph) ==")
+    shapes = shapes or [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (22016, 4096), (8192, 8192), (28672, 8192)]
+    for nbits in nbits_list:
+        for (N, K) in shapes:
+            for M in Ms:
                 nbytes = gemv_bytes(N, K, nbits, M)
                 pool_n = max(4, int(600e6 / nbytes) + 1)
                 pool = [rand_layer(N, K, nbits) for _ in range(pool_n)]
                 x = torch.randn(M, K, device="cuda", dtype=torch.float16)
                 y = torch.empty(M, N, device="cuda", dtype=torch.float16)
-                idx = [0]
 
-                def run():
-                    Wq, s, z = pool[idx[0] % pool_n]
-                    idx[0] += 1
-                    ops.gemv(x, Wq, s, z, None, N, K, 64, nbits, out=y)
+                def sweep():
+                    for (Wq, s, z) in pool:
+                        ops.gemv(x, Wq, s, z, None, N, K, 64, nbits, out=y)
 
-                t = ev_time(run, 4 * pool_n, warmup=pool_n)
+                t = graph_time(sweep, pool_n)
                 print(f"int{nbits} {N:6d}x{K:<6d} M={M}  {t * 1e6:8.2f} us  {nbytes / t / 1e9:8.1f} GB/s  {nbytes / t / HBM_PEAK * 100:5.1f}% of 8 TB/s  (pool {pool_n})")
                 del pool
+    print("== grouped launches (q|k|v and gate|up read the same x) ==")
+    for nbits in nbits_list:
+        for (n, N, K) in [(3, 4096, 4096), (2, 11008, 4096), (4, 4096, 4096)]:
+            nbytes = n * gemv_bytes(N, K, nbits, 1)
+            pool_n = max(3, int(600e6 / nbytes) + 1)
+            pool = [[rand_layer(N, K, nbits) for _ in range(n)] for _ in range(pool_n)]
+            x = torch.randn(1, K, device="cuda", dtype=torch.float16)
+            ys = [torch.empty(1, N, device="cuda", dtype=torch.float16) for _ in range(n)]
+
+            def sweep():
+                for grp in pool:
+                    ops.gemv_grouped(x, [(Wq, s, z, None, N) for (Wq, s, z) in grp], K, 64, nbits, outs=ys)
+
+            t = graph_time(sweep, pool_n)
+            print(f"int{nbits} {n} x {N}x{K} M=1  {t * 1e6:8.2f} us  {nbytes / t / 1e9:8.1f} GB/s  {nbytes / t / HBM_PEAK * 100:5.1f}% of 8 TB/s  (pool {pool_n})")
+            del pool
 
 
 def bench_gemm():
