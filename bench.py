@@ -175,7 +175,7 @@ def main():
         N = dict((n, nn) for n, nn, _ in LLAMA2_7B_BLOCK)[grp[0]]
         out_local[grp] = torch.empty(len(grp), M, N, device=dev, dtype=torch.float16)
         if world > 1:
-            out_full[grp] = torch.empty(world, len(grp), M, N, device=dev, dtype=torch.float16)
+            out_full[grp] = torch.empty(world * len(grp) * M, N, device=dev, dtype=torch.float16)   # rank-major concatenation
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -194,7 +194,7 @@ def main():
                         L = blk[name]
                         ops.forward(xs[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=ol[j])
                 if world > 1:
-                    dist.all_gather_into_tensor(out_full[grp], ol)
+                    dist.all_gather_into_tensor(out_full[grp], ol.view(len(grp) * M, -1))
 
     # ---- graph capture (launch-bound inner loop -> one hipGraph replay per step) ----
     use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0"

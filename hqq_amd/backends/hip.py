@@ -1,0 +1,75 @@
+"""`prepare_for_inference(model, backend="hip")` target: an inference-only layer that owns exactly what the fused kernels
+read (packed W_q in the reference layout, flat fp16 scale/zero, bias) and launches one HIP kernel per call.
+
+Follows the patch-function contract of the reference's optimised backends (hqq/backends/torchao.py:299-339,
+bitblas.py:174-202, gemlite.py:10-34): unwrap HQQLinearLoRA, return the layer unchanged (with a "Skipping" note) when the
+configuration is not covered, otherwise build the new module, drop the old tensors and return it.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..core.quantize import HQQLinear, Quantizer
+
+
+class HQQLinearHIP(nn.Module):
+    """y = x @ dequantize(W_q)^T (+ bias) through hqq_hip_forward.  Keeps the packed tensor bit-identical to the
+    HQQLinear it was built from, so `state_dict()`-level round trips back to the reference stay possible."""
+
+    def __init__(self, hqq_layer: HQQLinear):
+        super().__init__()
+        m = hqq_layer.meta
+        self.out_features, self.in_features = (int(v) for v in m["shape"])
+        self.nbits = Quantizer._packing_bits[m["packing"]]
+        self.group_size = int(m["group_size"])
+        self.axis = 1
+        self.compute_dtype = hqq_layer.compute_dtype
+        self.device = hqq_layer.device
+        self.name = getattr(hqq_layer, "name", None)
+        W_q = hqq_layer.W_q.data
+        if m["view_as_float"]:
+            W_q = W_q.view(m["unpack_view_dtype"])
+        self.W_q = nn.Parameter(W_q.contiguous(), requires_grad=False)
+        self.register_buffer("scale", m["scale"].reshape(-1).contiguous(), persistent=True)
+        self.register_buffer("zero", m["zero"].reshape(-1).contiguous(), persistent=True)
+        self.bias = None if hqq_layer.bias is None else hqq_layer.bias.to(device=W_q.device, dtype=self.compute_dtype)
+
+    @staticmethod
+    def check(hqq_layer: HQQLinear) -> bool:
+        """configurations the fused kernels cover (the rest keep HQQLinear.forward_hip's dequantise + GEMM)"""
+        m = getattr(hqq_layer, "meta", None)
+        if m is None or not m.get("packing"):
+            return False
+        gs = m["group_size"]
+        N, K = m["shape"]
+        return (m["axis"] == 1 and m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8") and hqq_layer.compute_dtype == torch.float16
+                and bool(gs) and gs % 16 == 0 and K % gs == 0 and N % ops.PER[Quantizer._packing_bits[m["packing"]]] == 0
+                and not m.get("quant_scale") and not m.get("quant_zero") and hqq_layer.W_q.is_cuda)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, nbits={self.nbits}, group_size={self.group_size}"
+
+    def dequantize(self) -> Tensor:
+        return ops.dequantize(self.W_q, self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits, 1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dtype != self.compute_dtype:
+            x = x.to(self.compute_dtype)
+        return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, self.nbits)
+
+
+def patch_hqq_to_hip(layer, patch_params=None):
+    hqq_layer = layer if isinstance(layer, HQQLinear) else getattr(layer, "linear_layer", None)
+    if not isinstance(hqq_layer, HQQLinear):
+        return layer
+    if not HQQLinearHIP.check(hqq_layer):
+        print("Skipping HIP conversion for ", getattr(hqq_layer, "name", None))
+        return layer
+    new = HQQLinearHIP(hqq_layer)
+    del hqq_layer.W_q, hqq_layer.meta, hqq_layer.bias
+    if hqq_layer is layer:
+        return new
+    layer.linear_layer = new   # HQQLinearLoRA-style wrapper keeps its adapters
+    return layer

@@ -1,0 +1,76 @@
+"""Output-column shard of a quantised layer across the GPUs of one node + the RCCL all-gather that completes it.
+
+y[:, n] = sum_k x[:, k] W[n, k]: with axis=1 every quantisation group lies inside one row of W, so the scale / zero / W_q
+values of a row subset are those of the full layer.  Rows n and n + slot*N/per share a packed byte, so
+a rank does not own a contiguous range of output rows but the packed-row block
+    packed rows [r*Np/P, (r+1)*Np/P),  Np = N/per          (a zero-copy slice of the reference W_q)
+i.e. the `per` output slabs  slot*N/per + [r*n', (r+1)*n'),  n' = N/(per*P).  Seen on its own that slice is a complete
+packed layer with N/P rows; the all-gather returns [P, M, N/P] in (rank, slab, n') order, and `unpermute` maps it back.
+3-bit containers mix rows of unrelated slabs (step = ceil(R/10)), so the shard is re-packed from the unpacked rows.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+def shard_rows(N: int, nbits: int, rank: int, world: int) -> Tensor:
+    """global output rows owned by `rank`, in the local row order of its packed slice"""
+    per = 1 if nbits == 3 else ops.PER[nbits]
+    if N % (per * world):
+        raise ValueError(f"out_features={N} cannot be split over {world} ranks at {nbits} bits (needs N % {per * world} == 0)")
+    n1 = N // (per * world)
+    base = torch.arange(n1) + rank * n1
+    return torch.cat([base + slot * (N // per) for slot in range(per)])
+
+
+def shard_packed(W_q: Tensor, scale: Tensor, zero: Tensor, bias, N: int, K: int, group_size: int, nbits: int, rank: int, world: int):
+    """-> (W_q_local, scale_local, zero_local, bias_local, N_local): the rank's self-contained packed layer."""
+    G = K // group_size
+    rows = shard_rows(N, nbits, rank, world).to(scale.device)
+    n_loc = N // world
+    sc = scale.reshape(N, G)[rows].reshape(-1, 1).contiguous()
+    ze = zero.reshape(N, G)[rows].reshape(-1, 1).contiguous()
+    b = None if bias is None else bias[rows].contiguous()
+    if nbits == 3:
+        U = ops.unpack(3, W_q)[: N * G].reshape(N, G * group_size)[rows]
+        Wl = ops.pack(3, U.reshape(n_loc * G, group_size).contiguous())
+    else:
+        per = ops.PER[nbits]
+        prow = (N // per) * G                   # packed rows of the full layer ([prow, group_size] bytes == [N/per, K])
+        p1 = prow // world
+        Wl = W_q.reshape(prow, group_size)[rank * p1:(rank + 1) * p1]   # zero-copy view
+    return Wl, sc, ze, b, n_loc
+
+
+def unpermute(y_gathered: Tensor, N: int, nbits: int, world: int) -> Tensor:
+    """[P, M, N/P] as all-gathered (rank-major, each rank in its local row order) -> [M, N] in global row order"""
+    P, M, n_loc = y_gathered.shape
+    per = 1 if nbits == 3 else ops.PER[nbits]
+    n1 = N // (per * world)
+    return y_gathered.reshape(P, M, per, n1).permute(1, 2, 0, 3).reshape(M, N)
+
+
+class ShardedHQQForward:
+    """One rank's share of a column-sharded layer.  forward(x) = local fused forward + one all-gather over the process
+    group (RCCL on GPUs; any torch.distributed backend works, the CPU tests use gloo with a stand-in local op)."""
+
+    def __init__(self, W_q, scale, zero, bias, N, K, group_size, nbits, group=None, local_forward=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.N, self.K, self.gs, self.nbits = N, K, group_size, nbits
+        self.Wq, self.scale, self.zero, self.bias, self.n_loc = shard_packed(W_q, scale, zero, bias, N, K, group_size, nbits, self.rank, self.world)
+        self._local = local_forward or (lambda x: ops.forward(x, self.Wq, self.scale, self.zero, self.bias, self.n_loc, K, group_size, nbits))
+
+    def forward(self, x: Tensor) -> Tensor:
+        y_loc = self._local(x).reshape(-1, self.n_loc).contiguous()
+        M = y_loc.shape[0]
+        out = torch.empty((self.world * M, self.n_loc), dtype=y_loc.dtype, device=y_loc.device)   # rank-major concatenation
+        self.dist.all_gather_into_tensor(out, y_loc, group=self.group)
+        return unpermute(out.view(self.world, M, self.n_loc), self.N, self.nbits, self.world).reshape(*x.shape[:-1], self.N)
+
+    __call__ = forward

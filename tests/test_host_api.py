@@ -1,0 +1,103 @@
+"""CPU tests of the host-side mirror of the reference interface: no kernel is launched here."""
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear, Quantizer, _META_TYPE  # noqa: E402
+from hqq_amd.core.utils import decode_safetensor_type, encode_safetensor_type  # noqa: E402
+
+
+def test_backend_enum_keeps_reference_members_verbatim():
+    # hqq/core/quantize.py:269-285 — value = name of the forward method
+    want = {"PYTORCH": "forward_pytorch_backprop", "PYTORCH_COMPILE": "forward_pytorch_backprop_compile", "ATEN": "forward_aten_backprop",
+            "PYTORCH_BACKPROP": "forward_pytorch_backprop", "PYTORCH_BACKPROP_COMPILE": "forward_pytorch_backprop_compile",
+            "ATEN_BACKPROP": "forward_aten_backprop", "PYTORCH_FORWARD": "forward_pytorch", "PYTORCH_FORWARD_COMPILE": "forward_pytorch_compile",
+            "ATEN_FORWARD": "forward_aten", "ATEN_FORWARD_INT8": "forward_aten_int8", "HIP": "forward_hip"}
+    assert {k: v.value for k, v in HQQBackend.__members__.items()} == want
+    for v in want.values():
+        assert callable(getattr(HQQLinear, v))
+
+
+def test_set_backend_rebinds_forward_class_wide():
+    try:
+        HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+        assert HQQLinear.forward is HQQLinear.forward_pytorch and HQQLinear.backend is HQQBackend.PYTORCH_FORWARD
+        assert HQQLinear(None, None).forward.__func__ is HQQLinear.forward_pytorch
+    finally:
+        HQQLinear.set_backend(HQQBackend.HIP)
+    assert HQQLinear.forward is HQQLinear.forward_hip
+
+
+def test_base_quantize_config_defaults():
+    # quantize.py:1076-1151: round_zero only for 4-bit, channel_wise/optimize on, axis=1 default
+    c = BaseQuantizeConfig(nbits=4, group_size=64)
+    assert c["weight_quant_params"] == {"nbits": 4, "channel_wise": True, "group_size": 64, "optimize": True, "round_zero": True,
+                                        "axis": 1, "view_as_float": False}
+    assert c["scale_quant_params"] is None and c["zero_quant_params"] is None and c["offload_meta"] is False
+    assert BaseQuantizeConfig(nbits=2)["weight_quant_params"]["round_zero"] is False
+    assert BaseQuantizeConfig(nbits=3, axis=0)["weight_quant_params"]["axis"] == 0
+    with pytest.raises(AssertionError):
+        BaseQuantizeConfig(nbits=7)
+    with pytest.raises(AssertionError):
+        BaseQuantizeConfig(nbits=4, group_size=12)
+
+
+def test_empty_layer_surface():
+    # loaders build HQQLinear(None, None) and fill it later (models/base.py:500-506)
+    lay = HQQLinear(None, None, compute_dtype=torch.float16, device="cuda")
+    assert not lay.is_initialized() and lay.ready is False and lay.bias is None
+    assert lay.to("cpu") is lay and lay.half() is lay and lay.float() is lay and lay.cpu() is lay and lay.type(torch.float32) is lay
+    sd = lay.state_dict()
+    assert set(sd) == lay.state_dict_keys() and all(v is None for v in sd.values())
+    assert lay.extra_repr() == ""
+
+
+@pytest.mark.parametrize("val,typ", [(True, bool), (False, bool), (4, int), (1.5, float), ("4bit_u8", str), (torch.float16, torch.dtype),
+                                      (torch.int32, torch.dtype), (torch.Size([4096, 11008]), torch.Size)])
+def test_safetensor_scalar_codec_round_trip(val, typ):
+    enc = encode_safetensor_type(val)
+    assert isinstance(enc, torch.Tensor)
+    assert decode_safetensor_type(enc, typ) == val
+
+
+def test_safetensor_codec_matches_reference_encoding():
+    # hqq/core/utils.py:37-52: bool -> uint8 scalar, int -> int32, float -> float32, str/dtype -> uint8 char codes
+    assert encode_safetensor_type(True).dtype == torch.uint8 and encode_safetensor_type(3).dtype == torch.int32
+    assert encode_safetensor_type(0.5).dtype == torch.float32
+    assert encode_safetensor_type(torch.float16).tolist() == [ord(c) for c in "torch.float16"]
+    assert encode_safetensor_type(torch.Size([2, 3])).tolist() == [2, 3]
+    t = torch.ones(2)
+    assert encode_safetensor_type(t) is t and decode_safetensor_type(t, torch.Tensor) is t
+    with pytest.raises(ValueError):
+        decode_safetensor_type(encode_safetensor_type("os.system"), torch.dtype)   # no eval() of checkpoint strings
+
+
+def test_quantizer_tables():
+    assert Quantizer.SUPPORTED_BITS == [8, 6, 5, 4, 3, 2, 1.58, 1]
+    assert Quantizer.bit_to_packing[3] == "3bit_32" and Quantizer.bit_to_packing[1.58] == "2bit_u8" and Quantizer.bit_to_packing[6] == "8bit_u8"
+    assert Quantizer.unpack_view_dtype["3bit_32"] == torch.int32 and Quantizer.unpack_view_dtype["4bit_u8"] == torch.uint8
+    assert set(Quantizer.pack) == set(Quantizer.unpack) == set(Quantizer.unpack_view_dtype)
+    assert _META_TYPE["shape"] is torch.Size and _META_TYPE["compute_dtype"] is torch.dtype
+
+
+def test_quantize_rejects_what_the_kernels_do_not_cover_loudly():
+    W = torch.zeros(64, 64)
+    with pytest.raises(NotImplementedError):
+        Quantizer.quantize(W, nbits=4, axis=0, device="cpu")
+    with pytest.raises(AssertionError):
+        Quantizer.quantize(W, nbits=4, group_size=48, axis=1)     # 4096 % 48 != 0 (quantize.py:94-100)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Quantizer.quantize(W, nbits=4, group_size=64, axis=1, device="cpu")
+
+
+def test_patching_skips_and_rejects():
+    from hqq_amd.utils.patching import prepare_for_inference
+    from hqq_amd.backends.hip import HQQLinearHIP, patch_hqq_to_hip
+    m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Sequential(torch.nn.Linear(8, 8)))
+    assert prepare_for_inference(m, backend="hip") is m and isinstance(m[0], torch.nn.Linear)   # nothing to patch
+    with pytest.raises(RuntimeError, match="not available"):
+        prepare_for_inference(m, backend="torchao_int4")
+    lin = torch.nn.Linear(4, 4)
+    assert patch_hqq_to_hip(lin, None) is lin
+    empty = HQQLinear(None, None)
+    assert HQQLinearHIP.check(empty) is False

@@ -1,0 +1,162 @@
+"""GPU tests of the drop-in surface: HQQLinear / HQQBackend / prepare_for_inference / column shard on the HIP kernels,
+against golden vectors produced by the reference's own HQQLinear (tests/golden/cfg1_1024_*.npz, BASELINE.json configs[0])."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from hqq_amd import ops as o
+    assert o.is_available()
+    return o
+
+
+def _cfg1_linear():
+    torch.manual_seed(0)
+    return torch.nn.Linear(1024, 1024, bias=False)
+
+
+def _levels_differ(ops, nbits, Wq_a, Wq_b, R):
+    a = ops.unpack(nbits, Wq_a)[:R].int()
+    b = ops.unpack(nbits, Wq_b)[:R].int()
+    return int((a != b).sum()), int((a - b).abs().max())
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+def test_hqqlinear_config1_matches_reference(ops, nbits):
+    g = load_golden(f"cfg1_1024_{nbits}b")
+    lin = _cfg1_linear()
+    if hashlib.sha256(lin.weight.data.numpy().tobytes()).hexdigest().encode() != g["W_sha256"].tobytes():
+        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    assert layer.ready and layer.in_gpu and HQQLinear.backend is HQQBackend.HIP
+    assert isinstance(layer.W_q, torch.nn.Parameter) and not layer.W_q.requires_grad
+    assert layer.W_q.dtype == (torch.int32 if nbits == 3 else torch.uint8)                # tests/test_quantize.py:36-39
+    assert tuple(layer.W_q.shape) == tuple(g["Wq_packed"].shape) and tuple(layer.meta["shape"]) == (1024, 1024)
+    assert layer.meta["scale"].dtype == torch.float16 and tuple(layer.meta["scale"].shape) == (1024 * 16, 1)
+    assert (layer.in_features, layer.out_features) == (1024, 1024) and not hasattr(layer, "linear_layer")
+    nbad, dmax = _levels_differ(ops, nbits, layer.W_q.data, torch.from_numpy(g["Wq_packed"]).cuda(), 1024 * 16)
+    assert dmax <= 1 and nbad <= 21, f"{nbad} levels differ from the reference"            # documented powf residual, <= 2e-5
+    x = torch.from_numpy(g["x_f32"]).cuda().half()
+    want = torch.from_numpy(g["y_f16"].astype(np.float32))
+    for backend in (HQQBackend.HIP, HQQBackend.PYTORCH, HQQBackend.PYTORCH_FORWARD, HQQBackend.ATEN_FORWARD):
+        HQQLinear.set_backend(backend)
+        try:
+            y = layer(x)
+        finally:
+            HQQLinear.set_backend(HQQBackend.HIP)
+        torch.testing.assert_close(y.float().cpu(), want, rtol=1e-3, atol=1e-3)
+    # dequantize() == reference formula on the layer's own tensors, bit for bit (and pure: meta untouched)
+    keys = set(layer.meta)
+    Wd = layer.dequantize()
+    assert set(layer.meta) == keys and tuple(Wd.shape) == (1024, 1024) and Wd.dtype == torch.float16
+    U = layer.unpack()[: 1024 * 16]
+    assert torch.equal(Wd, ((U - layer.meta["zero"]) * layer.meta["scale"]).reshape(1024, 1024))
+
+
+def test_state_dict_round_trip_and_float_view(ops):
+    lin = _cfg1_linear()
+    lin.bias = torch.nn.Parameter(torch.randn(1024))
+    cfg = BaseQuantizeConfig(nbits=4, group_size=64, axis=1)
+    a = HQQLinear(lin, cfg, compute_dtype=torch.float16, device="cuda", del_orig=False)
+    sd = a.state_dict()
+    assert set(sd) <= a.state_dict_keys() and all(isinstance(v, torch.Tensor) for v in sd.values())   # safetensors-compatible
+    assert sd["nbits"].dtype == torch.int32 and sd["packing"].dtype == torch.uint8 and sd["shape"].tolist() == [1024, 1024]
+    b = HQQLinear(None, None, compute_dtype=torch.float16, device="cuda")
+    b.load_state_dict({k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in sd.items()})
+    assert b.ready and torch.equal(b.W_q, a.W_q) and torch.equal(b.meta["scale"], a.meta["scale"]) and b.meta["packing"] == "4bit_u8"
+    assert b.meta["compute_dtype"] == torch.float16 and b.quant_config["weight_quant_params"]["round_zero"] is True
+    x = torch.randn(5, 1024, device="cuda", dtype=torch.float16)
+    assert torch.equal(a(x), b(x))
+    # nn.Module-style hierarchical load through _load_from_state_dict
+    holder = torch.nn.Module()
+    holder.proj = HQQLinear(None, None, compute_dtype=torch.float16, device="cuda")
+    dest = {}
+    a.state_dict(destination=dest, prefix="proj.")
+    holder.load_state_dict(dest)
+    assert torch.equal(holder.proj(x), a(x))
+    # view_as_float: same bytes stored as compute dtype (tests/test_quantize.py:41-48, :163)
+    cfg_f = BaseQuantizeConfig(nbits=4, group_size=64, axis=1, view_as_float=True)
+    c = HQQLinear(lin, cfg_f, compute_dtype=torch.float16, device="cuda", del_orig=False)
+    assert c.W_q.dtype == torch.float16 and torch.equal(c.W_q.data.view(torch.uint8), a.W_q.data)
+    assert torch.equal(c(x), a(x)) and torch.equal(c.dequantize(), a.dequantize())
+
+
+def test_backward_wrt_input_redequantises(ops):
+    lin = _cfg1_linear()
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    x = torch.randn(4, 1024, device="cuda", dtype=torch.float16, requires_grad=True)
+    y = layer(x)
+    y.float().sum().backward()
+    want = torch.ones(4, 1024, device="cuda", dtype=torch.float16) @ layer.dequantize()
+    torch.testing.assert_close(x.grad, want, rtol=2e-3, atol=2e-2)
+
+
+def test_prepare_for_inference_swaps_layers(ops):
+    from hqq_amd.backends.hip import HQQLinearHIP
+    from hqq_amd.utils.patching import prepare_for_inference
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            cfg4 = BaseQuantizeConfig(nbits=4, group_size=64, axis=1)
+            cfg3 = BaseQuantizeConfig(nbits=3, group_size=64, axis=1)
+            self.q = HQQLinear(torch.nn.Linear(256, 512, bias=True), cfg4, compute_dtype=torch.float16, device="cuda")
+            self.inner = torch.nn.Sequential(HQQLinear(torch.nn.Linear(512, 256, bias=False), cfg3, compute_dtype=torch.float16, device="cuda"))
+
+        def forward(self, x):
+            return self.inner(self.q(x))
+
+    m = Block()
+    x = torch.randn(2, 7, 256, device="cuda", dtype=torch.float16)
+    before = m(x)
+    wq = m.q.W_q.data.clone()
+    prepare_for_inference(m, backend="hip")
+    assert isinstance(m.q, HQQLinearHIP) and (m.q.in_features, m.q.out_features) == (256, 512) and m.q.bias is not None
+    assert torch.equal(m.q.W_q.data, wq)                                   # packed bytes untouched (no repacking)
+    assert isinstance(m.inner[0], HQQLinear)                               # 3-bit: not covered by the fused kernels -> skipped, still works
+    assert torch.equal(m(x), before) and tuple(before.shape) == (2, 7, 256)
+    assert torch.equal(m.q.dequantize().shape, torch.Size([512, 256])) if False else tuple(m.q.dequantize().shape) == (512, 256)
+
+
+@pytest.mark.parametrize("nbits", [4, 2, 3])
+@pytest.mark.parametrize("world", [2, 8])
+def test_column_shard_emulated_on_one_gpu(ops, nbits, world):
+    """every rank's packed slice run through the fused kernel, gathered and un-permuted == the full-layer forward.
+    (gpurun boxes expose one GPU: the ranks run one after the other; the collective itself is covered by the gloo test.)"""
+    from hqq_amd import shard
+    N, K, gs, M = 640, 512, 64, 3
+    g = torch.Generator().manual_seed(nbits)
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    Wq, s, z = ops.quantize(W, nbits=nbits, group_size=gs, round_zero=(nbits == 4))
+    s, z = s.half(), z.half()
+    bias = torch.randn(N, generator=g).half().cuda()
+    x = torch.randn(M, K, generator=g).half().cuda()
+
+    def fwd(Wq_, s_, z_, b_, n_):
+        if nbits == 3:   # no fused 3-bit kernel yet: dequantise kernel + library GEMM
+            return x @ ops.dequantize(Wq_, s_.reshape(-1), z_.reshape(-1), n_, K, gs, 3).t() + b_
+        return ops.forward(x, Wq_, s_, z_, b_, n_, K, gs, nbits)
+
+    full = fwd(Wq, s, z, bias, N)
+    parts = []
+    for r in range(world):
+        Wl, sl, zl, bl, n_loc = shard.shard_packed(Wq, s, z, bias, N, K, gs, nbits, r, world)
+        assert n_loc == N // world
+        parts.append(fwd(Wl.contiguous(), sl, zl, bl, n_loc))
+    y = shard.unpermute(torch.stack(parts), N, nbits, world)
+    if nbits == 3:
+        torch.testing.assert_close(y, full, rtol=1e-3, atol=1e-3)
+    else:
+        assert torch.equal(y, full)   # same weights, same k order per output row -> bit-identical

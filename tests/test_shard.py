@@ -1,0 +1,104 @@
+"""Column shard + all-gather (hqq_amd/shard.py): index math on CPU, and the N > 1 path with world_size-2 gloo."""
+import os
+import socket
+
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from hqq_amd import shard  # noqa: E402
+
+PER = {8: 1, 4: 2, 2: 4, 1: 8}
+
+
+def _pack_np(nbits, U):   # BitPack layout restated with torch on CPU (test-local helper)
+    per = PER[nbits]
+    step = U.shape[0] // per
+    out = torch.zeros((step, U.shape[1]), dtype=torch.uint8)
+    for s in range(per):
+        out |= (U[s * step:(s + 1) * step] << (nbits * (per - 1 - s))).to(torch.uint8)
+    return out
+
+
+@pytest.mark.parametrize("nbits", [4, 2, 8])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_shard_rows_partition_and_unpermute(nbits, world):
+    N = 64
+    rows = [shard.shard_rows(N, nbits, r, world) for r in range(world)]
+    assert sorted(torch.cat(rows).tolist()) == list(range(N))          # every output row owned exactly once
+    # gather order = rank-major, each rank in local order; unpermute must restore 0..N-1
+    M = 3
+    y = torch.stack([torch.stack([rows[r].float() + 1000 * m for m in range(M)]) for r in range(world)])   # [P, M, N/P]
+    back = shard.unpermute(y, N, nbits, world)
+    assert torch.equal(back, torch.stack([torch.arange(N).float() + 1000 * m for m in range(M)]))
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_packed_slice_is_a_self_contained_layer(nbits, monkeypatch):
+    """the zero-copy packed-row block of rank r unpacks to exactly the rows shard_rows() names"""
+    N, K, gs, world = 32, 128, 64, 2
+    G = K // gs
+    g = torch.Generator().manual_seed(0)
+    U = torch.randint(0, 2 ** nbits, (N * G, gs), generator=g, dtype=torch.uint8)      # [R, gs], row = n*G + k//gs
+    Wq = _pack_np(nbits, U)
+    scale = torch.rand(N * G, 1, generator=g)
+    zero = torch.rand(N * G, 1, generator=g)
+    for r in range(world):
+        Wl, sc, ze, b, n_loc = shard.shard_packed(Wq, scale, zero, None, N, K, gs, nbits, r, world)
+        assert Wl.data_ptr() == Wq[r * Wq.shape[0] // world].data_ptr()               # a view, not a copy
+        rows = shard.shard_rows(N, nbits, r, world)
+        want_U = U.reshape(N, G, gs)[rows].reshape(n_loc * G, gs)
+        assert torch.equal(_pack_np(nbits, want_U), Wl)
+        assert torch.equal(sc, scale.reshape(N, G)[rows].reshape(-1, 1)) and torch.equal(ze, zero.reshape(N, G)[rows].reshape(-1, 1))
+    with pytest.raises(ValueError):
+        shard.shard_rows(36, 4, 0, 8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nbits, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, K, gs, M = 32, 128, 64, 3
+        G = K // gs
+        g = torch.Generator().manual_seed(0)                                     # same layer on every rank
+        U = torch.randint(0, 2 ** nbits, (N * G, gs), generator=g, dtype=torch.uint8)
+        Wq = _pack_np(nbits, U)
+        scale = torch.rand(N * G, 1, generator=g) * 0.01
+        zero = torch.rand(N * G, 1, generator=g) * 8
+        bias = torch.rand(N, generator=g)
+        x = torch.randn(M, K, generator=g)
+        Wfull = ((U.float() - zero) * scale).reshape(N, K)
+        rows = shard.shard_rows(N, nbits, rank, world)
+        # stand-in for the HIP kernel on CPU: dense math on exactly this rank's rows (the GPU tests cover the kernel itself)
+        local = lambda xx: xx @ Wfull[rows].t() + bias[rows]                      # noqa: E731
+        sh = shard.ShardedHQQForward(Wq, scale, zero, bias, N, K, gs, nbits, local_forward=local)
+        y = sh(x)
+        ok = torch.allclose(y, x @ Wfull.t() + bias, atol=1e-5) and sh.n_loc == N // world and tuple(y.shape) == (M, N)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_sharded_forward_all_gather_gloo_world2(nbits):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nbits, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res == [(0, True), (1, True)]
