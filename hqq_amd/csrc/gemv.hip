@@ -40,12 +40,12 @@
 namespace hqq {
 
 #ifndef GV_WAVES_PER_WG
-#define GV_WAVES_PER_WG 8
+#define GV_WAVES_PER_WG 4
 #endif
 #ifndef GV_WG_PER_CU
-#define GV_WG_PER_CU 2
+#define GV_WG_PER_CU 4
 #endif
-constexpr int GV_WAVES = GV_WAVES_PER_WG;  // waves per workgroup (512 threads)
+constexpr int GV_WAVES = GV_WAVES_PER_WG;  // waves per workgroup (256 threads; 4 workgroups per CU measured best)
 constexpr int GV_KSTEP = 1024;            // k covered by one wave load instruction: 64 lanes x 16 bytes
 constexpr int GV_U = 4;                   // load instructions per unit
 constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
@@ -295,7 +295,40 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
     }
   };
 
-  // ---- first unit of this wave's first row goes out before anything else ----
+  // ---- prologue: the workgroup's first pass of x loads goes out first (their latency overlaps the kernarg-dependent row
+  //      set-up), then the first unit of this wave's first row, then x is written to LDS ----
+  float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64], FACTORED only
+  const int chunks_per_m = nsteps * 64;          // 16-k lane chunks per row of x, padded to whole steps
+  auto load_chunk = [&](int c, u32x4& v0, u32x4& v1) {
+    const int m = c / chunks_per_m, j = c - m * chunks_per_m;   // j = step * 64 + lane
+    const int k = j * 16;
+    v0 = u32x4{0u, 0u, 0u, 0u};
+    v1 = u32x4{0u, 0u, 0u, 0u};
+    if (c < M * chunks_per_m && k < K) {   // K % 16 == 0
+      const u32x4* src = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + k);
+      v0 = src[0];
+      v1 = src[1];
+    }
+  };
+  auto store_chunk = [&](int c, const u32x4& v0, const u32x4& v1) {
+    if (c >= M * chunks_per_m) return;
+    const int m = c / chunks_per_m, j = c - m * chunks_per_m;
+    const int it = j >> 6, ln = j & 63;
+    xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
+    xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
+    if constexpr (!EXACT) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const half2_t h0 = as_h2(v0[i]), h1 = as_h2(v1[i]);
+        sum += (static_cast<float>(h0.x) + static_cast<float>(h0.y)) + (static_cast<float>(h1.x) + static_cast<float>(h1.y));
+      }
+      xsum_lds[m * chunks_per_m + j] = sum;
+    }
+  };
+  u32x4 xv0, xv1;
+  load_chunk(tid, xv0, xv1);
+
   int prow = blockIdx.x * GV_WAVES + wave;
   int unit = 0;
   // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
@@ -304,34 +337,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   issue(ua, lc, prow < total ? prow : total - 1, 0, prow < total);
   GV_TS(1)
 
-  // ---- stage x[M, K] into LDS once per workgroup: two permuted 16-byte planes + the fp32 sum per 16-k lane chunk ----
-  float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64]
-  {
-    const int chunks_per_m = nsteps * 64;
-    for (int c = tid; c < M * chunks_per_m; c += GV_WAVES * 64) {
-      const int m = c / chunks_per_m, j = c - m * chunks_per_m;   // j = step * 64 + lane
-      const int k = j * 16;
-      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-      if (k < K) {   // K % 16 == 0
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + k);
-        v0 = src[0];
-        v1 = src[1];
-      }
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const half2_t h0 = as_h2(v0[i]), h1 = as_h2(v1[i]);
-        sum += (static_cast<float>(h0.x) + static_cast<float>(h0.y)) + (static_cast<float>(h1.x) + static_cast<float>(h1.y));
-      }
-      const int it = j >> 6, ln = j & 63;
-      xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
-      xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
-      xsum_lds[m * chunks_per_m + j] = sum;
-    }
-    GV_TS(2)
-    __syncthreads();
-    GV_TS(3)
+  store_chunk(tid, xv0, xv1);
+  for (int c = tid + GV_WAVES * 64; c < M * chunks_per_m; c += GV_WAVES * 64) {
+    load_chunk(c, xv0, xv1);
+    store_chunk(c, xv0, xv1);
   }
+  GV_TS(2)
+  __syncthreads();
+  GV_TS(3)
 
   // FACTORED: one fp32 partial per (x row, slab); EXACT: one 16x16 MFMA tile (4 VGPRs) per (x row, slab)
   using acc_t = std::conditional_t<EXACT, f32x4, float>;
@@ -491,7 +504,8 @@ static int launch_gemv_f16(const GvArgs& a, hipStream_t st) {
   const int nsteps = (a.K + GV_KSTEP - 1) / GV_KSTEP;
   const size_t lds = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
   const int tiles = (a.total_prow + GV_WAVES - 1) / GV_WAVES;
-  const int per_cu = lds <= 64 * 1024 ? GV_WG_PER_CU : 1;
+  int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
+  per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   const int cap = num_cus() * per_cu;
   const int grid = tiles < cap ? tiles : cap;
   auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT>;
