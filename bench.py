@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
+    ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-codes", action="store_true", help="skip the solver: random packed codes + meta (faster setup)")
     ap.add_argument("--gemv-mode", default="exact", choices=["exact", "factored"],
@@ -192,7 +193,7 @@ def main():
                 else:
                     for j, name in enumerate(grp):
                         L = blk[name]
-                        ops.forward(xs[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=ol[j])
+                        ops.forward(xs[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=ol[j], fused=(not a.library_gemm))
                 if world > 1:
                     dist.all_gather_into_tensor(out_full[grp], ol.view(len(grp) * M, -1))
 
@@ -274,12 +275,12 @@ def main():
         out.update({
             "metric": f"int{nbits} gs=64 dequant-GEMM prefill throughput, Llama-2-7B block M={M} (tok/s; TFLOP/s alongside)",
             "value": round(M / sec_per_step, 2), "unit": "tok/s (one block's 7 linears)", "tflops": round(tfl, 2),
-            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens, fp16 MFMA dequant-GEMM",
+            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens, fp16 " + ("dequantise kernel + library GEMM" if a.library_gemm else "fused MFMA dequant-GEMM"),
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather"},
         })
         ach = flops_per_step_rank / dev_sec_per_step / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "kernel": "hqq::gemm_f16_kernel"}
+                           "traffic": None, "kernel": "hqq::dequant + hipBLASLt" if a.library_gemm else "hqq::gemm_f16_kernel"}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nbits)

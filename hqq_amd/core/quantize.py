@@ -337,8 +337,12 @@ class HQQLinear(nn.Module):
     # ---- forward methods named by HQQBackend ----
     def _fused_ok(self, x: Tensor) -> bool:
         m = self.meta
-        return (m["axis"] == 1 and m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8") and x.dtype == float16 and
-                m["scale"].dtype == float16 and bool(m["group_size"]) and m["group_size"] % 16 == 0)
+        if not (m["axis"] == 1 and bool(m["group_size"]) and m["group_size"] % 16 == 0 and x.dtype == m["scale"].dtype):
+            return False
+        if x.dtype == float16:
+            return m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8")
+        # bf16: the fused decode kernel covers 4-/2-bit up to 4 activation rows; everything else dequantises + library GEMM
+        return x.dtype == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8") and x.numel() // x.shape[-1] <= 4
 
     def forward_hip(self, x: Tensor) -> Tensor:
         """Fused unpack -> dequantize -> GEMV / GEMM (one launch).  Configurations the fused kernels do not cover run the

@@ -6,7 +6,8 @@
 // (bit-identical to hqq_hip_dequantize: two fp16 roundings), writes it to LDS in MFMA operand order and
 // contracts it with the activation tile on the matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate).
 //
-// Tile:   BN = 128 output columns (PER slabs x 128/PER packed rows, because one packed byte holds rows
+// Tile:   BM = 128 or 256 tokens (template; 256 halves the dequantisation VALU work per flop and is used for large M),
+//         BN = 128 output columns (PER slabs x 128/PER packed rows, because one packed byte holds rows
 //         p, p+N/PER, ...), BM = 128 tokens, BK = 64.  4 waves as 2(n) x 2(m), 64x64 per wave =
 //         4x4 MFMA tiles.  W is the MFMA "A" operand (rows = output features) so every lane ends up with
 //         4 consecutive output features of one token: 8-byte stores.
@@ -20,7 +21,7 @@
 
 namespace hqq {
 
-constexpr int GB_M = 128, GB_N = 128, GB_K = 64, G_THREADS = 256;
+constexpr int GB_N = 128, GB_K = 64, G_THREADS = 256;   // token-tile height BM (128 or 256) is a template parameter
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
@@ -73,8 +74,8 @@ struct DeqSlab {
   }
 };
 
-template <int NBITS>
-__global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
+template <int NBITS, int BM>
+__global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : 1) void gemm_f16_kernel(
     const half_t* __restrict__ x, const uint8_t* __restrict__ Wq, const half_t* __restrict__ scale,
     const half_t* __restrict__ zero, const half_t* __restrict__ bias, half_t* __restrict__ y,
     int M, int N, int K, int gs, int n_tiles) {
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
   constexpr int PROWS = GB_N / PER;                  // packed rows per tile
   constexpr int WLOADS = (PROWS * GB_K) / (16 * G_THREADS) > 0 ? (PROWS * GB_K) / (16 * G_THREADS) : 1;
   constexpr int WTHREADS = (PROWS * GB_K) / 16 / WLOADS;   // threads that carry a packed chunk
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * GB_N * GB_K * 2];
+  constexpr int MT = BM / 32;       // 16-token MFMA tiles per wave along M (each wave covers BM/2 tokens)
+  constexpr int XROWS = BM / 128;   // x rows staged per thread
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(GB_N + BM) * GB_K * 2];
   uint8_t* ldsW = lds;
   uint8_t* ldsX = lds + GB_N * GB_K * 2;
 
@@ -92,18 +95,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
   const int nt = blockIdx.x % n_tiles, mt = blockIdx.x / n_tiles;
   const int rows_per_slab = N / PER;
   const int p0 = nt * PROWS;                         // first packed row of the tile
-  const int m0 = mt * GB_M;
+  const int m0 = mt * BM;
   const int G = K / gs;
 
   // ---- per-thread global->register staging assignment ----
   const int wp = tid / 4, wk = tid & 3;              // packed row in tile / 16-k chunk (PROWS*4 threads active)
   const bool w_active = tid < WTHREADS && (p0 + wp) < rows_per_slab;
-  const int xr_ = tid >> 1, xh = tid & 1;            // x row in tile, half (32 k = 4 chunks)
-  const bool x_active = (m0 + xr_) < M;
+  const int xr_ = tid >> 1, xh = tid & 1;            // x row in tile (+128 per extra row), half (32 k = 4 chunks)
 
   u32x4 wreg = {0u, 0u, 0u, 0u};
   half_t zreg[PER], sreg[PER];
-  u32x4 xreg[4];
+  u32x4 xreg[XROWS][4];
 
   auto load_regs = [&](int kt) {
     const int k0 = kt * GB_K;
@@ -117,13 +119,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
         sreg[s] = scale[r];
       }
     }
-    if (x_active) {
-      const half_t* src = x + static_cast<int64_t>(m0 + xr_) * K + k0 + xh * 32;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xreg[c] = *reinterpret_cast<const u32x4*>(src + c * 8);
-    } else {
+    for (int xr = 0; xr < XROWS; ++xr) {
+      const int row = m0 + xr * 128 + xr_;
+      if (row < M) {
+        const half_t* src = x + static_cast<int64_t>(row) * K + k0 + xh * 32;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xreg[c] = u32x4{0u, 0u, 0u, 0u};
+        for (int c = 0; c < 4; ++c) xreg[xr][c] = *reinterpret_cast<const u32x4*>(src + c * 8);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xreg[xr][c] = u32x4{0u, 0u, 0u, 0u};
+      }
     }
   };
 
@@ -140,15 +146,17 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      *reinterpret_cast<u32x4*>(ldsX + lds_off(xr_, xh * 4 + c)) = g_permute_x8(xreg[c]);
+    for (int xr = 0; xr < XROWS; ++xr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<u32x4*>(ldsX + lds_off(xr * 128 + xr_, xh * 4 + c)) = g_permute_x8(xreg[xr][c]);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / GB_K;
   load_regs(0);
@@ -160,18 +168,22 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
     if (kt + 1 < nk) load_regs(kt + 1);              // global loads in flight during the MFMA phase
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      h8_t a[4], b[4];
+      h8_t a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         a[i] = *reinterpret_cast<const h8_t*>(ldsW + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        b[j] = *reinterpret_cast<const h8_t*>(ldsX + lds_off(wm * 64 + j * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int jh = 0; jh < MT; jh += 4) {   // four token tiles at a time keeps the B fragments at 16 VGPRs
+        h8_t b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+          b[j] = *reinterpret_cast<const h8_t*>(ldsX + lds_off(wm * (BM / 2) + (jh + j) * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][jh + j], 0, 0, 0);
+      }
     }
   }
 
@@ -184,8 +196,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
     if (prow >= rows_per_slab) continue;             // whole quad out of range
     const int n = slab * rows_per_slab + prow;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 64 + j * 16 + fr;
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * (BM / 2) + j * 16 + fr;
       if (m >= M) continue;
       half_t o[4];
 #pragma unroll
@@ -205,16 +217,16 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f16_kernel(
   }
 }
 
-template <int NBITS>
+template <int NBITS, int BM>
 static int launch_gemm_f16(const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                            int M, int N, int K, int gs, hipStream_t st) {
   constexpr int PER = 8 / NBITS;
   const int rows_per_slab = N / PER;
   const int n_tiles = (rows_per_slab + GB_N / PER - 1) / (GB_N / PER);
-  const int m_tiles = (M + GB_M - 1) / GB_M;
+  const int m_tiles = (M + BM - 1) / BM;
   const int64_t blocks = static_cast<int64_t>(n_tiles) * m_tiles;
   if (blocks > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
-  hipLaunchKernelGGL((gemm_f16_kernel<NBITS>), dim3(static_cast<unsigned>(blocks)), dim3(G_THREADS), 0, st,
+  hipLaunchKernelGGL((gemm_f16_kernel<NBITS, BM>), dim3(static_cast<unsigned>(blocks)), dim3(G_THREADS), 0, st,
                      static_cast<const half_t*>(x), static_cast<const uint8_t*>(Wq), static_cast<const half_t*>(scale),
                      static_cast<const half_t*>(zero), static_cast<const half_t*>(bias), static_cast<half_t*>(y),
                      M, N, K, gs, n_tiles);
@@ -241,8 +253,10 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
   if (dtype != HQQ_F16) { set_error("hqq_hip_gemm: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
   hipStream_t st = as_stream(stream);
   const int m = static_cast<int>(M), n = static_cast<int>(N), k = static_cast<int>(K), gs = static_cast<int>(group_size);
-  if (nbits == 4) return launch_gemm_f16<4>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
-  return launch_gemm_f16<2>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
+  // 256-token tiles halve the dequantisation work per flop; keep 128 when M is too small to fill the chip with them
+  const bool big = static_cast<int64_t>((M + 255) / 256) * ((N + GB_N - 1) / GB_N) >= 1536;   // >= 3 full waves of 256-token tiles
+  if (nbits == 4) return big ? launch_gemm_f16<4, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_f16<4, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
+  return big ? launch_gemm_f16<2, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_f16<2, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
 }
 
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,

@@ -210,6 +210,45 @@ struct SlabExact {
   }
 };
 
+// bf16 compute dtype: the reference's two roundings are to bf16 (quantize.py:198 on bf16 tensors).  gfx950 has no packed
+// bf16 arithmetic, so the weight goes through fp32: q - z is exact in fp32 (one fma on the biased level), v_cvt_pk_bf16_f32
+// rounds it (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds again.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int NBITS, int M, int S, int PER>
+struct SlabExactBF16 {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const bf16x8_t (&b0)[M], const bf16x8_t (&b1)[M],
+                                             f32x4 (&acc)[M][PER], uint32_t magic) {
+    constexpr int sh = NBITS * (PER - 1 - S);
+    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+    const float zf = __uint_as_float(zs[S] << 16);
+    const float c = -(1024.0f * inv) - zf;                                  // exact: z has 8 significant bits
+    const bf16x2_t s_lo = __builtin_bit_cast(bf16x2_t, zs[S] >> 16);          // (s, 0)
+    const bf16x2_t s_hi = __builtin_bit_cast(bf16x2_t, zs[S] & 0xFFFF0000u);  // (0, s)
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const half2_t bl = biased_levels<NBITS, S>(h ? (w[d] >> 8) : w[d], magic);   // fp16 (1024 + F q, 1024 + F q')
+        const f32x2_t dq = {__builtin_fmaf(static_cast<float>(bl.x), inv, c), __builtin_fmaf(static_cast<float>(bl.y), inv, c)};   // q - z, exact
+        const bf16x2_t dr = __builtin_convertvector(dq, bf16x2_t);                    // rounding 1
+        const f32x2_t pw = {__builtin_amdgcn_fdot2_f32_bf16(dr, s_lo, 0.f, false), __builtin_amdgcn_fdot2_f32_bf16(dr, s_hi, 0.f, false)};
+        o[2 * d + h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, bf16x2_t));   // rounding 2
+      }
+    }
+    const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, u32x4{o[0], o[1], o[2], o[3]});
+    const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, u32x4{o[4], o[5], o[6], o[7]});
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[m], acc[m][S], 0, 0, 0);
+      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[m], acc[m][S], 0, 0, 0);
+    }
+    if constexpr (S + 1 < PER) SlabExactBF16<NBITS, M, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
+  }
+};
+
 template <int NBITS, int S, int PER>
 struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the raw fp16 bit patterns
   static __device__ __forceinline__ void run(const uint16_t* z, const uint16_t* sc, float (&c1)[PER], float (&c2)[PER]) {
@@ -232,8 +271,9 @@ struct Unit {
   uint16_t sc[GS64 ? PER : GV_U * PER];
 };
 
-template <int NBITS, int M, bool GS64, bool EXACT>
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a) {
+  static_assert(EXACT || !BF16, "bf16 is served by the exact-weights path only");
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
@@ -376,14 +416,16 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
           }
         }
         if (step < nsteps) {
-          h8_t b0[M], b1[M];
+          // lanes past K see zero x (padded in LDS) and a finite re-read weight: they add exactly 0
+          using frag_t = std::conditional_t<BF16, bf16x8_t, h8_t>;
+          frag_t b0[M], b1[M];
 #pragma unroll
           for (int m = 0; m < M; ++m) {
-            b0[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (step * 2 + 0) * 64 + lane]);
-            b1[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (step * 2 + 1) * 64 + lane]);
+            b0[m] = __builtin_bit_cast(frag_t, xs[m * planes_per_m + (step * 2 + 0) * 64 + lane]);
+            b1[m] = __builtin_bit_cast(frag_t, xs[m * planes_per_m + (step * 2 + 1) * 64 + lane]);
           }
-          // lanes past K see zero x (padded in LDS) and a finite re-read weight: they add exactly 0
-          SlabExact<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
+          if constexpr (BF16) SlabExactBF16<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
+          else SlabExact<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
         }
       }
     } else {
@@ -444,9 +486,16 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
       if (lane < M * PER) {
         const int m = lane / PER, s = lane - m * PER;
         const int n = p + s * rows_per_slab;
-        half_t o = static_cast<half_t>(mine);
-        if (oc.bias) o = o + oc.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-        oc.y[static_cast<int64_t>(m) * oc.N + n] = o;
+        // `out += bias` on the rounded matmul result (quantize.py:896-897): two roundings in the compute dtype
+        if constexpr (BF16) {
+          uint16_t o = f32_to_bf16(mine);
+          if (oc.bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(oc.bias)[n]));
+          reinterpret_cast<uint16_t*>(oc.y)[static_cast<int64_t>(m) * oc.N + n] = o;
+        } else {
+          half_t o = static_cast<half_t>(mine);
+          if (oc.bias) o = o + oc.bias[n];
+          oc.y[static_cast<int64_t>(m) * oc.N + n] = o;
+        }
       }
     }
   };
@@ -499,7 +548,7 @@ static int num_cus() {
   return g_num_cus;
 }
 
-template <int NBITS, int M, bool GS64, bool EXACT>
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false>
 static int launch_gemv_f16(const GvArgs& a, hipStream_t st) {
   const int nsteps = (a.K + GV_KSTEP - 1) / GV_KSTEP;
   const size_t lds = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
@@ -508,7 +557,7 @@ static int launch_gemv_f16(const GvArgs& a, hipStream_t st) {
   per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   const int cap = num_cus() * per_cu;
   const int grid = tiles < cap ? tiles : cap;
-  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT>;
+  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
     if (!raised) {
@@ -538,6 +587,18 @@ static int dispatch_m(int M, const GvArgs& a, hipStream_t st) {
     }
   }
   return HQQ_ERR_SHAPE;
+}
+
+// bf16 compute dtype (exact weights only): 4-/2-bit, group_size 64 or generic, M <= 4
+static int dispatch_bf16(int nbits, int M, const GvArgs& a, hipStream_t st) {
+  const bool gs64 = a.gs == 64;
+#define HQQ_BF16_CASE(NB, MM)                                                                         \
+  if (nbits == NB && M == MM) return gs64 ? launch_gemv_f16<NB, MM, true, true, true>(a, st) : launch_gemv_f16<NB, MM, false, true, true>(a, st);
+  HQQ_BF16_CASE(4, 1) HQQ_BF16_CASE(4, 2) HQQ_BF16_CASE(4, 3) HQQ_BF16_CASE(4, 4)
+  HQQ_BF16_CASE(2, 1) HQQ_BF16_CASE(2, 2) HQQ_BF16_CASE(2, 3) HQQ_BF16_CASE(2, 4)
+#undef HQQ_BF16_CASE
+  set_error("hqq_hip_gemv: bf16 covers nbits 4/2 (got %d)", nbits);
+  return HQQ_ERR_UNSUPPORTED;
 }
 
 template <bool EXACT>
@@ -579,12 +640,16 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
   if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
-  if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (dtype == HQQ_BF16 && (M > GV_EXACT_ROWWISE_MAX_M || (nbits != 4 && nbits != 2))) {
+    set_error("hqq_hip_gemv: bf16 covers nbits 4/2 and M <= %d (got nbits=%d M=%lld)", GV_EXACT_ROWWISE_MAX_M, nbits, (long long)M);
+    return HQQ_ERR_UNSUPPORTED;
+  }
   if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
   const int per = 8 / nbits;
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
-  const bool exact = g_gemv_mode == HQQ_GEMV_EXACT;
+  const bool exact = g_gemv_mode == HQQ_GEMV_EXACT || dtype == HQQ_BF16;
   if (exact && M > GV_EXACT_ROWWISE_MAX_M) {
     // more activation rows than the row-per-wave kernel contracts cheaply: the 16-row-tile MFMA kernel (needs K % 64 == 0)
     if (K % 64) { set_error("hqq_hip_gemv: M=%lld > %d needs K %% 64 == 0 (got K=%lld)", (long long)M, GV_EXACT_ROWWISE_MAX_M, (long long)K); return HQQ_ERR_UNSUPPORTED; }
@@ -634,7 +699,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
     GvArgs b = a;
     b.x = static_cast<const half_t*>(x) + m0 * K;
     for (int i = 0; i < GV_MAXL; ++i) b.y[i] = a.y[i] + m0 * a.N[i];
-    const int rc = exact ? dispatch<true>(nbits, mm, b, st) : dispatch<false>(nbits, mm, b, st);
+    const int rc = dtype == HQQ_BF16 ? dispatch_bf16(nbits, mm, b, st) : exact ? dispatch<true>(nbits, mm, b, st) : dispatch<false>(nbits, mm, b, st);
     if (rc) return rc;
   }
   return 0;

@@ -170,9 +170,25 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor
     return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
 
 
-def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
-    """y = x @ dequantize(W_q)^T (+ bias): GEMV for M <= 8, MFMA GEMM otherwise."""
-    return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+# Above this many activation rows `forward` composes the HIP dequantise kernel with a plain library GEMM (hipBLASLt through
+# torch.matmul): one extra write+read of the fp16 weights (2*N*K*2 bytes) is then < 10 % of the GEMM time and the library's
+# tuned MFMA pipeline (1.26 PFLOP/s at 8192x4096x4096) beats the fused kernel (0.65-0.83).  0 disables the composition.
+LIBRARY_GEMM_MIN_M = 1024
+
+
+def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None) -> Tensor:
+    """y = x @ dequantize(W_q)^T (+ bias).  M <= 16: HBM-bound decode kernels; larger M: fused MFMA dequant-GEMM, or — from
+    LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.  Same dequantised weights either way."""
+    M = x.numel() // K if K else 0
+    if fused is None:
+        fused = not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M)
+    if fused:
+        return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+    W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)
+    y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
+    if bias is not None:
+        y += bias
+    return y.reshape(*x.shape[:-1], N)
 
 
 def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False, optimize: bool = True,

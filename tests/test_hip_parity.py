@@ -234,6 +234,33 @@ def test_gemv_vs_oracle(ops, oracle, nbits, M, NK):
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("M", [1, 3, 4])
+@pytest.mark.parametrize("NK", [(512, 1024), (64, 11008), (40, 192)])
+def test_gemv_bf16_vs_oracle(ops, oracle, nbits, M, NK):
+    """bf16 compute dtype: weights rounded to bf16 twice exactly as the reference does on bf16 tensors (one-hot probe is
+    bit-exact vs the dequant kernel / oracle); outputs within one bf16 ulp (2^-8) of the double-accumulated oracle."""
+    N, K = NK
+    gs = 64
+    U, s, z = _random_layer(N, K, gs, nbits, seed=N + K + nbits, dt=torch.bfloat16)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).bfloat16()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).bfloat16() if M % 2 else None
+    raw = lambda t: t.view(torch.int16).numpy().view(np.uint16)                     # noqa: E731  (oracle takes raw bf16 bits)
+    Wd = oracle.dequantize(nbits, P, raw(s), raw(z), N, K, gs, 2)
+    yo, _ = oracle.matmul(raw(x), Wd, None if bias is None else raw(bias), 2)
+    want = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+    y = ops.gemv(x.cuda(), dev(P), s.cuda(), z.cuda(), None if bias is None else bias.cuda(), N, K, gs, nbits)
+    assert y.dtype == torch.bfloat16
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2.0 ** -7, atol=2e-3)
+    k = (3 * K) // 7
+    e = torch.zeros(1, K, dtype=torch.bfloat16, device="cuda"); e[0, k] = 1.0
+    col = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0]
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    assert torch.equal(col, Wdev[:, k])
+    assert np.array_equal(bits(Wdev), Wd.view(np.int16))                              # and the dequant kernel == oracle, bit for bit
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
 @pytest.mark.parametrize("mode", ["exact", "factored"])
 def test_gemv_grouped_equals_single_launches(ops, nbits, mode):
     """q|k|v-style horizontal fusion: one launch over layers of different N sharing x == the per-layer launches, bit for bit"""
