@@ -45,10 +45,10 @@ class HQQLinearHIP(nn.Module):
         gs = m["group_size"]
         N, K = m["shape"]
         dt = hqq_layer.compute_dtype
-        covered = (dt == torch.float16 and m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8")) or \
+        covered = (dt == torch.float16 and (m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8") or (m["packing"] == "3bit_32" and gs == 64))) or \
                   (dt == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8"))
         return (m["axis"] == 1 and covered
-                and bool(gs) and gs % 16 == 0 and K % gs == 0 and N % ops.PER[Quantizer._packing_bits[m["packing"]]] == 0
+                and bool(gs) and gs % 16 == 0 and K % gs == 0 and (m["packing"] == "3bit_32" or N % ops.PER[Quantizer._packing_bits[m["packing"]]] == 0)
                 and not m.get("quant_scale") and not m.get("quant_zero") and hqq_layer.W_q.is_cuda)
 
     def extra_repr(self) -> str:
@@ -60,8 +60,8 @@ class HQQLinearHIP(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
-        if self.compute_dtype == torch.bfloat16 and x.numel() // x.shape[-1] > 4:
-            # bf16 beyond the decode kernel's 4 rows: HIP dequantise kernel + library GEMM (still one pass over the packed bytes)
+        if (self.compute_dtype == torch.bfloat16 or self.nbits == 3) and x.numel() // x.shape[-1] > 4:
+            # bf16 / 3-bit beyond the decode kernels' 4 rows: HIP dequantise kernel + library GEMM
             out = torch.matmul(x, self.dequantize().t())
             if self.bias is not None:
                 out += self.bias

@@ -339,7 +339,10 @@ class HQQLinear(nn.Module):
         m = self.meta
         if not (m["axis"] == 1 and bool(m["group_size"]) and m["group_size"] % 16 == 0 and x.dtype == m["scale"].dtype):
             return False
+        rows = x.numel() // x.shape[-1]
         if x.dtype == float16:
+            if m["packing"] == "3bit_32":   # fused 3-bit kernel: decode-sized batches, group_size 64
+                return rows <= 4 and m["group_size"] == 64
             return m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8")
         # bf16: the fused decode kernel covers 4-/2-bit up to 4 activation rows; everything else dequantises + library GEMM
         return x.dtype == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8") and x.numel() // x.shape[-1] <= 4

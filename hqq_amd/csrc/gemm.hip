@@ -261,7 +261,7 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
 
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                     void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream) {
-  if (M >= 1 && M <= HQQ_GEMV_MAX_M) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
+  if (M >= 1 && M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
   return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
 }
 

@@ -625,6 +625,8 @@ static int max_m_per_launch(int64_t K) {
 namespace hqq {
 int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                   const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
+int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
 static int g_gemv_mode = HQQ_GEMV_EXACT;
 }  // namespace hqq
 
@@ -639,6 +641,12 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
+  if (nbits == 3) {   // int32 containers, ten slabs: its own kernel (gemv3.hip), fp16, exact weights
+    if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers fp16 (got dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+    if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
+    if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    return gemv3_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
+  }
   if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
   if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
   if (dtype == HQQ_BF16 && (M > GV_EXACT_ROWWISE_MAX_M || (nbits != 4 && nbits != 2))) {

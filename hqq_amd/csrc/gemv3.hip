@@ -1,0 +1,303 @@
+// gemv3.hip — fused unpack -> dequantize -> GEMV for 3-bit HQQ layers (M <= 4 activation rows), gfx950.
+//
+// Reference chain replaced: BitPack.unpack_3bit_32 -> [: R] -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
+//   hqq/core/bitpack.py:95-110, hqq/core/quantize.py:183-199 (the 3-bit slice at :190-195), :880-898.
+//
+// Layout (as stored by the reference, no repacking): P [step, gs=64] int32, step = ceil(R/10), R = N*G groups; the unpacked
+// group row r = n*G + g lives in slab s = r / step at packed row p = r - s*step, bits [27-3s, 29-3s] of every word.  Ten
+// *unrelated* output rows share each packed row, and step is not a multiple of G, so there is no packed-row range that
+// maps to whole output rows for all ten slabs at once.
+//
+// Decomposition chosen: one wave per OUTPUT row.  Row n's G groups are G consecutive packed rows of one slab (two slabs
+// when the row straddles a slab boundary — handled per lane): 256*G contiguous bytes of which the wave uses 3 bits per
+// word.  The other nine users of the same bytes are the rows n + j*step/G; the grid walks n in order, so they are
+// in flight within the same few microseconds and the re-reads are served by L2 / Infinity Cache — HBM sees each packed
+// byte about once, L2->CU traffic is 10x the packed bytes.  That trades L2 bandwidth (plentiful) for a kernel with no
+// atomics, no cross-wave reduction and a deterministic summation order.
+//
+// Per wave instruction: 64 lanes x 16 B = four groups; lane (i = lane & 15, j = lane >> 4) holds words 4i..4i+3 of group
+// 4u + j.  Levels of a slab are pulled out two words at a time (v_lshrrev x2, v_perm, v_and_or onto the fp16 exponent
+// 0x6400), then rebuilt exactly as Quantizer.dequantize does (-1024, -zero, *scale: two fp16 roundings) and contracted on
+// the matrix core with the diagonal trick of gemv.hip (all lanes hold the same output row; D[i][i] are the partial sums).
+#include <type_traits>
+
+#include "hqq_common.h"
+
+namespace hqq {
+
+constexpr int G3_MAXL = HQQ_GEMV_MAX_GROUP;
+constexpr int G3_WAVES = 4;
+constexpr int G3_U = 4;                    // loads per unit -> 16 groups = 1024 k
+constexpr int G3_MAX_M = 4;
+
+typedef _Float16 g3_h8_t __attribute__((ext_vector_type(8)));
+
+struct G3Args {
+  const int32_t* Wq[G3_MAXL];
+  const half_t* scale[G3_MAXL];
+  const half_t* zero[G3_MAXL];
+  const half_t* bias[G3_MAXL];
+  half_t* y[G3_MAXL];
+  int N[G3_MAXL];
+  int step[G3_MAXL];       // ceil(N*G / 10)
+  int row_end[G3_MAXL];    // end (exclusive) of layer i's output rows in the group's concatenated row space
+  const half_t* x;
+  int K, G, total_rows;
+};
+
+struct G3Layer {
+  const int32_t* Wq;
+  const half_t* scale;
+  const half_t* zero;
+  const half_t* bias;
+  half_t* y;
+  int N, step, row0, end;
+};
+
+__device__ __forceinline__ G3Layer g3_select(const G3Args& a, int row) {
+  G3Layer c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], a.step[0], 0, a.row_end[0]};
+#pragma unroll
+  for (int i = 1; i < G3_MAXL; ++i) {
+    const bool in = row >= a.row_end[i - 1];
+    c.Wq = in ? a.Wq[i] : c.Wq;
+    c.scale = in ? a.scale[i] : c.scale;
+    c.zero = in ? a.zero[i] : c.zero;
+    c.bias = in ? a.bias[i] : c.bias;
+    c.y = in ? a.y[i] : c.y;
+    c.N = in ? a.N[i] : c.N;
+    c.step = in ? a.step[i] : c.step;
+    c.row0 = in ? a.row_end[i - 1] : c.row0;
+    c.end = in ? a.row_end[i] : c.end;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float g3_wave_sum(float v) {
+  auto dpp_add = [](float x, auto ctrl) {
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(float, y);
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+struct G3Unit {
+  u32x4 w[G3_U];          // words 4i..4i+3 of group (16*unit + 4u + j)
+  uint32_t sh[G3_U];      // bit position 27 - 3*slab of that group
+  uint16_t z, sc;         // lanes 0..15: zero / scale of group 16*unit + lane (raw fp16 bits)
+};
+
+template <int M>
+__global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // x[M][Kpad] fp16, natural order, zero padded to 1024-k units
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lj = lane >> 4;
+  const int K = a.K, G = a.G;
+  const int nunits = (G + 15) >> 4;
+  const int kpad = nunits * 1024;
+  const int stride = gridDim.x * G3_WAVES;
+  const int total = a.total_rows;
+
+  // ---- stage x (natural k order) ----
+  for (int v = tid; v < M * (kpad >> 3); v += G3_WAVES * 64) {
+    const int m = v / (kpad >> 3), j = v - m * (kpad >> 3);
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (j * 8 < K) val = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + j * 8);
+    *reinterpret_cast<u32x4*>(smem + (static_cast<size_t>(m) * kpad + j * 8) * 2) = val;
+  }
+
+  // r0 = first group row of output row `row`; groups past G (last unit of a row) re-read group 0 and meet zero x
+  auto issue = [&](G3Unit& un, const G3Layer& ly, int row, int unit) {
+    const int n = row - ly.row0;
+    const int r0 = n * G;
+    const int s0 = r0 / ly.step;                       // slab of the row's first group (wave-uniform)
+    const int bound = (s0 + 1) * ly.step;              // first group row of the next slab
+#pragma unroll
+    for (int u = 0; u < G3_U; ++u) {
+      int g = unit * 16 + u * 4 + lj;
+      g = g < G ? g : 0;
+      const int r = r0 + g;
+      const int s = s0 + (r >= bound ? 1 : 0);         // a row spans at most two slabs (G <= step)
+      const int p = r - s * ly.step;
+      un.sh[u] = 27 - 3 * s;
+      un.w[u] = *reinterpret_cast<const u32x4*>(ly.Wq + static_cast<int64_t>(p) * 64 + li * 4);
+    }
+    int gm = unit * 16 + (lane & 15);
+    gm = gm < G ? gm : 0;
+    un.z = __builtin_bit_cast(uint16_t, ly.zero[static_cast<int64_t>(r0) + gm]);
+    un.sc = __builtin_bit_cast(uint16_t, ly.scale[static_cast<int64_t>(r0) + gm]);
+  };
+
+  int row = blockIdx.x * G3_WAVES + wave;
+  int unit = 0;
+  G3Layer ly = g3_select(a, row < total ? row : total - 1);
+  G3Unit ua, ub;
+  if (row < total) issue(ua, ly, row, 0);
+  __syncthreads();
+
+  uint32_t magic;
+  asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+  f32x4 acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // four exactly-dequantised weights (one lane's words of one load) as two fp16 pairs in natural k order
+  auto deq4 = [&](const u32x4& w, uint32_t sh, uint32_t zs, uint32_t (&o)[2]) {
+    const half2_t pr = __builtin_bit_cast(half2_t, zs);
+    const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
+    const half2_t k1024 = {static_cast<half_t>(1024.0f), static_cast<half_t>(1024.0f)};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t t0 = w[2 * h] >> sh, t1 = w[2 * h + 1] >> sh;
+      const uint32_t pk = __builtin_amdgcn_perm(t1, t0, 0x0C040C00u);   // byte0 <- t0.b0, byte2 <- t1.b0, others 0
+      uint32_t b;
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(pk), "s"(0x00070007u), "v"(magic));
+      const half2_t q = __builtin_bit_cast(half2_t, b) - k1024;           // exact level
+      o[h] = __builtin_bit_cast(uint32_t, (q - zz) * ss);                 // two roundings, as Quantizer.dequantize
+    }
+  };
+
+  auto consume = [&](const G3Unit& cur, const G3Layer& oly, int orow, int unit) {
+    const uint32_t mine = static_cast<uint32_t>(cur.z) | (static_cast<uint32_t>(cur.sc) << 16);
+#pragma unroll
+    for (int u = 0; u < G3_U; u += 2) {
+      // loads u and u+1 -> one MFMA: this lane's k-octet = 4 values of group (4u+j) and 4 of group (4u+4+j)
+      const uint32_t zs0 = __builtin_amdgcn_ds_bpermute((u * 4 + lj) << 2, mine);
+      const uint32_t zs1 = __builtin_amdgcn_ds_bpermute(((u + 1) * 4 + lj) << 2, mine);
+      uint32_t o0[2], o1[2];
+      deq4(cur.w[u], cur.sh[u], zs0, o0);
+      deq4(cur.w[u + 1], cur.sh[u + 1], zs1, o1);
+      const g3_h8_t A = __builtin_bit_cast(g3_h8_t, u32x4{o0[0], o0[1], o1[0], o1[1]});
+      const int k0 = (unit * 16 + u * 4 + lj) * 64 + li * 4;   // past K: zero-padded x
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const u32x2 xa = *reinterpret_cast<const u32x2*>(smem + (static_cast<size_t>(m) * kpad + k0) * 2);
+        const u32x2 xb = *reinterpret_cast<const u32x2*>(smem + (static_cast<size_t>(m) * kpad + k0 + 256) * 2);
+        const g3_h8_t B = __builtin_bit_cast(g3_h8_t, u32x4{xa.x, xa.y, xb.x, xb.y});
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[m], 0, 0, 0);
+      }
+    }
+    if (unit == nunits - 1) {   // row finished
+      const int n = orow - oly.row0;
+      float mine_out = 0.f;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i = (lane & 15) - 4 * (lane >> 4);
+        const float part = i == 0 ? acc[m][0] : i == 1 ? acc[m][1] : i == 2 ? acc[m][2] : i == 3 ? acc[m][3] : 0.f;
+        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float v = g3_wave_sum(part);
+        mine_out = lane == m ? v : mine_out;
+      }
+      if (lane < M) {
+        half_t o = static_cast<half_t>(mine_out);
+        if (oly.bias) o = o + oly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+        oly.y[static_cast<int64_t>(lane) * oly.N + n] = o;
+      }
+    }
+  };
+
+  auto advance = [&](int& r, int& u, G3Layer& c) {
+    if (++u == nunits) {
+      u = 0;
+      r += stride;
+      if (r >= c.end && r < total) c = g3_select(a, r);
+    }
+  };
+
+  G3Layer la = ly;
+  if (row < total) {
+    for (;;) {
+      int r1 = row, u1 = unit;
+      advance(r1, u1, ly);
+      if (r1 >= total) { consume(ua, la, row, unit); break; }
+      const G3Layer lb = ly;
+      issue(ub, lb, r1, u1);
+      consume(ua, la, row, unit);
+      int r2 = r1, u2 = u1;
+      advance(r2, u2, ly);
+      if (r2 >= total) { consume(ub, lb, r1, u1); break; }
+      la = ly;
+      issue(ua, la, r2, u2);
+      consume(ub, lb, r1, u1);
+      row = r2;
+      unit = u2;
+    }
+  }
+}
+
+template <int M>
+static int g3_launch(const G3Args& a, hipStream_t st) {
+  const int nunits = (a.G + 15) >> 4;
+  const size_t lds = static_cast<size_t>(M) * nunits * 1024 * 2;
+  if (lds > 144 * 1024) { set_error("hqq_hip_gemv: x[M=%d, K=%d] does not fit the LDS staging budget", M, a.K); return HQQ_ERR_UNSUPPORTED; }
+  int n_cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0) n_cus = 256;
+  int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
+  per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
+  const int tiles = (a.total_rows + G3_WAVES - 1) / G3_WAVES;
+  const int cap = n_cus * per_cu;
+  auto kern = gemv3_f16_kernel<M>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(G3_WAVES * 64), lds, st, a);
+  return check_launch("hqq_hip_gemv(3-bit)");
+}
+
+// called by hqq_hip_gemv_grouped (gemv.hip) for nbits == 3 after the common argument checks
+int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st) {
+  if (group_size != 64) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers group_size 64 (got %lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
+  if (M > G3_MAX_M) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers M <= %d (got %lld)", G3_MAX_M, (long long)M); return HQQ_ERR_UNSUPPORTED; }
+  G3Args a;
+  const int64_t G = K / 64;
+  int64_t rows = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    if (N[i] <= 0) { set_error("hqq_hip_gemv: bad N"); return HQQ_ERR_SHAPE; }
+    if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
+    if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    const int64_t R = N[i] * G;
+    if (R > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    rows += N[i];
+    a.Wq[i] = static_cast<const int32_t*>(Wq[i]);
+    a.scale[i] = static_cast<const half_t*>(scale[i]);
+    a.zero[i] = static_cast<const half_t*>(zero[i]);
+    a.bias[i] = bias ? static_cast<const half_t*>(bias[i]) : nullptr;
+    a.y[i] = static_cast<half_t*>(y[i]);
+    a.N[i] = static_cast<int>(N[i]);
+    a.step[i] = static_cast<int>((R + 9) / 10);
+    a.row_end[i] = static_cast<int>(rows);
+    if (G > a.step[i]) { set_error("hqq_hip_gemv: 3-bit layer with fewer than 10 output rows per slab is not covered"); return HQQ_ERR_UNSUPPORTED; }
+  }
+  for (int i = n_layers; i < G3_MAXL; ++i) {
+    a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
+    a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.row_end[i] = a.row_end[n_layers - 1];
+  }
+  a.x = static_cast<const half_t*>(x);
+  a.K = static_cast<int>(K);
+  a.G = static_cast<int>(G);
+  a.total_rows = static_cast<int>(rows);
+  switch (M) {
+    case 1: return g3_launch<1>(a, st);
+    case 2: return g3_launch<2>(a, st);
+    case 3: return g3_launch<3>(a, st);
+    case 4: return g3_launch<4>(a, st);
+  }
+  return HQQ_ERR_SHAPE;
+}
+
+}  // namespace hqq

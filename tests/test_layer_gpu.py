@@ -125,8 +125,11 @@ def test_prepare_for_inference_swaps_layers(ops):
     prepare_for_inference(m, backend="hip")
     assert isinstance(m.q, HQQLinearHIP) and (m.q.in_features, m.q.out_features) == (256, 512) and m.q.bias is not None
     assert torch.equal(m.q.W_q.data, wq)                                   # packed bytes untouched (no repacking)
-    assert isinstance(m.inner[0], HQQLinear)                               # 3-bit: not covered by the fused kernels -> skipped, still works
-    assert torch.equal(m(x), before) and tuple(before.shape) == (2, 7, 256)
+    assert isinstance(m.inner[0], HQQLinearHIP) and m.inner[0].nbits == 3   # 3-bit: fused decode kernel for <= 4 rows, dequant + GEMM beyond
+    torch.testing.assert_close(m(x), before, rtol=1e-3, atol=1e-3)
+    assert tuple(before.shape) == (2, 7, 256)
+    x1 = x[:1, :1]
+    torch.testing.assert_close(m(x1), before[:1, :1], rtol=1e-3, atol=2e-3)   # decode-sized call goes through the fused kernels
     assert torch.equal(m.q.dequantize().shape, torch.Size([512, 256])) if False else tuple(m.q.dequantize().shape) == (512, 256)
 
 
