@@ -13,10 +13,10 @@
 //
 // Launch shape: a *group* of up to GV_MAXL layers that read the same activation rows (q/k/v, gate/up, or
 // a single layer) is one launch.  Their packed rows form one concatenated row space that a persistent
-// grid (<= 2 workgroups per CU, 8 waves each) strides over; one wave owns one packed row (-> `per`
-// output rows) at a time and walks it in 4 KiB units (4 x global_load_dwordx4 per lane, non-temporal).
+// grid (<= 4 workgroups of 4 waves per CU) strides over; one wave owns one packed row (-> `per`
+// output rows) at a time and walks it in 2 KiB units (2 x global_load_dwordx4 per lane, non-temporal).
 // The loads of unit i+1 are issued before unit i is consumed, and the very first unit is requested
-// before x is staged, so every wave keeps 4-8 KiB of the weight stream in flight.
+// before x is staged, so every wave keeps 2-4 KiB of the weight stream in flight (16 waves per CU).
 //   x       staged once per workgroup in LDS, in the order the nibble extraction produces values
 //   meta    per unit the (zero, scale) of the <= 64 groups it spans are fetched with one coalesced
 //           2-byte load per lane and slab and handed to the consuming lanes with ds_bpermute
@@ -47,7 +47,10 @@ namespace hqq {
 #endif
 constexpr int GV_WAVES = GV_WAVES_PER_WG;  // waves per workgroup (256 threads; 4 workgroups per CU measured best)
 constexpr int GV_KSTEP = 1024;            // k covered by one wave load instruction: 64 lanes x 16 bytes
-constexpr int GV_U = 4;                   // load instructions per unit
+#ifndef GV_U_LOADS
+#define GV_U_LOADS 2
+#endif
+constexpr int GV_U = GV_U_LOADS;          // load instructions per unit
 constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
 constexpr int GV_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int GV_LDS_MAX = 144 * 1024;    // x staging budget per workgroup

@@ -44,7 +44,7 @@ def rand_layer(N, K, nbits, gs=64, dt=torch.float16):
 
 
 def gemv_bytes(N, K, nbits, M=1, gs=64):
-    wq = N * K * nbits // 8
+    wq = 4 * gs * ((N * K // gs + 9) // 10) if nbits == 3 else N * K * nbits // 8
     return wq + 4 * (N * K // gs) + 2 * K * M + 2 * N * M
 
 

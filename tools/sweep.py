@@ -48,6 +48,10 @@ def main():
                 t, nb = gemv_time(N, K, nbits, 1, g)
                 row(nbits, mname, label, f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{nb / t / HBM * 100:.1f}")
     ops.set_gemv_mode(ops.GEMV_EXACT)
+    for label, N, K, g in (("o 4096x4096", 4096, 4096, 1), ("q|k|v 3x4096x4096", 4096, 4096, 3), ("gate|up 2x11008x4096", 11008, 4096, 2),
+                           ("down 4096x11008", 4096, 11008, 1)):
+        t, nb = gemv_time(N, K, 3, 1, g)
+        row(3, "exact", label, f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{nb / t / HBM * 100:.1f}")
     print("\n## small batches (exact mode, int4, 11008x4096)\n")
     row("M", "µs", "GB/s", "kernel")
     row("---", "---", "---", "---")
