@@ -170,10 +170,12 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor
     return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
 
 
-# Above this many activation rows `forward` composes the HIP dequantise kernel with a plain library GEMM (hipBLASLt through
-# torch.matmul): one extra write+read of the fp16 weights (2*N*K*2 bytes) is then < 10 % of the GEMM time and the library's
-# tuned MFMA pipeline (1.26 PFLOP/s at 8192x4096x4096) beats the fused kernel (0.65-0.83).  0 disables the composition.
-LIBRARY_GEMM_MIN_M = 1024
+# From this many activation rows on, `forward` composes the HIP dequantise kernel with a plain library GEMM (hipBLASLt through
+# torch.matmul).  Measured on MI355X (profiles/r01_sweep.md): the composition costs one extra write+read of the fp16 weights
+# (13.6 us for 4096x4096) and then runs the library's tuned MFMA pipeline — 26 us at M = 256 and 1.05-1.4 PFLOP/s at M = 8192,
+# against 81 us / 0.63-0.83 PFLOP/s for the fused 128-tile kernel, whose only remaining advantage is that it needs no N*K*2-byte
+# temporary.  `fused=True` (or LIBRARY_GEMM_MIN_M = 0) forces the fused kernel.  M <= 16 always takes the fused decode kernels.
+LIBRARY_GEMM_MIN_M = 17
 
 
 def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None) -> Tensor:

@@ -101,3 +101,17 @@ def test_patching_skips_and_rejects():
     assert patch_hqq_to_hip(lin, None) is lin
     empty = HQQLinear(None, None)
     assert HQQLinearHIP.check(empty) is False
+
+
+def test_custom_ops_registered_with_fake_kernels():
+    """torch.library nodes for compile/export graphs: shape/dtype inference must work without touching a GPU"""
+    import hqq_amd.custom_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert hasattr(torch.ops.hqq_hip, "forward") and hasattr(torch.ops.hqq_hip, "dequantize")
+    with FakeTensorMode():
+        Wq = torch.empty(2048, 64, dtype=torch.uint8)
+        s = torch.empty(4096, 1, dtype=torch.float16)
+        x = torch.empty(2, 3, 512, dtype=torch.float16)
+        y = torch.ops.hqq_hip.forward(x, Wq, s, s, None, 512, 512, 64, 4)
+        W = torch.ops.hqq_hip.dequantize(Wq, s, s, 512, 512, 64, 4, 1)
+    assert tuple(y.shape) == (2, 3, 512) and y.dtype == torch.float16 and tuple(W.shape) == (512, 512)

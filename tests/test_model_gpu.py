@@ -1,0 +1,58 @@
+"""End-to-end on a GPU: a randomly initialised HF Llama decoder is quantised layer by layer with the HIP solver, runs through
+the fused kernels via the reference's call chain (decoder layer -> q_proj(x) -> HQQLinear.forward), survives
+prepare_for_inference, and decodes.  Small sizes: this is a plumbing test of SURVEY.md §8b "what calls it"."""
+import pytest
+
+torch = pytest.importorskip("torch")
+transformers = pytest.importorskip("transformers")
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=512, max_position_embeddings=128)
+    return LlamaForCausalLM(cfg).half().cuda().eval()
+
+
+@pytest.mark.parametrize("nbits", [4, 3])
+def test_quantize_hf_llama_and_decode(nbits):
+    from hqq_amd.backends.hip import HQQLinearHIP
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear
+    from hqq_amd.utils.model import LLAMA_LINEAR_TAGS, quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    assert torch.cuda.is_available()
+    model = _tiny_llama()
+    ids = torch.randint(0, 512, (2, 9), generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        ref = model(ids).logits.float()
+    cfg = BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1)
+    quantize_model(model, cfg, compute_dtype=torch.float16, device="cuda")
+    qs = [m for m in model.modules() if isinstance(m, HQQLinear)]
+    assert len(qs) == 2 * len(LLAMA_LINEAR_TAGS) and all(q.ready and q.W_q.is_cuda for q in qs)
+    assert isinstance(model.lm_head, torch.nn.Linear)                      # untagged linears are left alone
+    model.to(torch.float16)                                                # HF-style .to() must not disturb packed weights
+    with torch.no_grad():
+        out = model(ids).logits.float()
+        one = model(ids[:, :1]).logits.float()                             # bs*seq = 2 rows -> the fused decode kernels
+    # (i) plumbing: the fused kernels give what dequantise + dense matmul give on the same quantised weights
+    HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+    try:
+        with torch.no_grad():
+            dense = model(ids).logits.float()
+    finally:
+        HQQLinear.set_backend(HQQBackend.HIP)
+    torch.testing.assert_close(out, dense, rtol=2e-3, atol=2e-3)
+    # (ii) sanity: quantisation noise only (random-init weights are the worst case for a 2-block toy model)
+    rel = (out - ref).norm() / ref.norm()
+    assert rel < (0.3 if nbits == 4 else 0.6), f"quantised logits drifted: rel {rel:.3f}"
+    prepare_for_inference(model, backend="hip")
+    assert sum(isinstance(m, HQQLinearHIP) for m in model.modules()) == len(qs)
+    with torch.no_grad():
+        out2 = model(ids).logits.float()
+        one2 = model(ids[:, :1]).logits.float()
+        gen = model.generate(ids[:1, :4], max_new_tokens=5, do_sample=False)
+    torch.testing.assert_close(out2, out, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(one2, one, rtol=2e-3, atol=2e-3)
+    assert tuple(gen.shape) == (1, 9)
