@@ -194,14 +194,21 @@ struct SlabExact {
     const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
     const half2_t pr = as_h2(zs[S]);
     const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
+    // stage-wise over the eight weight pairs (not pair by pair): eight independent chains keep the packed-fp16 pipe busy
+    // instead of stalling on each fma -> add -> mul dependency
+    half2_t q[8];
     uint32_t o[8];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const half2_t q0 = __builtin_elementwise_fma(biased_levels<NBITS, S>(w[d], magic), k1, k2);        // bytes (4d+0, 4d+2)
-      const half2_t q1 = __builtin_elementwise_fma(biased_levels<NBITS, S>(w[d] >> 8, magic), k1, k2);   // bytes (4d+1, 4d+3)
-      o[2 * d] = __builtin_bit_cast(uint32_t, (q0 - zz) * ss);
-      o[2 * d + 1] = __builtin_bit_cast(uint32_t, (q1 - zz) * ss);
+      q[2 * d] = biased_levels<NBITS, S>(w[d], magic);            // bytes (4d+0, 4d+2)
+      q[2 * d + 1] = biased_levels<NBITS, S>(w[d] >> 8, magic);   // bytes (4d+1, 4d+3)
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], k1, k2);   // exact integer level
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = q[i] - zz;                                  // rounding 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_bit_cast(uint32_t, q[i] * ss);    // rounding 2
     const h8_t a0 = __builtin_bit_cast(h8_t, u32x4{o[0], o[1], o[2], o[3]});
     const h8_t a1 = __builtin_bit_cast(h8_t, u32x4{o[4], o[5], o[6], o[7]});
 #pragma unroll

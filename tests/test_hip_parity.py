@@ -333,6 +333,21 @@ def test_gemm_vs_oracle(ops, oracle, nbits, M, N, K):
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
+def test_gemm_wave_specialised_variant(ops, nbits, monkeypatch):
+    """opt-in producer/consumer kernel (HQQ_HIP_GEMM_WS=1): same tiles, same exact weights -> same result as the default kernel
+    up to fp32 summation order (here: identical k order per output, so bit-identical)"""
+    M, N, K = 16384, 4096, 512
+    U, s, z = _random_layer(N, K, 64, nbits, seed=3)
+    P = ops.pack(nbits, U.cuda())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).half().cuda()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).half().cuda()
+    base = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
+    monkeypatch.setenv("HQQ_HIP_GEMM_WS", "1")
+    ws = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
+    assert torch.equal(ws, base)
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
 def test_forward_full_size_properties(ops, nbits):
     """Llama-2-7B shapes (BASELINE.json configs[1]): linearity and one-hot exactness, no oracle needed."""
     for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008)]:
