@@ -143,6 +143,8 @@ def main():
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
+    if os.environ.get("HQQ_BENCH_ONE_GPU"):   # debug: every rank on GPU 0 (single-GPU boxes; use with HQQ_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -150,7 +152,11 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("HQQ_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from hqq_amd import ops
     assert ops.is_available(), "libhqq_hip.so must be built (python -c 'import __graft_entry__ as g; g.build()')"
@@ -198,7 +204,9 @@ def main():
                     dist.all_gather_into_tensor(out_full[grp], ol.view(len(grp) * M, -1))
 
     # ---- graph capture (launch-bound inner loop -> one hipGraph replay per step) ----
-    use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0"
+    # hipGraph capture of the whole step (incl. the RCCL all-gathers for N > 1; torch captures NCCL collectives).  Backends
+    # that stage through the host (gloo debug mode) cannot be captured: launch eagerly there.
+    use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0" and (world == 1 or dist.get_backend() == "nccl")
     graph = None
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -209,7 +217,7 @@ def main():
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 step()
             graph.replay()
             torch.cuda.synchronize()
@@ -217,6 +225,7 @@ def main():
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else step
     mode_name = {ops.GEMV_EXACT: "exact", ops.GEMV_FACTORED: "factored"}[ops.get_gemv_mode()]
 

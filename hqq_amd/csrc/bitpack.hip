@@ -213,6 +213,7 @@ int64_t hqq_hip_packed_rows(int nbits, int64_t rows) {
 }
 
 int hqq_hip_pack(int nbits, const void* U, int in_dtype, int64_t rows, int64_t cols, void* out, void* stream) {
+  clear_stale_error();
   const int64_t prow = hqq_hip_packed_rows(nbits, rows);
   if (prow < 0) { set_error("hqq_hip_pack: nbits=%d rows=%lld not packable", nbits, (long long)rows); return static_cast<int>(prow); }
   if (in_dtype != HQQ_U8 && in_dtype != HQQ_F32) { set_error("hqq_hip_pack: in_dtype must be U8 or F32"); return HQQ_ERR_DTYPE; }
@@ -232,6 +233,7 @@ int hqq_hip_pack(int nbits, const void* U, int in_dtype, int64_t rows, int64_t c
 }
 
 int hqq_hip_unpack(int nbits, const void* packed, int64_t packed_rows, int64_t cols, void* out, int out_dtype, void* stream) {
+  clear_stale_error();
   const int per = per_of(nbits);
   if (!per) { set_error("hqq_hip_unpack: nbits=%d not in {8,4,3,2,1}", nbits); return HQQ_ERR_NBITS; }
   if (!aligned16(packed) || !aligned16(out)) { set_error("hqq_hip_unpack: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
@@ -250,6 +252,7 @@ int hqq_hip_unpack(int nbits, const void* packed, int64_t packed_rows, int64_t c
 
 int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void* zero, void* out,
                        int64_t N, int64_t K, int64_t group_size, int axis, int dtype, void* stream) {
+  clear_stale_error();
   const int per = per_of(nbits);
   if (!per) { set_error("hqq_hip_dequantize: nbits=%d not in {8,4,3,2,1}", nbits); return HQQ_ERR_NBITS; }
   const int64_t total = N * K;

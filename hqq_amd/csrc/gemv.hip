@@ -648,6 +648,7 @@ extern unsigned long long* g_lab_ts;
 extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
                                     const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
                                     int64_t M, int64_t K, int64_t group_size, int dtype, void* stream) {
+  clear_stale_error();
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }

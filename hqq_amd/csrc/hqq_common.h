@@ -19,6 +19,9 @@ struct bf16_t { uint16_t v; };
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// hipLaunchKernelGGL reports through the sticky last-error slot: drop whatever an earlier, unrelated failure (e.g. an invalidated
+// stream capture in the caller) left there, so that check_launch() reports this call's launch only
+static inline void clear_stale_error() { (void)hipGetLastError(); }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

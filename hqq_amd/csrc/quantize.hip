@@ -335,6 +335,7 @@ int hqq_hip_quantize(const void* W, int w_dtype, int64_t numel, int64_t group_si
                      int round_zero, int optimize, int iters, float beta, float lp_norm,
                      void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
                      void* workspace, size_t workspace_bytes, void* stream) {
+  clear_stale_error();
   if (numel <= 0 || group_size <= 0 || numel % group_size) {   // quantize.py:94-100
     set_error("hqq_hip_quantize: group_size should divide the tensor size (numel=%lld, group_size=%lld)", (long long)numel, (long long)group_size);
     return HQQ_ERR_SHAPE;
