@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
     ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
+    ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-codes", action="store_true", help="skip the solver: random packed codes + meta (faster setup)")
     ap.add_argument("--gemv-mode", default="exact", choices=["exact", "factored"],
@@ -188,7 +189,32 @@ def main():
 
     grouped = decode and not a.no_group and nbits in (4, 2, 8, 1)
 
+    # --streams S > 1 (study mode, not the headline): the step's launches are dealt over S parallel graph branches, i.e. the
+    # dependency chain q|k|v -> o -> gate|up -> down of a real decoder is NOT modelled and consecutive launches may overlap;
+    # it shows what the kernels sustain once launch boundaries are hidden.  Outputs then need one buffer per launch in flight.
+    S = max(1, a.streams)
+    branch_streams = [torch.cuda.Stream() for _ in range(S - 1)] if S > 1 else []
+    if S > 1:
+        out_local_s = [{g: torch.empty_like(t) for g, t in out_local.items()} for _ in range(S)]
+
     def step():
+        if S > 1:
+            main = torch.cuda.current_stream()
+            for st in branch_streams:
+                st.wait_stream(main)
+            i = 0
+            for blk in blocks:
+                for grp in EXCHANGE_GROUPS:
+                    b = i % S
+                    i += 1
+                    with torch.cuda.stream(main if b == 0 else branch_streams[b - 1]):
+                        ol = out_local_s[b][grp]
+                        Ls = [blk[name] for name in grp]
+                        ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
+                                         outs=[ol[j] for j in range(len(grp))])
+            for st in branch_streams:
+                main.wait_stream(st)
+            return
         for blk in blocks:
             for grp in EXCHANGE_GROUPS:
                 ol = out_local[grp]
@@ -268,7 +294,7 @@ def main():
             "value": round(gbs, 2), "unit": "GB/s",
             "tok_s": round(M / sec_per_step, 2),
             "config": {"workload": f"llama2-7b linear stack ({nblocks} blocks x q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, bs={M} decode, "
-                                   f"fp16, {launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" + (", hipGraph replay" if graph is not None else ", eager launches"),
+                                   f"fp16, {launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" + (", hipGraph replay" if graph is not None else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather (weak: {world}x wider layers)",
                        "gemv_mode": mode_name, "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
         })

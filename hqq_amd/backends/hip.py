@@ -82,3 +82,71 @@ def patch_hqq_to_hip(layer, patch_params=None):
         return new
     layer.linear_layer = new   # HQQLinearLoRA-style wrapper keeps its adapters
     return layer
+
+
+class _GroupedMember(nn.Module):
+    """One of several HQQLinearHIP layers that are always called with the same activation tensor (q/k/v, gate/up).
+    The first member called with a new `x` launches ONE grouped kernel for the whole set (hqq_hip_gemv_grouped) and parks the
+    siblings' outputs; the siblings then return theirs without a launch.  Falls back to the member's own forward for batches the
+    grouped decode kernel does not cover.  Transparent to the calling code (HF attention / MLP modules)."""
+
+    def __init__(self, layer: HQQLinearHIP, group: "_GroupState", index: int):
+        super().__init__()
+        self.layer, self._group, self._index = layer, group, index
+        self.in_features, self.out_features, self.bias = layer.in_features, layer.out_features, layer.bias
+        self.compute_dtype, self.device = layer.compute_dtype, layer.device
+
+    def dequantize(self) -> Tensor:
+        return self.layer.dequantize()
+
+    def forward(self, x: Tensor) -> Tensor:
+        g = self._group
+        if g.x is x and g.version == x._version and g.outs[self._index] is not None:
+            out, g.outs[self._index] = g.outs[self._index], None
+            return out
+        rows = x.numel() // x.shape[-1]
+        if rows > g.max_rows or x.dtype != torch.float16:
+            return self.layer(x)
+        layers = [m.layer for m in g.members]
+        outs = ops.gemv_grouped(x, [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers], self.in_features,
+                                layers[0].group_size, layers[0].nbits)
+        g.x, g.version, g.outs = x, x._version, list(outs)
+        out, g.outs[self._index] = g.outs[self._index], None
+        return out
+
+
+class _GroupState:
+    def __init__(self):
+        self.members, self.x, self.version, self.outs, self.max_rows = [], None, -1, [], 4
+
+
+def group_projections(parent: nn.Module, names) -> bool:
+    """Fuse `parent.<name>` for name in names (all HQQLinearHIP, same in_features / nbits / group_size, fp16) into one grouped
+    launch per distinct input.  Returns False (and changes nothing) when the layers cannot be grouped."""
+    layers = [getattr(parent, n, None) for n in names]
+    if not all(isinstance(L, HQQLinearHIP) for L in layers) or not 2 <= len(layers) <= ops.GEMV_MAX_GROUP:
+        return False
+    L0 = layers[0]
+    if any((L.in_features, L.nbits, L.group_size, L.compute_dtype) != (L0.in_features, L0.nbits, L0.group_size, torch.float16) for L in layers):
+        return False
+    if L0.nbits == 3 and any(L.group_size != 64 for L in layers):
+        return False
+    state = _GroupState()
+    state.max_rows = 4 if L0.nbits == 3 else ops.GEMV_MAX_M
+    for i, (n, L) in enumerate(zip(names, layers)):
+        m = _GroupedMember(L, state, i)
+        state.members.append(m)
+        setattr(parent, n, m)
+    return True
+
+
+def group_llama_projections(model: nn.Module) -> int:
+    """q|k|v and gate|up of every Llama-style decoder block -> grouped launches (what bench.py measures).  Returns the number
+    of groups formed.  Call after prepare_for_inference(model, backend="hip")."""
+    n = 0
+    for mod in model.modules():
+        if all(hasattr(mod, a) for a in ("q_proj", "k_proj", "v_proj")):
+            n += int(group_projections(mod, ("q_proj", "k_proj", "v_proj")))
+        if all(hasattr(mod, a) for a in ("gate_proj", "up_proj")):
+            n += int(group_projections(mod, ("gate_proj", "up_proj")))
+    return n

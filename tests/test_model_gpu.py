@@ -56,3 +56,11 @@ def test_quantize_hf_llama_and_decode(nbits):
     torch.testing.assert_close(out2, out, rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(one2, one, rtol=2e-3, atol=2e-3)
     assert tuple(gen.shape) == (1, 9)
+    # q|k|v and gate|up as grouped launches (one kernel per distinct input): transparent to the HF modules, same numbers
+    from hqq_amd.backends.hip import group_llama_projections
+    assert group_llama_projections(model) == 2 * 2
+    with torch.no_grad():
+        one3 = model(ids[:, :1]).logits.float()          # 2 rows -> grouped decode kernel
+        out3 = model(ids).logits.float()                 # 18 rows -> members fall back to their own forward
+        gen3 = model.generate(ids[:1, :4], max_new_tokens=5, do_sample=False)
+    assert torch.equal(one3, one2) and torch.equal(out3, out2) and torch.equal(gen3, gen)
