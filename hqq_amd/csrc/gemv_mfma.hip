@@ -22,9 +22,10 @@
 // at k = 64*kb + 16*c (global_load_dwordx4, non-temporal; a wave instruction covers 16 rows x 64 contiguous bytes),
 // dequantises them in registers, and feeds two MFMAs per slab (k-octets 16c + 0..7 and 16c + 8..15).  Loads are issued
 // four blocks (one *unit*, 4 KiB per wave) ahead of their use, ping-pong between two register sets.
-//   x      [M, K] staged once per workgroup in LDS, rows padded so that the B-operand ds_read_b128 are conflict-free, in the
-//          k order the nibble extraction produces ((k0,k2),(k1,k3),(k4,k6),(k5,k7) inside each octet); lanes of the
-//          unused columns M..15 read a shared zero row.
+//   x      [M, K] is read straight from global memory (it is a few hundred KiB at most and L2-resident): lane (r, c) loads
+//          the two k-octets it needs of activation row r together with the weights of the same unit and permutes them in
+//          registers into the k order the nibble extraction produces ((k0,k2),(k1,k3),(k4,k6),(k5,k7)); lanes of the unused
+//          columns M..15 hold zeros.  No LDS staging, hence no limit on M*K and no extra passes over the weights.
 //   meta   group_size 64: one 64-k block is exactly one group; per unit each lane fetches (zero, scale) of group
 //          (4*unit + c) of its row with coalesced 2-byte loads and the four blocks pick theirs with ds_bpermute.
 //          other group sizes: fetched per lane and block.
@@ -35,9 +36,8 @@
 namespace hqq {
 
 constexpr int GM_MAXL = HQQ_GEMV_MAX_GROUP;
-constexpr int GM_UB = 4;              // 64-k blocks per unit
+constexpr int GM_UB = 2;              // 64-k blocks per unit
 constexpr int GM_MAX_M = HQQ_GEMV_MAX_M;
-constexpr int GM_LDS_MAX = 152 * 1024;
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
@@ -50,7 +50,7 @@ struct GmArgs {
   int N[GM_MAXL];          // out_features
   int tile_end[GM_MAXL];   // end (exclusive) of layer i's tiles in the group's concatenated tile space (unused entries repeat the last)
   const half_t* x;
-  int M, K, gs, total_tiles, x_stride /* bytes between rows of x in LDS */;
+  int M, K, gs, total_tiles;
 };
 
 struct GmLayer {   // the layer a workgroup is currently streaming (workgroup-uniform -> SGPRs)
@@ -133,6 +133,7 @@ struct GmSlab {
 template <int PER, bool GS64>
 struct GmUnit {
   u32x4 w[GM_UB];
+  u32x4 xv[GM_UB][2];   // this lane's two k-octets of activation row r per block (zeros for r >= M)
   // raw 2-byte loads, combined only when consumed.  GS64: the pair of group (4*unit + c) of the lane's row, per slab;
   // otherwise the pair of the group the lane's 16 k-values of block b fall into, [b * PER + s]
   uint16_t z[GS64 ? PER : GM_UB * PER];
@@ -155,9 +156,7 @@ __global__ __launch_bounds__(1024) void gemv_mfma_f16_kernel(const GmArgs a) {
   const int kb1 = static_cast<int>(static_cast<int64_t>(nb) * (wave + 1) / KS);
   const int nunits = (kb1 - kb0 + GM_UB - 1) / GM_UB;   // may be 0 when KS > nb
 
-  // LDS: x rows (M real + 1 zero row) | reduction buffer [KS][PER][64] f32x4
-  const int xs_bytes = (M + 1) * a.x_stride;
-  f32x4* red = reinterpret_cast<f32x4*>(smem + ((xs_bytes + 15) & ~15));
+  f32x4* red = reinterpret_cast<f32x4*>(smem);   // LDS: reduction buffer [KS][PER][64] f32x4 only
 
   // Every issue() emits exactly GM_UB weight loads + the unit's meta loads, live or not, so that the waits the compiler
   // derives are exact vmcnt(<loads of the following unit>).  Blocks past the slice / rows past the layer re-read a valid
@@ -196,6 +195,9 @@ __global__ __launch_bounds__(1024) void gemv_mfma_f16_kernel(const GmArgs a) {
       int kb = kbu + b;
       kb = kb < kb1 ? kb : kb0;                          // past the slice: re-read its first block (skipped by consume)
       un.w[b] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(kb) * 64));
+      const u32x4* xp = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(r < M ? r : 0) * K + kb * 64 + c * 16);
+      un.xv[b][0] = xp[0];
+      un.xv[b][1] = xp[1];
     }
   };
 
@@ -206,19 +208,7 @@ __global__ __launch_bounds__(1024) void gemv_mfma_f16_kernel(const GmArgs a) {
   const bool have_work = nunits > 0 && tile < total;
   if (have_work) issue(ua, ly, tile, 0);
 
-  // ---- stage x[M, K] (+ one zero row) into LDS, permuted inside each k-octet ----
-  {
-    const int vec_per_row = K >> 3;
-    for (int v = tid; v < (M + 1) * vec_per_row; v += blockDim.x) {
-      const int m = v / vec_per_row, j = v - m * vec_per_row;
-      u32x4 val = {0u, 0u, 0u, 0u};
-      if (m < M) val = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + j * 8);
-      *reinterpret_cast<u32x4*>(smem + m * a.x_stride + j * 16) = gm_permute_x8(val);
-    }
-    __syncthreads();
-  }
-  // B operand of this lane: column (= row of x) r, k-octets 16c + 0..7 / + 8..15 of every block; columns >= M read zeros
-  const uint8_t* xrow = smem + (r < M ? r : M) * a.x_stride + c * 32;
+  const bool col_live = r < M;   // this lane's MFMA column carries a real activation row
 
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));   // opaque to the optimiser: stays in a VGPR
@@ -242,8 +232,9 @@ __global__ __launch_bounds__(1024) void gemv_mfma_f16_kernel(const GmArgs a) {
         }
       }
       if (kb < kb1) {   // wave-uniform
-        const h8_t b0 = *reinterpret_cast<const h8_t*>(xrow + kb * 128);
-        const h8_t b1 = *reinterpret_cast<const h8_t*>(xrow + kb * 128 + 16);
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        const h8_t b0 = __builtin_bit_cast(h8_t, col_live ? gm_permute_x8(cur.xv[b][0]) : zero4);
+        const h8_t b1 = __builtin_bit_cast(h8_t, col_live ? gm_permute_x8(cur.xv[b][1]) : zero4);
         GmSlab<NBITS, 0, PER>::run(cur.w[b], zs, b0, b1, acc, magic);
       }
     }
@@ -340,28 +331,12 @@ static int gm_launch(GmArgs& a, hipStream_t st) {
   ks = ks > ks_max ? ks_max : ks;
   const int ks_cap = 32 / PER < 16 ? 32 / PER : 16;      // reduction buffer <= 32 KiB
   ks = ks > ks_cap ? ks_cap : (ks < 1 ? 1 : ks);
-  // row stride of x in LDS: (stride / 16) % 16 == 2 makes the 16 lanes of every ds_read_b128 group hit distinct banks
-  int stride16 = (a.K * 2 + 15) / 16;
-  stride16 += (2 - stride16 % 16 + 16) % 16;
-  a.x_stride = stride16 * 16;
-  const size_t xs = static_cast<size_t>(a.M + 1) * a.x_stride;
-  const size_t lds = ((xs + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(ks) * PER * 64 * sizeof(f32x4);
-  if (lds > static_cast<size_t>(GM_LDS_MAX)) return HQQ_ERR_UNSUPPORTED;
-  const int waves_per_cu_lds = static_cast<int>(160 * 1024 / lds) * ks;
-  int wg_per_cu = 16 / ks;                               // <= 16 waves per CU
-  if (wg_per_cu * ks > waves_per_cu_lds) wg_per_cu = waves_per_cu_lds / ks;
+  const size_t lds = static_cast<size_t>(ks) * PER * 64 * sizeof(f32x4);
+  int wg_per_cu = 16 / ks;                               // <= 16 waves per CU (105 VGPRs -> 4 waves per SIMD)
   wg_per_cu = wg_per_cu < 1 ? 1 : wg_per_cu;
   const int cap = cus * wg_per_cu;
   const int grid = a.total_tiles < cap ? a.total_tiles : cap;
   auto kern = gemv_mfma_f16_kernel<NBITS, GS64>;
-  if (lds > 64 * 1024) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS_MAX);
-      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-      raised = true;
-    }
-  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ks * 64), lds, st, a);
   return check_launch("hqq_hip_gemv");
 }
@@ -375,15 +350,6 @@ static int gm_dispatch(int nbits, GmArgs& a, hipStream_t st) {
     case 1: return gm_launch<1, false>(a, st);
   }
   return HQQ_ERR_NBITS;
-}
-
-// rows of x one launch can stage in LDS
-static int gm_max_m(int64_t K) {
-  int64_t stride16 = (K * 2 + 15) / 16;
-  stride16 += (2 - stride16 % 16 + 16) % 16;
-  const int64_t avail = GM_LDS_MAX - 32 * 1024 - 16;     // reduction buffer is capped at 32 KiB (gm_launch)
-  const int64_t m = avail / (stride16 * 16) - 1;
-  return static_cast<int>(m < 1 ? 0 : (m > GM_MAX_M ? GM_MAX_M : m));
 }
 
 // exact-weights skinny GEMM; called by hqq_hip_gemv_grouped (gemv.hip) after argument validation
@@ -410,18 +376,10 @@ int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq,
   a.K = static_cast<int>(K);
   a.gs = static_cast<int>(group_size);
   a.total_tiles = static_cast<int>(tiles);
-  const int m_max = gm_max_m(K);
-  if (m_max < 1) { set_error("hqq_hip_gemv: K=%lld too large to stage one row of x in LDS", (long long)K); return HQQ_ERR_UNSUPPORTED; }
-  // rows of x beyond the LDS budget of one launch are served by further launches over row blocks of x / y
-  for (int64_t m0 = 0; m0 < M; m0 += m_max) {
-    GmArgs b = a;
-    b.M = static_cast<int>(M - m0 < m_max ? M - m0 : m_max);
-    b.x = static_cast<const half_t*>(x) + m0 * K;
-    for (int i = 0; i < GM_MAXL; ++i) b.y[i] = a.y[i] + m0 * a.N[i];
-    const int rc = gm_dispatch(nbits, b, st);
-    if (rc == HQQ_ERR_UNSUPPORTED) { set_error("hqq_hip_gemv: x[M=%d, K=%lld] does not fit the LDS staging budget", b.M, (long long)K); }
-    if (rc) return rc;
-  }
+  a.M = static_cast<int>(M);
+  a.x = static_cast<const half_t*>(x);
+  const int rc = gm_dispatch(nbits, a, st);
+  if (rc) return rc;
   return 0;
 }
 
