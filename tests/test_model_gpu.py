@@ -64,3 +64,24 @@ def test_quantize_hf_llama_and_decode(nbits):
         out3 = model(ids).logits.float()                 # 18 rows -> members fall back to their own forward
         gen3 = model.generate(ids[:1, :4], max_new_tokens=5, do_sample=False)
     assert torch.equal(one3, one2) and torch.equal(out3, out2) and torch.equal(gen3, gen)
+
+
+def test_graphed_greedy_decoder_matches_generate():
+    """one hipGraph per decode step over the quantised model (fused GEMVs, grouped q|k|v / gate|up) == eager greedy generate"""
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    model = _tiny_llama()
+    quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    ids = torch.randint(0, 512, (1, 6), generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        want = model.generate(ids, max_new_tokens=12, do_sample=False)
+    dec = GraphedGreedyDecoder(model, max_cache_len=64)
+    eager = dec.generate(ids, 12, use_graph=False)
+    graphed = dec.generate(ids, 12, use_graph=True)
+    assert dec.graph is not None
+    assert torch.equal(eager, want) and torch.equal(graphed, want)
