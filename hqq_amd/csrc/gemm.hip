@@ -55,7 +55,7 @@ __device__ __forceinline__ u32x4 g_permute_x8(u32x4 v) {   // (k0..k7) -> (k0,k2
 // byte offset of 16-byte chunk `c` (0..7) of row `row` in a [rows][64] fp16 LDS tile
 __device__ __forceinline__ int lds_off(int row, int c) { return row * 128 + ((c ^ (row & 7)) << 4); }
 
-template <int NBITS, int S, int PER>
+template <int NBITS, int S, int PER, int BN = GB_N>
 struct DeqSlab {
   // dequantise the 16 k-values of slab S held in `w` and write them (2 chunks) to the W tile
   static __device__ __forceinline__ void run(const u32x4& w, const half_t (&z)[PER], const half_t (&s)[PER], uint8_t* ldsW,
@@ -69,10 +69,10 @@ struct DeqSlab {
       o[2 * d] = g_as_u32((q0 - zz) * ss);        // (k0,k2) of quad d
       o[2 * d + 1] = g_as_u32((q1 - zz) * ss);    // (k1,k3)
     }
-    const int row = S * (GB_N / PER) + prow_in_tile;
+    const int row = S * (BN / PER) + prow_in_tile;
     *reinterpret_cast<u32x4*>(ldsW + lds_off(row, kchunk16 * 2)) = u32x4{o[0], o[1], o[2], o[3]};
     *reinterpret_cast<u32x4*>(ldsW + lds_off(row, kchunk16 * 2 + 1)) = u32x4{o[4], o[5], o[6], o[7]};
-    if constexpr (S + 1 < PER) DeqSlab<NBITS, S + 1, PER>::run(w, z, s, ldsW, prow_in_tile, kchunk16);
+    if constexpr (S + 1 < PER) DeqSlab<NBITS, S + 1, PER, BN>::run(w, z, s, ldsW, prow_in_tile, kchunk16);
   }
 };
 
@@ -220,32 +220,53 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : 1) void gemm_f16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant for large M: 256 tokens x 128 features per workgroup, 8 waves.  Waves 0-3 are *producers* (packed
-// weights -> registers -> exact dequantisation -> LDS; x tile -> LDS), waves 4-7 are *consumers* (LDS -> MFMA only, 64 MFMAs per
-// K-step each).  A workgroup's waves are dealt over the SIMDs cyclically, so every SIMD hosts one producer and one consumer:
-// the unpack arithmetic (VALU) and the contraction (matrix pipe) run concurrently instead of alternating inside one wave —
-// the single-role kernel above measures MFMA busy 36 % / VALU busy 40 % with almost no overlap (profiles/r01_prefill_*).
-// Two LDS stages (2 x 48 KiB), one workgroup barrier per K-step: producers fill stage (kt+1)&1 while consumers read kt&1.
+// Large-M kernel: 256 tokens x (16*PER*8 = 256 features at 4 bits) per workgroup, 8 waves.  Weights never touch LDS: wave w owns
+// 16 packed rows (-> 16*PER output features), loads their 16 packed bytes per lane and K-step straight in MFMA operand layout
+// (lane (r = lane & 15, c = lane >> 4): row r, k = 16c .. 16c+15, as in gemv_mfma.hip), dequantises them exactly in registers
+// and uses them as the A operand against all 256 tokens.  Only the activation tile goes through LDS (two 32 KiB stages, one
+// workgroup barrier per K-step), staged cooperatively by all waves.
+// Why (in-kernel cycle accounting, tools/gemm_lab.hip, on two producer/consumer variants of the LDS-staged design): writing the
+// dequantised fp16 weight tile to LDS costs 4x its packed size in LDS-write bandwidth (64-85 B/clk/CU) and pins the producers at
+// 2700-4400 cycles per K-step against 1000-2000 cycles of MFMA work; the CU's address/L1 path (64 B/clk) is the second limit,
+// which the 256x256 tile relieves (40 KiB per step for 8.4 MFLOP).  Here every wave does both jobs — 64 exact-dequant VALU ops
+// and 64 MFMAs per K-step — so the two pipes overlap inside each wave without a producer/consumer hand-off.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int WS_BM = 256, WS_THREADS = 512;
+constexpr int RT_WAVES = 8, RT_THREADS = 64 * RT_WAVES;   // token-tile height BM: 256 at 4 bits, 128 at 2 bits (accumulator registers)
+#ifdef GEMM_LAB_TS
+__device__ unsigned long long* g_ws_ts_dev = nullptr;   // lab only
+#endif
 
-template <int NBITS>
-__global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_f16_kernel(
+template <int NBITS, int S, int PER>
+struct RtSlab {   // A fragments (two k-octets) of slab S from the lane's 16 packed bytes: exact, two fp16 roundings
+  static __device__ __forceinline__ void run(const u32x4& w, const half_t (&z)[PER], const half_t (&s)[PER], h8_t (&a0)[PER], h8_t (&a1)[PER]) {
+    const half2_t zz = {z[S], z[S]}, ss = {s[S], s[S]};
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      o[2 * d] = g_as_u32((g_levels<NBITS, S>(w[d]) - zz) * ss);            // bytes (4d+0, 4d+2)
+      o[2 * d + 1] = g_as_u32((g_levels<NBITS, S>(w[d] >> 8) - zz) * ss);   // bytes (4d+1, 4d+3)
+    }
+    a0[S] = __builtin_bit_cast(h8_t, u32x4{o[0], o[1], o[2], o[3]});   // k = 16c + 0..7 (permuted inside the octet, like x in LDS)
+    a1[S] = __builtin_bit_cast(h8_t, u32x4{o[4], o[5], o[6], o[7]});   // k = 16c + 8..15
+    if constexpr (S + 1 < PER) RtSlab<NBITS, S + 1, PER>::run(w, z, s, a0, a1);
+  }
+};
+
+template <int NBITS, int RT_BM>
+__global__ __launch_bounds__(RT_THREADS, 2) void gemm_rt_f16_kernel(
     const half_t* __restrict__ x, const uint8_t* __restrict__ Wq, const half_t* __restrict__ scale,
     const half_t* __restrict__ zero, const half_t* __restrict__ bias, half_t* __restrict__ y,
     int M, int N, int K, int gs, int n_tiles) {
   constexpr int PER = 8 / NBITS;
-  constexpr int PROWS = GB_N / PER;                       // packed rows per tile
-  constexpr int WTHREADS = (PROWS * GB_K) / 16;           // producer threads that carry a packed 16-byte chunk (<= 256)
-  constexpr int STAGE = (GB_N + WS_BM) * GB_K * 2;        // W tile + x tile
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // two stages
+  constexpr int PROWS = 16 * RT_WAVES;                    // packed rows per workgroup tile (128) -> 128*PER features
+  constexpr int XSTAGE = RT_BM * GB_K * 2;                // 32 KiB
+  constexpr int MT = RT_BM / 16;                          // token tiles
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // two x stages
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave < 4;
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).  All n tiles
-  // of one token tile are given to the same XCD, so the 256 x K activation tile is fetched into one L2 and shared by the
-  // 32 CUs working on it, instead of being pulled into all eight L2s.
+  const int r = lane & 15, c = lane >> 4;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only): all n tiles of a token tile on one XCD -> its x tile in one L2
   int nt, mt;
   {
     const int m_tiles = gridDim.x / n_tiles;
@@ -259,175 +280,144 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_ws_f16_kernel(
     }
   }
   const int rows_per_slab = N / PER;
-  const int p0 = nt * PROWS;
-  const int m0 = mt * WS_BM;
+  const int m0 = mt * RT_BM;
   const int G = K / gs;
   const int nk = K / GB_K;
+  int prow = nt * PROWS + wave * 16 + r;                  // this lane's packed row
+  const bool row_ok = prow < rows_per_slab;
+  prow = row_ok ? prow : rows_per_slab - 1;               // ragged last tile: duplicate the last row (masked at the store)
 
-  // ---- producer state ----
-  const int ptid = tid & 255;
-  const int wp = ptid / 4, wk = ptid & 3;
-  const bool w_active = ptid < WTHREADS && (p0 + wp) < rows_per_slab;
-  const int xr_ = ptid >> 1, xh = ptid & 1;
-  // three K-steps of global data in flight per producer thread (a K-step of MFMA work is ~1000 cycles, an HBM round trip 2-4x that)
-  struct PStage { u32x4 wreg; half_t zreg[PER], sreg[PER]; u32x4 xreg[2][4]; };
-  PStage ring[3];
+  // x staging assignment: XCH consecutive 16-byte chunks of one row per thread (a row of the tile is 8 chunks)
+  constexpr int XCH = RT_BM * 8 / RT_THREADS;             // 4 (BM = 256) or 2 (BM = 128)
+  const int xr_ = tid / (8 / XCH), xc0 = (tid % (8 / XCH)) * XCH;
+  const half_t* xsrc = x + static_cast<int64_t>(m0 + xr_ < M ? m0 + xr_ : 0) * K + xc0 * 8;
+  const bool x_ok = m0 + xr_ < M;
 
-  auto load_regs = [&](PStage& st, int kt) {
+  struct WStage { u32x4 w; half_t z[PER], s[PER]; };
+  auto load_w = [&](WStage& st, int kt) {
     const int k0 = kt * GB_K;
-    st.wreg = u32x4{0u, 0u, 0u, 0u};
-    if (w_active) {
-      st.wreg = *reinterpret_cast<const u32x4*>(Wq + static_cast<int64_t>(p0 + wp) * K + k0 + wk * 16);
-      const int g = (k0 + wk * 16) / gs;
+    st.w = *reinterpret_cast<const u32x4*>(Wq + static_cast<int64_t>(prow) * K + k0 + c * 16);
+    const int g = (k0 + c * 16) / gs;
 #pragma unroll
-      for (int s = 0; s < PER; ++s) {
-        const int64_t r = static_cast<int64_t>(p0 + wp + s * rows_per_slab) * G + g;
-        st.zreg[s] = zero[r];
-        st.sreg[s] = scale[r];
-      }
-    }
-#pragma unroll
-    for (int xr = 0; xr < 2; ++xr) {
-      const int row = m0 + xr * 128 + xr_;
-      if (row < M) {
-        const half_t* src = x + static_cast<int64_t>(row) * K + k0 + xh * 32;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) st.xreg[xr][c] = *reinterpret_cast<const u32x4*>(src + c * 8);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) st.xreg[xr][c] = u32x4{0u, 0u, 0u, 0u};
-      }
+    for (int s = 0; s < PER; ++s) {
+      const int64_t q = static_cast<int64_t>(prow + s * rows_per_slab) * G + g;
+      st.z[s] = zero[q];
+      st.s[s] = scale[q];
     }
   };
-  auto write_lds = [&](const PStage& st, uint8_t* ldsW) {
-    uint8_t* ldsX = ldsW + GB_N * GB_K * 2;
-    if (ptid < WTHREADS) {
-      if (w_active) {
-        DeqSlab<NBITS, 0, PER>::run(st.wreg, st.zreg, st.sreg, ldsW, wp, wk);
-      } else {
+  u32x4 xreg[XCH];
+  auto load_x = [&](int kt) {
 #pragma unroll
-        for (int s = 0; s < PER; ++s) {
-          *reinterpret_cast<u32x4*>(ldsW + lds_off(s * PROWS + wp, wk * 2)) = u32x4{0u, 0u, 0u, 0u};
-          *reinterpret_cast<u32x4*>(ldsW + lds_off(s * PROWS + wp, wk * 2 + 1)) = u32x4{0u, 0u, 0u, 0u};
-        }
-      }
-    }
+    for (int i = 0; i < XCH; ++i) xreg[i] = x_ok ? *reinterpret_cast<const u32x4*>(xsrc + kt * GB_K + i * 8) : u32x4{0u, 0u, 0u, 0u};
+  };
+  auto write_x = [&](uint8_t* ldsX) {
 #pragma unroll
-    for (int xr = 0; xr < 2; ++xr)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        *reinterpret_cast<u32x4*>(ldsX + lds_off(xr * 128 + xr_, xh * 4 + c)) = g_permute_x8(st.xreg[xr][c]);
+    for (int i = 0; i < XCH; ++i) *reinterpret_cast<u32x4*>(ldsX + lds_off(xr_, xc0 + i)) = g_permute_x8(xreg[i]);
   };
 
-  // The two roles run separate loops (separate register allocation: the consumer's 128 accumulator registers are not live in
-  // the producer's code) and meet at the same number of workgroup barriers: 1 + nk.
-  if (producer) {
-    load_regs(ring[0], 0);
-    if (nk > 1) load_regs(ring[1], 1);
-    if (nk > 2) load_regs(ring[2], 2);
-    write_lds(ring[0], lds);
-    if (nk > 3) load_regs(ring[0], 3);
-    __syncthreads();
-    // iteration kt: fill stage (kt+1)&1 from ring slot (kt+1)%3, then refill that slot with step kt+4
-    auto step = [&](PStage& st, int kt) {
-      if (kt + 1 < nk) write_lds(st, lds + ((kt + 1) & 1) * STAGE);
-      if (kt + 4 < nk) load_regs(st, kt + 4);
-      __syncthreads();                                             // stage (kt+1)&1 filled, stage kt&1 drained
-    };
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 3) {
-      step(ring[1], kt);
-      step(ring[2], kt + 1);
-      step(ring[0], kt + 2);
-    }
-    if (kt < nk) { step(ring[1], kt); ++kt; }
-    if (kt < nk) { step(ring[2], kt); ++kt; }
-    return;
-  }
+  f32x4 acc[PER][MT];
+#pragma unroll
+  for (int s = 0; s < PER; ++s)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- consumer: wave (wn, wm) owns features wn*64..+63 x tokens wm*128..+127 ----
-  const int cw = wave & 3;
-  const int wn = cw & 1, wm = cw >> 1;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  WStage wa, wb;
+  load_w(wa, 0);
+  load_x(0);
+  if (nk > 1) load_w(wb, 1);
+  write_x(lds);
+  if (nk > 1) load_x(1);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const uint8_t* ldsW = lds + (kt & 1) * STAGE;
-    const uint8_t* ldsX = ldsW + GB_N * GB_K * 2;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8_t a[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        a[i] = *reinterpret_cast<const h8_t*>(ldsW + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int jh = 0; jh < 8; jh += 4) {
-        h8_t b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          b[j] = *reinterpret_cast<const h8_t*>(ldsX + lds_off(wm * 128 + (jh + j) * 16 + fr, ks * 4 + fq));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][jh + j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
 
-  // ---- epilogue (consumers): lane holds features (fq*4 .. +3) of feature block i, token fr of token block j ----
+#ifdef GEMM_LAB_TS
+  unsigned long long t_w = 0, t_d = 0, t_m = 0, t_b = 0;
+#define RT_STAMP(v) { const unsigned long long n_ = __builtin_readcyclecounter(); v += n_ - t_last; t_last = n_; }
+#else
+#define RT_STAMP(v)
+#endif
+  auto step = [&](WStage& cur, int kt) {
+#ifdef GEMM_LAB_TS
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    const uint8_t* ldsX = lds + (kt & 1) * XSTAGE;
+    if (kt + 1 < nk) write_x(lds + ((kt + 1) & 1) * XSTAGE);       // registers hold x of step kt+1
+    RT_STAMP(t_w)
+    h8_t a0[PER], a1[PER];
+    RtSlab<NBITS, 0, PER>::run(cur.w, cur.z, cur.s, a0, a1);
+    if (kt + 2 < nk) { load_w(cur, kt + 2); load_x(kt + 2); }       // two steps ahead, in flight across the barrier
+    RT_STAMP(t_d)
+    // four token tiles at a time: 4*PER independent MFMAs between two MFMAs on the same accumulator (a dependent pair issued
+    // back to back stalls for the full MFMA latency)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int trow = wn * 64 + i * 16 + fq * 4;
-    const int slab = trow / PROWS, pin = trow % PROWS;
-    const int prow = p0 + pin;
-    if (prow >= rows_per_slab) continue;
-    const int n = slab * rows_per_slab + prow;
+    for (int jh = 0; jh < MT; jh += 4) {
+      h8_t b0[4], b1[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + wm * 128 + j * 16 + fr;
+      for (int j = 0; j < 4; ++j) {
+        b0[j] = *reinterpret_cast<const h8_t*>(ldsX + lds_off((jh + j) * 16 + r, c * 2));
+        b1[j] = *reinterpret_cast<const h8_t*>(ldsX + lds_off((jh + j) * 16 + r, c * 2 + 1));
+      }
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s], b0[j], acc[s][jh + j], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s], b1[j], acc[s][jh + j], 0, 0, 0);
+    }
+    RT_STAMP(t_m)
+    __syncthreads();   // x stage (kt+1)&1 filled, stage kt&1 drained
+    RT_STAMP(t_b)
+  };
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(wa, kt);
+    step(wb, kt + 1);
+  }
+  if (kt < nk) step(wa, kt);
+#ifdef GEMM_LAB_TS
+  if (lane == 0 && g_ws_ts_dev && blockIdx.x < 64) { unsigned long long* o = g_ws_ts_dev + (blockIdx.x * 8 + wave) * 5; o[0] = t_w; o[1] = t_d; o[2] = t_m; o[3] = t_b; o[4] = nk; }
+#endif
+
+  // ---- epilogue: D layout — lane holds packed rows 4c + i (i = 0..3) of the wave's 16, token r of token tile j ----
+  const int p_base = nt * PROWS + wave * 16 + c * 4;
+#pragma unroll
+  for (int s = 0; s < PER; ++s) {
+    if (p_base >= rows_per_slab) continue;
+    const int n = s * rows_per_slab + p_base;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + j * 16 + r;
       if (m >= M) continue;
       half_t o[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o[r] = static_cast<half_t>(acc[i][j][r]);
-        if (bias && prow + r < rows_per_slab) o[r] = o[r] + bias[n + r];
+      for (int i = 0; i < 4; ++i) {
+        o[i] = static_cast<half_t>(acc[s][j][i]);
+        if (bias && p_base + i < rows_per_slab) o[i] = o[i] + bias[n + i];
       }
       half_t* dst = y + static_cast<int64_t>(m) * N + n;
-      if (prow + 3 < rows_per_slab) {
+      if (p_base + 3 < rows_per_slab) {
         *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (prow + r < rows_per_slab) dst[r] = o[r];
+        for (int i = 0; i < 4; ++i)
+          if (p_base + i < rows_per_slab) dst[i] = o[i];
       }
     }
   }
 }
 
-template <int NBITS>
-static int launch_gemm_ws_f16(const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
+template <int NBITS, int RT_BM>
+static int launch_gemm_rt_f16(const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                               int M, int N, int K, int gs, hipStream_t st) {
   constexpr int PER = 8 / NBITS;
   const int rows_per_slab = N / PER;
-  const int n_tiles = (rows_per_slab + GB_N / PER - 1) / (GB_N / PER);
-  const int m_tiles = (M + WS_BM - 1) / WS_BM;
+  const int n_tiles = (rows_per_slab + 16 * RT_WAVES - 1) / (16 * RT_WAVES);
+  const int m_tiles = (M + RT_BM - 1) / RT_BM;
   const int64_t blocks = static_cast<int64_t>(n_tiles) * m_tiles;
   if (blocks > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
-  constexpr int lds_bytes = 2 * (GB_N + WS_BM) * GB_K * 2;
-  auto kern = gemm_ws_f16_kernel<NBITS>;
-  static bool raised = false;   // per instantiation
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) { set_error("hqq_hip_gemm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-    raised = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(WS_THREADS), lds_bytes, st,
+  constexpr int lds_bytes = 2 * RT_BM * GB_K * 2;
+  hipLaunchKernelGGL((gemm_rt_f16_kernel<NBITS, RT_BM>), dim3(static_cast<unsigned>(blocks)), dim3(RT_THREADS), lds_bytes, st,
                      static_cast<const half_t*>(x), static_cast<const uint8_t*>(Wq), static_cast<const half_t*>(scale),
                      static_cast<const half_t*>(zero), static_cast<const half_t*>(bias), static_cast<half_t*>(y),
                      M, N, K, gs, n_tiles);
@@ -471,10 +461,10 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
   if (dtype != HQQ_F16) { set_error("hqq_hip_gemm: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
   hipStream_t st = as_stream(stream);
   const int m = static_cast<int>(M), n = static_cast<int>(N), k = static_cast<int>(K), gs = static_cast<int>(group_size);
-  // opt-in (HQQ_HIP_GEMM_WS=1): the wave-specialised 256x128 kernel.  Round 1 status: correct, 0.58-0.74 PFLOP/s — not yet
-  // ahead of the single-role kernels below (0.65-0.83); PMC: MFMA busy 29 %, waves waiting 50 % of their cycles.
-  if (getenv("HQQ_HIP_GEMM_WS") && static_cast<int64_t>((M + 255) / 256) * ((N + GB_N - 1) / GB_N) >= 512)
-    return nbits == 4 ? launch_gemm_ws_f16<4>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_ws_f16<2>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
+  // opt-in (HQQ_HIP_GEMM_RT=1): register-tile kernel (weights never touch LDS).  Round-1 status: correct, 0.62-0.81 PFLOP/s — level
+  // with the LDS-staged kernels below (0.65-0.83), not ahead; PMC: waves stall on issue 33 % and wait 45 % of their cycles.
+  if (getenv("HQQ_HIP_GEMM_RT") && static_cast<int64_t>((M + 255) / 256) * ((N / per + 127) / 128) >= 256)
+    return nbits == 4 ? launch_gemm_rt_f16<4, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_rt_f16<2, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
   // 256-token tiles halve the dequantisation work per flop; keep 128 when M is too small to fill the chip with them
   const bool big = static_cast<int64_t>((M + 255) / 256) * ((N + GB_N - 1) / GB_N) >= 1536;   // >= 3 full waves of 256-token tiles
   if (nbits == 4) return big ? launch_gemm_f16<4, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_f16<4, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);

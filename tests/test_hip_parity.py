@@ -333,18 +333,24 @@ def test_gemm_vs_oracle(ops, oracle, nbits, M, N, K):
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
-def test_gemm_wave_specialised_variant(ops, nbits, monkeypatch):
-    """opt-in producer/consumer kernel (HQQ_HIP_GEMM_WS=1): same tiles, same exact weights -> same result as the default kernel
-    up to fp32 summation order (here: identical k order per output, so bit-identical)"""
-    M, N, K = 16384, 4096, 512
-    U, s, z = _random_layer(N, K, 64, nbits, seed=3)
-    P = ops.pack(nbits, U.cuda())
-    x = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).half().cuda()
-    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).half().cuda()
-    base = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
-    monkeypatch.setenv("HQQ_HIP_GEMM_WS", "1")
-    ws = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
-    assert torch.equal(ws, base)
+def test_gemm_register_tile_variant(ops, nbits, monkeypatch):
+    """opt-in register-tile kernel (HQQ_HIP_GEMM_RT=1: weights dequantised straight into MFMA operands, only x through LDS) vs the
+    default LDS-staged kernel: same exact weights, different fp32 summation order; ragged N and M exercise the masked edges"""
+    for (M, N, K) in ((16384, 4096, 512), (8200, 4112, 256)):
+        U, s, z = _random_layer(N, K, 64, nbits, seed=3)
+        P = ops.pack(nbits, U.cuda())
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).half().cuda()
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).half().cuda()
+        base = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
+        monkeypatch.setenv("HQQ_HIP_GEMM_RT", "1")
+        rt = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
+        monkeypatch.delenv("HQQ_HIP_GEMM_RT")
+        torch.testing.assert_close(rt.float(), base.float(), rtol=1e-3, atol=2e-3)
+        e = torch.zeros_like(x); e[torch.arange(M, device="cuda"), torch.arange(M, device="cuda") * 5 % K] = 1.0   # one-hot rows: exact columns
+        monkeypatch.setenv("HQQ_HIP_GEMM_RT", "1")
+        rt1 = ops.gemm(e, P, s.cuda(), z.cuda(), None, N, K, 64, nbits)
+        monkeypatch.delenv("HQQ_HIP_GEMM_RT")
+        assert torch.equal(rt1, ops.gemm(e, P, s.cuda(), z.cuda(), None, N, K, 64, nbits))
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
