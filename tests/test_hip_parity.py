@@ -233,6 +233,41 @@ def test_gemv_vs_oracle(ops, oracle, nbits, M, NK):
         assert max_ulp_f16(colf, Wdev[:, k]) <= 1
 
 
+@pytest.mark.parametrize("nbits", [8, 1])
+@pytest.mark.parametrize("M", [1, 3, 7, 16])
+def test_gemv_8bit_1bit_vs_oracle(ops, oracle, nbits, M):
+    """the other byte containers of the reference (8-bit: also 5/6-bit levels; 1-bit: eight slabs per byte) on the same kernels"""
+    N, K, gs = 256, 1024, 64
+    U, s, z = _random_layer(N, K, gs, nbits, seed=nbits)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
+    yo, _ = oracle.matmul(x.numpy(), Wd, None, 1)
+    y = ops.gemv(x.cuda(), dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)
+    torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3 * (16 if nbits == 8 else 1))
+    e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, 5] = 1.0
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    assert torch.equal(ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0], Wdev[:, 5])
+
+
+def test_forward_empty_and_shape_errors(ops):
+    N, K, gs = 64, 128, 64
+    U, s, z = _random_layer(N, K, gs, 4, seed=1)
+    P = ops.pack(4, U.cuda())
+    s, z = s.cuda(), z.cuda()
+    y = ops.forward(torch.zeros(0, K, dtype=torch.float16, device="cuda"), P, s, z, None, N, K, gs, 4)
+    assert tuple(y.shape) == (0, N)
+    assert ops.gemv_grouped(torch.zeros(0, K, dtype=torch.float16, device="cuda"), [(P, s, z, None, N)], K, gs, 4)[0].shape == (0, N)
+    y3 = ops.forward(torch.randn(2, 3, K, device="cuda").half(), P, s, z, None, N, K, gs, 4)      # leading dims are flattened and restored
+    assert tuple(y3.shape) == (2, 3, N)
+    with pytest.raises(ValueError):
+        ops.forward(torch.zeros(1, K + 16, dtype=torch.float16, device="cuda"), P, s, z, None, N, K, gs, 4)
+    with pytest.raises(TypeError):
+        ops.forward(torch.zeros(1, K, dtype=torch.float32, device="cuda"), P, s, z, None, N, K, gs, 4)      # x must share the compute dtype
+    with pytest.raises(RuntimeError):
+        ops.forward(torch.zeros(1, K, dtype=torch.float16), P, s, z, None, N, K, gs, 4)                         # CPU tensor: no CPU path
+
+
 @pytest.mark.parametrize("M", [1, 2, 4])
 @pytest.mark.parametrize("NK", [(512, 1024), (101, 512), (1001, 4096), (64, 11008), (4096, 4096)])
 def test_gemv_3bit_vs_oracle(ops, oracle, M, NK):

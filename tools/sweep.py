@@ -3,7 +3,6 @@
     python tools/sweep.py > profiles/r01_sweep.md
 All timings: device time from one hipGraph replay over a rotating pool of distinct layers > 256 MiB (no host launch cost, no
 Infinity-Cache hits).  70B shards: the per-rank packed-row block of hqq_amd.shard (what rank r of P would run), on this one GPU."""
-import os
 import sys
 import time
 
@@ -106,23 +105,7 @@ def main():
             t = a.elapsed_time(b) / 5 * 1e-3
             res += [f"{t * 1e3:.3f}", f"{2.0 * M * N * K / t / 1e12:.0f}"]
         row(f"{N}x{K}", *res)
-    print("\n## CPU baseline on this box (oracle/hqq_oracle.c, OpenMP on %d cores)\n" % len(os.sched_getaffinity(0)))
-    import numpy as np
-    from oracle import hqq_oracle as orc
-    Wn = (np.random.default_rng(0).standard_normal((4096, 4096)) * 0.02).astype(np.float32)
-    t0 = time.perf_counter(); o = orc.quantize(Wn, nbits=4, group_size=64); tq = time.perf_counter() - t0
-    P = orc.pack(4, o["Wq"]); s16, z16 = orc.to_cd(o["scale"], orc.F16), orc.to_cd(o["zero"], orc.F16)
-    xn = orc.to_cd(np.random.default_rng(1).standard_normal((1, 4096)).astype(np.float32), orc.F16)
-    orc.forward(4, P, s16, z16, None, xn, 4096, 4096, 64, orc.F16)
-    t0 = time.perf_counter()
-    for _ in range(20):
-        orc.forward(4, P, s16, z16, None, xn, 4096, 4096, 64, orc.F16)
-    tf = (time.perf_counter() - t0) / 20
-    row("op", "time")
-    row("---", "---")
-    row("Quantizer.quantize 4096x4096 int4 (20 iterations)", f"{tq * 1e3:.0f} ms")
-    row("forward bs=1 4096x4096 int4 (unpack+dequantize+matmul)", f"{tf * 1e3:.1f} ms")
-
+    print("\n(CPU baseline: `bench.py` times the oracle on the host cores in its own run — `cpu_baseline` in its JSON line.)")
 
 if __name__ == "__main__":
     main()
