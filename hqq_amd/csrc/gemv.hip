@@ -68,7 +68,7 @@ struct GvArgs {
   int prow_end[GV_MAXL];   // end (exclusive) of layer i's packed rows in the group's concatenated row space;
                            // unused entries repeat the last layer
   const half_t* x;
-  int K, gs, total_prow;
+  int K, gs, G /* K / gs */, total_prow;
 #ifdef GV_LAB_TS
   unsigned long long* ts;   // lab only: per-wave timestamps
 #endif
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the row bookkeeping in SGPRs
-  const int K = a.K, gs = a.gs, G = K / gs;
+  const int K = a.K, gs = a.gs, G = a.G;
   const int nsteps = (K + GV_KSTEP - 1) / GV_KSTEP;   // wave load instructions per row
   const int nunits = (nsteps + GV_U - 1) / GV_U;
   const int planes_per_m = nsteps * 2 * 64;
@@ -349,20 +349,19 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   //      set-up), then the first unit of this wave's first row, then x is written to LDS ----
   float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64], FACTORED only
   const int chunks_per_m = nsteps * 64;          // 16-k lane chunks per row of x, padded to whole steps
-  auto load_chunk = [&](int c, u32x4& v0, u32x4& v1) {
-    const int m = c / chunks_per_m, j = c - m * chunks_per_m;   // j = step * 64 + lane
+  // (m, j) = (row of x, 16-k chunk j = step * 64 + lane); no division on the way to the first loads
+  auto load_chunk = [&](int m, int j, u32x4& v0, u32x4& v1) {
     const int k = j * 16;
     v0 = u32x4{0u, 0u, 0u, 0u};
     v1 = u32x4{0u, 0u, 0u, 0u};
-    if (c < M * chunks_per_m && k < K) {   // K % 16 == 0
+    if (j < chunks_per_m && k < K) {   // K % 16 == 0
       const u32x4* src = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + k);
       v0 = src[0];
       v1 = src[1];
     }
   };
-  auto store_chunk = [&](int c, const u32x4& v0, const u32x4& v1) {
-    if (c >= M * chunks_per_m) return;
-    const int m = c / chunks_per_m, j = c - m * chunks_per_m;
+  auto store_chunk = [&](int m, int j, const u32x4& v0, const u32x4& v1) {
+    if (j >= chunks_per_m) return;
     const int it = j >> 6, ln = j & 63;
     xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
     xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
     }
   };
   u32x4 xv0, xv1;
-  load_chunk(tid, xv0, xv1);
+  load_chunk(0, tid, xv0, xv1);
 
   int prow = blockIdx.x * GV_WAVES + wave;
   int unit = 0;
@@ -387,11 +386,13 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   issue(ua, lc, prow < total ? prow : total - 1, 0, prow < total);
   GV_TS(1)
 
-  store_chunk(tid, xv0, xv1);
-  for (int c = tid + GV_WAVES * 64; c < M * chunks_per_m; c += GV_WAVES * 64) {
-    load_chunk(c, xv0, xv1);
-    store_chunk(c, xv0, xv1);
-  }
+  store_chunk(0, tid, xv0, xv1);
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+    for (int j = tid + (m == 0 ? GV_WAVES * 64 : 0); j < chunks_per_m; j += GV_WAVES * 64) {
+      load_chunk(m, j, xv0, xv1);
+      store_chunk(m, j, xv0, xv1);
+    }
   GV_TS(2)
   __syncthreads();
   GV_TS(3)
@@ -707,6 +708,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   }
   a.K = static_cast<int>(K);
   a.gs = static_cast<int>(group_size);
+  a.G = static_cast<int>(K / group_size);
   a.total_prow = static_cast<int>(total);
 #ifdef GV_LAB_TS
   a.ts = g_lab_ts;
