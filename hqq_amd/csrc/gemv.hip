@@ -69,6 +69,8 @@ struct GvArgs {
                            // unused entries repeat the last layer
   const half_t* x;
   int K, gs, G /* K / gs */, total_prow;
+  int red_off;  // byte offset of the K-split reduction buffer in LDS
+  int ksplit;   // 1: the workgroup's waves share ONE packed row (units interleaved), partial sums meet in LDS — for few-row / long-K layers
 #ifdef GV_LAB_TS
   unsigned long long* ts;   // lab only: per-wave timestamps
 #endif
@@ -301,7 +303,9 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   const int nsteps = (K + GV_KSTEP - 1) / GV_KSTEP;   // wave load instructions per row
   const int nunits = (nsteps + GV_U - 1) / GV_U;
   const int planes_per_m = nsteps * 2 * 64;
-  const int stride = gridDim.x * GV_WAVES;
+  const bool ksplit = a.ksplit != 0;                   // workgroup-uniform
+  const int stride = ksplit ? gridDim.x : gridDim.x * GV_WAVES;
+  const int ustep = ksplit ? GV_WAVES : 1, ubase = ksplit ? wave : 0;
   const int total = a.total_prow;
 
   // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
@@ -378,12 +382,12 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   u32x4 xv0, xv1;
   load_chunk(0, tid, xv0, xv1);
 
-  int prow = blockIdx.x * GV_WAVES + wave;
-  int unit = 0;
+  int prow = ksplit ? blockIdx.x : blockIdx.x * GV_WAVES + wave;
+  int unit = ubase;
   // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
   LayerCtx lc = select_layer(a, prow < total ? prow : total - 1);
   Unit<PER, GS64> ua, ub;
-  issue(ua, lc, prow < total ? prow : total - 1, 0, prow < total);
+  issue(ua, lc, prow < total ? prow : total - 1, unit, prow < total);
   GV_TS(1)
 
   store_chunk(0, tid, xv0, xv1);
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
     }
     }
     // ---- row finished: one wave reduction per output row; lane (m * PER + s) writes its value ----
-    if (unit == nunits - 1) {
+    if (unit + ustep >= nunits) {
       const int p = prow - oc.row0;
       const int rows_per_slab = oc.N / PER;
       float mine = 0.f;
@@ -494,6 +498,18 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
           const float v = wave_sum(part);
           mine = (lane == m * PER + s) ? v : mine;
         }
+      if (ksplit) {   // the row's K range was shared by the workgroup's waves: add their partial sums (fixed order) in wave 0
+        float* red = reinterpret_cast<float*>(smem + a.red_off);
+        if (lane < M * PER) red[wave * (M * PER) + lane] = mine;
+        __syncthreads();
+        if (wave == 0 && lane < M * PER) {
+          mine = red[lane];
+#pragma unroll
+          for (int w = 1; w < GV_WAVES; ++w) mine += red[w * (M * PER) + lane];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+      }
       if (lane < M * PER) {
         const int m = lane / PER, s = lane - m * PER;
         const int n = p + s * rows_per_slab;
@@ -513,8 +529,9 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
 
   // next unit of this wave: same row, or the wave's next row (re-selecting the layer when the row leaves it)
   auto advance = [&](int& p, int& u, LayerCtx& c) {
-    if (++u == nunits) {
-      u = 0;
+    u += ustep;
+    if (u >= nunits) {
+      u = ubase;
       p += stride;
       if (p >= c.end && p < total) c = select_layer(a, p);
     }
@@ -560,13 +577,22 @@ static int num_cus() {
 }
 
 template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false>
-static int launch_gemv_f16(const GvArgs& a, hipStream_t st) {
+static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
+  constexpr int PER = 8 / NBITS;
+  GvArgs a = args;
   const int nsteps = (a.K + GV_KSTEP - 1) / GV_KSTEP;
-  const size_t lds = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
-  const int tiles = (a.total_prow + GV_WAVES - 1) / GV_WAVES;
+  const int nunits = (nsteps + GV_U - 1) / GV_U;
+  const size_t xs_bytes = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
+  a.red_off = static_cast<int>((xs_bytes + 15) & ~static_cast<size_t>(15));
+  const size_t lds = a.red_off + sizeof(float) * GV_WAVES * M * PER;                  // + K-split reduction buffer
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
   per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   const int cap = num_cus() * per_cu;
+  // few rows x long K (e.g. the 1024 x 28672 shard of a 70B down-projection): one row per wave would leave most of the chip idle
+  // and each wave with 2-4 KiB in flight; let the workgroup's waves share a row instead
+  // (the choice depends on the layer shape only, never on M: a row's result does not change with the batch it is computed in)
+  a.ksplit = (nunits >= GV_WAVES && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * GV_WG_PER_CU * GV_WAVES) ? 1 : 0;
+  const int tiles = a.ksplit ? a.total_prow : (a.total_prow + GV_WAVES - 1) / GV_WAVES;
   const int grid = tiles < cap ? tiles : cap;
   auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16>;
   if (lds > 64 * 1024) {

@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
     return 0;
   }
 #endif
+  if (argc > 1 && argv[1][0] == 's') { run_case(4, 1, 1024, 28672, 1, reps); run_case(4, 1, 1024, 8192, 1, reps); run_case(4, 1, 8192, 28672, 1, reps); run_case(4, 1, 2048, 28672, 1, reps); run_case(4, 1, 128, 8192, 1, reps); run_case(4, 1, 4096, 11008, 1, reps); return 0; }
   if (argc > 1 && argv[1][0] == 'm') { for (int M : {1, 4, 8, 16}) { run_case(4, 1, 11008, 4096, M, reps); run_case(4, 1, 28672, 8192, M, reps); } return 0; }
   if (argc > 1) { run_case(4, 1, 4096, 4096, 1, reps); run_case(4, 1, 11008, 4096, 1, reps); run_case(4, 1, 28672, 8192, 1, reps); return 0; }
   run_case(4, 1, 4096, 4096, 1, reps);
