@@ -472,6 +472,17 @@ def test_quantize_vs_oracle_half_input(ops, oracle, nbits):
     assert True
 
 
+@pytest.mark.parametrize("nbits", [8, 6, 5, 1.58, 1])
+def test_quantize_other_supported_bits(ops, oracle, nbits):
+    """Quantizer.SUPPORTED_BITS beyond 4/3/2: 6- and 5-bit levels live in 8-bit containers, 1.58-bit (3 levels) in 2-bit ones
+    (Quantizer.bit_to_packing, hqq/core/quantize.py:40-49); max_v = round(2^nbits - 1) (:121)"""
+    W = (torch.randn(256, 512, generator=torch.Generator().manual_seed(int(nbits * 10))) * 0.02)
+    o = oracle.quantize(W.numpy(), nbits=nbits, group_size=64)
+    assert int(o["Wq"].max()) <= round(2 ** nbits - 1)
+    container = ops.PACK_BITS[nbits]
+    _check_quant(ops, W.numpy(), nbits, 64, oracle.pack(container, o["Wq"]), o["scale"], o["zero"], max_frac=1e-4)
+
+
 def test_quantize_full_size_properties(ops):
     """4096x4096 N(0,0.02^2): levels in range, dequant error sane, round trip through pack."""
     W = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(0)) * 0.02).half().cuda()
