@@ -1,38 +1,43 @@
-// gemv.hip — C entry points of the fused decode path (hqq_hip_gemv / hqq_hip_gemv_grouped) and the *factored* dot2 kernel
-// (mode HQQ_GEMV_FACTORED, and the fallback for K % 64 != 0).  The default kernel is the exact-weights MFMA one in
-// gemv_mfma.hip.
+// gemv.hip — the decode kernel: fused unpack -> dequantize -> GEMV for HQQLinear.forward with a few activation rows, gfx950,
+// and the C entry points of the decode path (hqq_hip_gemv / hqq_hip_gemv_grouped / hqq_hip_set_gemv_mode), which also route to
+// gemv3.hip (3-bit containers) and gemv_mfma.hip (5..16 rows).
 //
 // Replaces, for axis=1 layers, the reference's per-call chain
 //   BitPack.unpack_*  -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
 //   (hqq/core/bitpack.py:31-64, hqq/core/quantize.py:183-199, :880-898; patching.py:82-86 "TODO GEMV use-case")
-// which moves ~12.5 B/param through HBM, by one pass over the packed weights (0.5625 B/param at 4-bit).
+// which moves ~12.5 B/param through HBM, by one pass over the packed weights (0.5625 B/param at 4-bit).  HBM-bandwidth bound.
 //
-// HBM-bandwidth bound, no MFMA.  Data layout consumed as stored by the reference (no repacking):
+// Data layout consumed as stored by the reference (no repacking):
 //   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
 //   scale  [N*G] , zero [N*G] in the compute dtype, G = K/group_size; row n uses [n*G, (n+1)*G)
 //
-// Launch shape: a *group* of up to GV_MAXL layers that read the same activation rows (q/k/v, gate/up, or
-// a single layer) is one launch.  Their packed rows form one concatenated row space that a persistent
-// grid (<= 4 workgroups of 4 waves per CU) strides over; one wave owns one packed row (-> `per`
-// output rows) at a time and walks it in 2 KiB units (2 x global_load_dwordx4 per lane, non-temporal).
-// The loads of unit i+1 are issued before unit i is consumed, and the very first unit is requested
-// before x is staged, so every wave keeps 2-4 KiB of the weight stream in flight (16 waves per CU).
+// Launch shape: a *group* of up to GV_MAXL layers that read the same activation rows (q/k/v, gate/up, or a single layer) is
+// one launch.  Their packed rows form one concatenated row space that a persistent grid (<= 4 workgroups of 4 waves per CU)
+// strides over; one wave owns one packed row (-> `per` output rows) at a time and walks it in 2 KiB units
+// (2 x global_load_dwordx4 per lane, non-temporal, 1 KiB per wave instruction).  The loads of unit i+1 are issued before unit i
+// is consumed (two register sets, no copies), every issue() emits the same number of loads so that the compiler's waits are
+// exact `s_waitcnt vmcnt(n)`, the very first unit is requested before x is staged, and the last unit of a wave has its own code
+// path with nothing issued behind it.  Few-row / long-K layers switch to K-split: the workgroup's waves share one row.
 //   x       staged once per workgroup in LDS, in the order the nibble extraction produces values
-//   meta    per unit the (zero, scale) of the <= 64 groups it spans are fetched with one coalesced
-//           2-byte load per lane and slab and handed to the consuming lanes with ds_bpermute
-//           (group_size 64; other group sizes fetch per lane)
-// Each lane keeps per*M fp32 accumulators; one wave reduction per packed row.  No inter-wave traffic.
+//   meta    per unit the (zero, scale) of the <= 64 groups it spans are fetched with one coalesced 2-byte load per lane and slab
+//           and handed to the consuming lanes with ds_bpermute (group_size 64; other group sizes fetch per lane)
+//   layers  kernel arguments are structure-of-arrays; the current layer is picked with scalar selects and lives in SGPRs
 //
-// Numerics.  gfx950 issues packed-fp16 / dot2 / three-operand VALU at half the v_fma_f32 rate (measured with
-// tools/instr_bench.hip), so rebuilding every weight as round(round(q - z) * s) (5 such ops per weight pair) is
-// VALU-bound at ~6 TB/s before any other instruction.  The kernel therefore factors the group affine map out of the
-// dot product:   sum_k x_k (q_k - z) s  =  (s/F) * ( sum_k x_k (1024 + F q_k)  -  (1024 + F z) * sum_k x_k )
-// where 1024 + F q_k is the fp16 number obtained by OR-ing the exponent 0x6400 onto the masked nibble (F = 2^shift of
-// the slab) — one v_and_or_b32 + one v_dot2 per weight pair — and sum_k x_k per 16-k lane chunk is precomputed when x is
-// staged.  Everything after the nibble is fp32.  The result equals the exact-arithmetic product of x with the
-// *unrounded* affine weights (q - z) s; it differs from HQQBackend.PYTORCH (which rounds each weight to fp16 twice
-// before an fp32-accumulating GEMM) by less than that backend's own weight-rounding noise (tests: rtol = atol = 1e-3
-// against the oracle; one-hot probes within 1 fp16 ulp of hqq_hip_dequantize).
+// Arithmetic, two modes (template parameter EXACT; hqq_hip_set_gemv_mode):
+//  EXACT (default)  every weight pair is rebuilt exactly as Quantizer.dequantize does it — (w & mask) | 0x6400 -> v_pk_fma (exact
+//           level) -> v_pk_add(-zero) -> v_pk_mul(scale): two fp16 roundings, bit-identical to hqq_hip_dequantize / the reference
+//           — and contracted on the matrix core: all 64 lanes hold the SAME output row, lane (i = l & 15, o = l >> 4) supplies
+//           row i / k-octet o of the A operand (its 8 weights) and column i / k-octet o of B (its 8 x values); D[i][i] is the
+//           partial dot product of lanes {i + 16 o}, the row result the sum of the diagonal.  15/16 of the MFMA flops are thrown
+//           away on purpose: the matrix pipe is otherwise idle and the dot product costs no VALU slot.  bf16: same, with the two
+//           roundings done through fp32 (v_cvt_pk_bf16_f32 / v_dot2_f32_bf16), gfx950 having no packed bf16 arithmetic.
+//  FACTORED gfx950 issues packed-fp16 / dot2 / three-operand VALU at ~2/3 of the v_fma_f32 rate (tools/instr_bench.hip), so the
+//           4 ops per weight pair of EXACT cap the kernel near 4.5 TB/s.  FACTORED takes the group affine map out of the dot
+//           product:  sum_k x_k (q_k - z) s  =  (s/F) * ( sum_k x_k (1024 + F q_k)  -  (1024 + F z) * sum_k x_k ),  where
+//           1024 + F q_k is the fp16 number obtained by OR-ing the exponent 0x6400 onto the masked nibble (F = 2^shift of the
+//           slab) — one v_and_or_b32 + one v_dot2 per weight pair — and sum_k x_k per 16-k lane chunk is precomputed when x is
+//           staged.  Everything after the nibble is fp32; no per-weight fp16 rounding, so results differ from the reference by
+//           less than its own weight-rounding noise (<= 2^-10 * sum|x_k w_k|; tests state the tolerance).  ~20 % faster.
 #include <type_traits>
 
 #include "hqq_common.h"

@@ -130,7 +130,7 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
 
 
 def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
-    """fused unpack->dequant->GEMV, 1 <= M <= 8 (decode)."""
+    """fused unpack->dequant->GEMV for decode-sized batches: 1 <= M <= 16 (3-bit and bf16: <= 4; FACTORED mode: <= 8)."""
     return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
 
 

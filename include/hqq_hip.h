@@ -75,7 +75,7 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * HQQLinear.forward (quantize.py:880-898 forward_pytorch / matmul; patching.py:82-86) fused:
  *   y[M,N] = x[M,K] @ dequantize(Wq)^T (+ bias[N]),  axis=1 layout, dequantised weights bit-identical
  *   to hqq_hip_dequantize, fp32 accumulation, one rounding to `dtype` (+ one for the bias add).
- * hqq_hip_gemv : small M (decode), HBM-bandwidth bound, no MFMA.            1 <= M <= HQQ_GEMV_MAX_M
+ * hqq_hip_gemv : small M (decode), HBM-bandwidth bound (MFMA only as a free dot-product unit).  1 <= M <= HQQ_GEMV_MAX_M
  * hqq_hip_gemm : large M (prefill), MFMA f16/bf16.                          any M >= 1
  * hqq_hip_forward picks one of the two by M.
  * Covered by hqq_hip_gemv: nbits in {8,4,2,1} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0, fp16,
