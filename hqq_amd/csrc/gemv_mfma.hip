@@ -1,16 +1,17 @@
-// gemv_mfma.hip — fused unpack -> dequantize -> skinny GEMM on the matrix cores, 1 <= M <= 16 activation rows (decode /
-// small-batch HQQLinear.forward), gfx950.  The default kernel behind hqq_hip_gemv / hqq_hip_gemv_grouped.
+// gemv_mfma.hip — fused unpack -> dequantize -> skinny GEMM on the matrix cores for small batches (decode with several
+// sequences): hqq_hip_gemv / hqq_hip_gemv_grouped route 5 <= M <= 16 activation rows here (M <= 4 stays on the row-per-wave
+// kernel of gemv.hip, which streams each packed row contiguously).  gfx950.
 //
 // Reference chain replaced (axis=1): BitPack.unpack_* -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
 //   hqq/core/bitpack.py:31-64, hqq/core/quantize.py:183-199, :880-898; patching.py:82-86 ("TODO GEMV use-case").
 //
-// Why MFMA for a GEMV.  The kernel is HBM-bound by design (0.5625 B/param at 4-bit), but on gfx950 the VALU work of
-// rebuilding each weight exactly as the reference does — w = round16(round16(q - z) * s), 4 packed-fp16 ops per weight
-// pair — already costs ~130 ns per wave-KiB, i.e. a ~7 TB/s ceiling; spending a fifth op per pair and per activation row
-// on v_dot2 would push the kernel VALU-bound below the HBM rate.  v_mfma_f32_16x16x32_f16 does the contraction for up
-// to 16 rows of x at no VALU cost, so the same kernel serves M = 1 .. 16 at the same speed, and the weights it
-// multiplies are bit-identical to hqq_hip_dequantize / Quantizer.dequantize (only the fp32 summation order differs
-// from a BLAS GEMM).
+// Why a tile kernel here.  Rebuilding each weight exactly as the reference does — w = round16(round16(q - z) * s), 4
+// packed-fp16 ops per weight pair — costs ~130 ns per wave-KiB on gfx950 whatever M is; the row-per-wave kernel then spends
+// 2*per MFMAs per KiB *per activation row*, which passes the VALU time around M = 4.  With 16 packed rows per wave the weights
+// are the MFMA A operand and all M <= 16 activation rows ride in one B operand: the cost no longer depends on M.  The weights
+// it multiplies are bit-identical to hqq_hip_dequantize / Quantizer.dequantize (only the fp32 summation order differs from a
+// BLAS GEMM).  Round-1 status: 1.0-1.8 TB/s (a wave instruction touches 16 rows x 64 B, i.e. 16 DRAM pages at once, and x is
+// re-read from L2 per tile); next: stage the packed bytes through LDS so that global reads stay row-contiguous.
 //
 // Data layout, consumed as the reference stores it (no repacking):
 //   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
@@ -21,13 +22,13 @@
 // SIMDs).  A wave walks its slice in 64-k blocks: lane (r = lane & 15, c = lane >> 4) loads the 16 packed bytes of row r
 // at k = 64*kb + 16*c (global_load_dwordx4, non-temporal; a wave instruction covers 16 rows x 64 contiguous bytes),
 // dequantises them in registers, and feeds two MFMAs per slab (k-octets 16c + 0..7 and 16c + 8..15).  Loads are issued
-// four blocks (one *unit*, 4 KiB per wave) ahead of their use, ping-pong between two register sets.
+// two blocks (one *unit*, 2 KiB of weights per wave) ahead of their use, ping-pong between two register sets.
 //   x      [M, K] is read straight from global memory (it is a few hundred KiB at most and L2-resident): lane (r, c) loads
 //          the two k-octets it needs of activation row r together with the weights of the same unit and permutes them in
 //          registers into the k order the nibble extraction produces ((k0,k2),(k1,k3),(k4,k6),(k5,k7)); lanes of the unused
 //          columns M..15 hold zeros.  No LDS staging, hence no limit on M*K and no extra passes over the weights.
 //   meta   group_size 64: one 64-k block is exactly one group; per unit each lane fetches (zero, scale) of group
-//          (4*unit + c) of its row with coalesced 2-byte loads and the four blocks pick theirs with ds_bpermute.
+//          (2*unit + c) of its row with 2-byte loads and the unit's blocks pick theirs with ds_bpermute.
 //          other group sizes: fetched per lane and block.
 // The KS partial accumulators of a tile are summed through LDS; wave 0 rounds to fp16, adds the bias and stores.
 // Several layers that read the same x (q/k/v, gate/up) form one launch: their tiles are concatenated.
@@ -37,7 +38,6 @@ namespace hqq {
 
 constexpr int GM_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int GM_UB = 2;              // 64-k blocks per unit
-constexpr int GM_MAX_M = HQQ_GEMV_MAX_M;
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
