@@ -187,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
-    grouped = decode and not a.no_group and nbits in (4, 2, 8, 1)
+    grouped = decode and not a.no_group and nbits in (4, 3, 2, 8, 1)
 
     # --streams S > 1 (study mode, not the headline): the step's launches are dealt over S parallel graph branches, i.e. the
     # dependency chain q|k|v -> o -> gate|up -> down of a real decoder is NOT modelled and consecutive launches may overlap;

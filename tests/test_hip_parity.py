@@ -410,6 +410,22 @@ def test_forward_full_size_properties(ops, nbits):
         torch.testing.assert_close(ops.gemm(X64, P, s, z, None, N, K, 64, nbits).float(), X64.float() @ Wd.t(), rtol=1e-3, atol=2e-3)
 
 
+def test_forward_70b_shard_shapes_properties(ops):
+    """Llama-2-70B shapes (BASELINE.json configs[4]) incl. the few-row / long-K per-rank shards that take the K-split path:
+    one-hot exactness and agreement with the dequantise kernel, no oracle needed at this size"""
+    for (N, K) in [(8192, 8192), (1024, 8192), (1024, 28672), (128, 8192), (3584, 8192)]:
+        U, s, z = _random_layer(N, K, 64, 4, seed=N + K)
+        P = ops.pack(4, U.cuda())
+        s, z = s.cuda(), z.cuda()
+        Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, 4)
+        x = torch.randn(2, K, generator=torch.Generator().manual_seed(1)).half().cuda()
+        y = ops.forward(x, P, s, z, None, N, K, 64, 4)
+        torch.testing.assert_close(y.float(), x.float() @ Wd.float().t(), rtol=1e-3, atol=2e-3)
+        assert torch.equal(ops.forward(x[:1], P, s, z, None, N, K, 64, 4)[0], y[0])          # a row's result does not depend on the batch
+        e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, K - 3] = 1.0
+        assert torch.equal(ops.forward(e, P, s, z, None, N, K, 64, 4)[0], Wd[:, K - 3])
+
+
 def test_forward_unsupported_is_loud(ops):
     # 3-bit with a group size the fused kernel does not cover: reported, never silently computed elsewhere
     x = torch.zeros(1, 128, dtype=torch.float16, device="cuda")
