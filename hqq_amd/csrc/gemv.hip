@@ -667,6 +667,9 @@ static int max_m_per_launch(int64_t K) {
 namespace hqq {
 int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                   const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
+bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
+int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st);
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
 static int g_gemv_mode = HQQ_GEMV_EXACT;
@@ -682,7 +685,12 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
                                     int64_t M, int64_t K, int64_t group_size, int dtype, void* stream) {
   clear_stale_error();
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
-  if (M < 1 || M > HQQ_GEMV_MAX_M) { set_error("hqq_hip_gemv: M=%lld outside [1,%d]", (long long)M, HQQ_GEMV_MAX_M); return HQQ_ERR_SHAPE; }
+  // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
+  const bool skinny_ok = N && dtype == HQQ_F16 && skinny_covers(nbits, M, K, group_size, N, n_layers);
+  if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
+    set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 4-/2-bit, group_size 64, K %% 256 == 0)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
+    return HQQ_ERR_SHAPE;
+  }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
   if (nbits == 3) {   // int32 containers, ten slabs: its own kernel (gemv3.hip), fp16, exact weights
     if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers fp16 (got dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
@@ -701,7 +709,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
   const bool exact = g_gemv_mode == HQQ_GEMV_EXACT || dtype == HQQ_BF16;
-  if (exact && M > GV_EXACT_ROWWISE_MAX_M) {
+  if (exact ? M > GV_EXACT_ROWWISE_MAX_M : (M > 8 && skinny_ok)) {   // (FACTORED: the row-per-wave kernel serves M <= 8 per launch)
     // more activation rows than the row-per-wave kernel contracts cheaply: the 16-row-tile MFMA kernel (needs K % 64 == 0)
     if (K % 64) { set_error("hqq_hip_gemv: M=%lld > %d needs K %% 64 == 0 (got K=%lld)", (long long)M, GV_EXACT_ROWWISE_MAX_M, (long long)K); return HQQ_ERR_UNSUPPORTED; }
     for (int i = 0; i < n_layers; ++i) {
@@ -710,6 +718,8 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
+    if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }
   int m_max = max_m_per_launch(K);

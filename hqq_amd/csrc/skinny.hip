@@ -1,0 +1,513 @@
+// skinny.hip — fused unpack -> dequantize -> skinny GEMM on the matrix cores for decode with a batch (5 <= M <= 64 activation
+// rows, fp16, 4-/2-bit, group_size 64): the weights are streamed from HBM exactly once, whatever M is.  gfx950.
+//
+// Reference chain replaced (axis=1): BitPack.unpack_* -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
+//   hqq/core/bitpack.py:31-64, hqq/core/quantize.py:183-199, :880-898; patching.py:82-86.
+// The weights it multiplies are bit-identical to hqq_hip_dequantize / Quantizer.dequantize (two fp16 roundings); only the
+// fp32 summation order differs from a BLAS GEMM, and it is fixed (no atomics), so results are reproducible and a row of y does
+// not depend on the batch it was computed in.
+//
+// Why not the row-per-wave kernel of gemv.hip: there every activation row costs its own MFMAs per weight fragment and the
+// matrix pipe passes the dequantisation time around M = 4.  Why not dequantise + library GEMM: that writes and re-reads the
+// fp16 matrix (5x the packed bytes) — 28 us for a 4096 x 4096 layer at M = 32 where the packed weights stream in under 3 us.
+//
+// Data layout, consumed as the reference stores it (no repacking):
+//   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
+//   scale  [N*G], zero [N*G] fp16, G = K/64; output row n uses [n*G, (n+1)*G)
+//
+// Work decomposition.  A *panel* is 64 packed rows (-> 64*per output rows): one workgroup of four waves, 16 packed rows each,
+// so a wave's accumulators are its own and nothing is reduced across waves.  K is walked in chunks of 256: lane (r = lane & 15,
+// c = lane >> 4) loads the 16 packed bytes of row r at k = 256*chunk + 64*j + 16*c for the chunk's four 64-k blocks j
+// (global_load_dwordx4, non-temporal), two chunks ahead of their use, ping-pong between two register sets; each block is one
+// quantisation group, whose (zero, scale) the workgroup copied to LDS for its whole K range before the loop (requested before
+// anything else, four lanes per 128-byte line of the two tensors: loads return in order, and as one-lane-per-line gathers behind
+// the weights they were the last thing to arrive, 7 us into the launch).
+//   x      every wave of the workgroup needs the same activations, so the chunk [M, 256] is staged ONCE per workgroup in LDS
+//          (double-buffered; global -> registers one chunk ahead, written behind the MFMAs, one barrier per chunk), already
+//          in MFMA B-fragment order: fragment (m-tile, block j, half h) is 64 lanes x 16 bytes, lane (m & 15) + 16 c holding
+//          the k-octet 64 j + 16 c + 8 h of activation row m, permuted to the k order the nibble extraction produces.
+//          The previous tile kernel (gemv_mfma.hip) re-read x from L2 in every wave: twice the weight bytes through the CU's
+//          address path, which held it at 1.0-1.8 TB/s.
+//   split-K  small layers do not have 256 panels: the grid is (8, panels / 8, KS), workgroup (panel, ks) walks the ks-th share of
+//          the chunks (<= 8) and writes its fp32 partial tile to a scratch buffer [KS][16 MT][sum N]; a second, tiny kernel adds
+//          the KS partials in a fixed order, rounds to fp16, adds the bias and stores.  KS depends on the layer shape only.
+//          KS = 1 stores directly.  blockIdx.x is the XCD (workgroup b runs on XCD b % 8 — observed, a speed assumption only):
+//          the KS workgroups of a panel share the lines of zero / scale and the x chunks through one L2.
+// Round-1 status (MI355X, int4, graph replay over > 256 MiB of layers): 4096 x 4096: 11.6 us at M = 8, 15 at M = 32, 21 at M = 64
+// (dequantise + hipBLASLt: 28-30); 11008 x 4096: 20.6 / 29 / 45 (43-46).  The first 5 us of a launch go into the prologue: the
+// CU's L1 issues the misses of 16 rows x 64 B per wave instruction slowly, and x / group constants queue behind them.
+// Several layers that read the same x (q/k/v, gate/up) form one launch: their panels are concatenated.
+#include "hqq_common.h"
+
+#ifdef SK_LAB_TS
+extern unsigned long long* g_sk_lab_ts;
+#endif
+namespace hqq {
+
+constexpr int SK_MAXL = HQQ_GEMV_MAX_GROUP;
+constexpr int SK_WAVES = 4;
+constexpr int SK_ROWS = 16 * SK_WAVES;   // packed rows per panel
+constexpr int SK_KC = 256;               // k per chunk
+constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
+constexpr int SK_T = SK_WAVES * 64;
+constexpr int SK_MAX_CPS = 8;           // chunks per K split (the group constants of a split are fetched in one batch)
+
+typedef _Float16 sk_h8_t __attribute__((ext_vector_type(8)));
+
+struct SkArgs {
+  const uint8_t* Wq[SK_MAXL];
+  const half_t* scale[SK_MAXL];
+  const half_t* zero[SK_MAXL];
+  const half_t* bias[SK_MAXL];
+  half_t* y[SK_MAXL];
+  int N[SK_MAXL];           // out_features
+  int panel_end[SK_MAXL];   // end (exclusive) of layer i's panels in the concatenated panel space (unused entries repeat the last)
+  int n_off[SK_MAXL];       // first column of layer i in the concatenated output space of the scratch buffer
+  const half_t* x;
+  float* part;              // [KS][16 MT][n_total] fp32 partial results (KS > 1 only)
+  int M, K, G, total_panels, KS, cps, n_total;
+#ifdef SK_LAB_TS
+  unsigned long long* ts;   // lab only: per-wave timestamps
+#endif
+};
+
+struct SkLayer {   // workgroup-uniform -> SGPRs
+  const uint8_t* Wq;
+  const half_t* scale;
+  const half_t* zero;
+  const half_t* bias;
+  half_t* y;
+  int N, panel0, n_off;
+};
+
+__device__ __forceinline__ SkLayer sk_select(const SkArgs& a, int panel) {
+  SkLayer c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], 0, a.n_off[0]};
+#pragma unroll
+  for (int i = 1; i < SK_MAXL; ++i) {
+    const bool in = panel >= a.panel_end[i - 1];
+    c.Wq = in ? a.Wq[i] : c.Wq;
+    c.scale = in ? a.scale[i] : c.scale;
+    c.zero = in ? a.zero[i] : c.zero;
+    c.bias = in ? a.bias[i] : c.bias;
+    c.y = in ? a.y[i] : c.y;
+    c.N = in ? a.N[i] : c.N;
+    c.panel0 = in ? a.panel_end[i - 1] : c.panel0;
+    c.n_off = in ? a.n_off[i] : c.n_off;
+  }
+  return c;
+}
+
+__device__ __forceinline__ half2_t sk_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t sk_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+
+// exact integer levels of slab S for the byte pairs (b0,b2) [word] / (b1,b3) [word >> 8] of a packed dword as fp16:
+// (word & mask) | 0x6400 is the fp16 number 1024 + q * 2^sh; one packed fma removes the bias exactly.
+template <int NBITS, int S>
+__device__ __forceinline__ half2_t sk_levels(uint32_t word_or_shifted, uint32_t magic) {
+  constexpr int per = 8 / NBITS;
+  constexpr int sh = NBITS * (per - 1 - S);
+  constexpr uint32_t m1 = ((1u << NBITS) - 1u) << sh;
+  constexpr uint32_t m = m1 | (m1 << 16);
+  uint32_t b;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(word_or_shifted), "s"(m), "v"(magic));
+  constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+  const half2_t k1 = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
+  const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
+  return __builtin_elementwise_fma(sk_h2(b), k1, k2);
+}
+
+__device__ __forceinline__ u32x4 sk_permute_x8(u32x4 v) {   // (k0..k7) -> (k0,k2,k1,k3,k4,k6,k5,k7)
+  u32x4 r;
+  r.x = (v.x & 0xFFFFu) | (v.y << 16);
+  r.y = (v.x >> 16) | (v.y & 0xFFFF0000u);
+  r.z = (v.z & 0xFFFFu) | (v.w << 16);
+  r.w = (v.z >> 16) | (v.w & 0xFFFF0000u);
+  return r;
+}
+
+// one 64-k block of one slab: dequantise the lane's 16 weights exactly as Quantizer.dequantize does (two fp16 roundings) ONCE,
+// then contract them with every m-tile's activation octets on the matrix core
+template <int NBITS, int MT, int S, int PER>
+struct SkSlab {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const sk_h8_t (&b0)[MT], const sk_h8_t (&b1)[MT],
+                                             f32x4 (&acc)[PER][MT], uint32_t magic) {
+    const half2_t pr = sk_h2(zs[S]);
+    const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
+    half2_t q[8];
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      q[2 * d] = sk_levels<NBITS, S>(w[d], magic);            // bytes (4d+0, 4d+2)
+      q[2 * d + 1] = sk_levels<NBITS, S>(w[d] >> 8, magic);   // bytes (4d+1, 4d+3)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = q[i] - zz;                                  // rounding 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = sk_u32(q[i] * ss);                          // rounding 2
+    const sk_h8_t a0 = __builtin_bit_cast(sk_h8_t, u32x4{o[0], o[1], o[2], o[3]});   // k = 16c + 0..7 (permuted inside the octet)
+    const sk_h8_t a1 = __builtin_bit_cast(sk_h8_t, u32x4{o[4], o[5], o[6], o[7]});   // k = 16c + 8..15
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[t], acc[S][t], 0, 0, 0);
+      acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[t], acc[S][t], 0, 0, 0);
+    }
+    if constexpr (S + 1 < PER) SkSlab<NBITS, MT, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
+  }
+};
+
+struct SkUnit {   // one chunk of one wave: 4 KiB of packed weights
+  u32x4 w[SK_BLK];
+};
+
+template <int NBITS, int MT>
+__global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
+  constexpr int PER = 8 / NBITS;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [2 buffers][MT][SK_BLK][2 halves][64 lanes] x 16 B
+  constexpr int XS_BUF = MT * SK_BLK * 2 * 64;  // u32x4 per buffer
+  uint32_t* mz = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(2) * XS_BUF * sizeof(u32x4));   // [64 rows][PER][mstride] (zero | scale << 16)
+  constexpr int XP = MT * 2;                    // 16-byte pieces of x per thread and chunk (16 MT rows x 32 octets / 256 threads)
+
+#ifdef SK_LAB_TS
+  unsigned long long t_[8] = {};
+  int tsn = 0;
+#define SK_TS() do { if (tsn < 8) t_[tsn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SK_TS()
+#endif
+  SK_TS();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, c = lane >> 4;
+  const int K = a.K, G = a.G, M = a.M;
+  // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; a speed assumption only), and the KS workgroups of one panel all
+  // read the same 128-byte lines of zero / scale (a row's 64 groups).  Spread over eight L2s each of those lines was fetched up to
+  // KS times and the group constants cost as much HBM traffic as the weights; on one XCD they are fetched once.
+  const int panel = blockIdx.y * 8 + blockIdx.x, ks = blockIdx.z;   // grid (8, panels / 8, KS): blockIdx.x is the XCD
+  if (panel >= a.total_panels) return;
+  const int nchunks = K / SK_KC;
+  const int cps = a.cps;                                       // chunks per split (<= SK_MAX_CPS)
+  const int c0 = ks * cps, c1 = (c0 + cps < nchunks) ? c0 + cps : nchunks;
+  const int mstride = cps * SK_BLK + 1;   // dwords per (row, slab) of group constants in LDS; odd: rows fall on different banks
+  const SkLayer ly = sk_select(a, panel);
+  const int rows_per_slab = ly.N / PER;
+  int p = (panel - ly.panel0) * SK_ROWS + wave * 16 + r;       // packed row inside the layer
+  p = p < rows_per_slab ? p : rows_per_slab - 1;               // ragged last panel: duplicate the last row (masked at the store)
+  const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * K + c * 16;
+
+  // x: the 256 threads fill the chunk's 8 MT fragments in LDS order — piece q = tid + 256 i is lane (q & 63) of fragment
+  // f = q >> 6 = (m-tile t, block j, half h), i.e. the k-octet 64 j + 16 c + 8 h of activation row 16 t + r.  Rows >= M repeat
+  // row 0 (finite values; their columns of the result are never stored) — zeroing them would put the load under a branch:
+  // a wave writes 1 KiB of consecutive LDS (no bank conflicts; a row-major assignment of the pieces put 32 lanes on one bank)
+  u32x4 xr[XP];
+  uint32_t xkeep = ~0u;
+  auto xload = [&](int chunk) {
+    // past the range (odd number of chunks): zeros, so that the ring's second unit can be consumed unconditionally (it then holds
+    // finite dummy weights and adds exactly 0) — a consume under a branch gets its first instructions hoisted above the branch,
+    // in front of the next request, and the wave ends up with one unit in flight instead of two
+    xkeep = chunk < c1 ? ~0u : 0u;   // wave-uniform; applied when the registers are written to LDS (not here: an instruction on
+    chunk = chunk < c1 ? chunk : c1 - 1;   // the loaded value would wait for the load on the spot)
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = wave + SK_WAVES * i, t = f >> 3, j = (f & 7) >> 1, h = f & 1;
+      const int m = 16 * t + r;
+      xr[i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
+    }
+  };
+  auto xstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int f = wave + SK_WAVES * i;
+      const u32x4 v = sk_permute_x8(xr[i]);
+      xs[buf * XS_BUF + f * 64 + lane] = u32x4{v.x & xkeep, v.y & xkeep, v.z & xkeep, v.w & xkeep};
+    }
+  };
+  // Every issue() emits exactly SK_BLK weight loads, in range or not, so that the waits the compiler derives
+  // are exact vmcnt counts and never vmcnt(0).
+  auto issue = [&](SkUnit& un, int chunk) {
+    const bool live = chunk < c1;          // past the range: every lane reads the first bytes of x instead (one cached line,
+    chunk = live ? chunk : c1 - 1;         // no HBM traffic); the unit is never consumed
+#pragma unroll
+    for (int j = 0; j < SK_BLK; ++j) {
+      const u32x4* src = live ? reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(chunk) * SK_KC + j * 64) : reinterpret_cast<const u32x4*>(a.x);
+      un.w[j] = __builtin_nontemporal_load(src);
+    }
+  };
+
+  uint32_t magic;
+  asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));   // opaque to the optimiser: stays in a VGPR
+  f32x4 acc[PER][MT];
+#pragma unroll
+  for (int s = 0; s < PER; ++s)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto consume = [&](const SkUnit& cur, int buf, int chunk) {
+#pragma unroll
+    for (int j = 0; j < SK_BLK; ++j) {
+      uint32_t zs[PER];
+#pragma unroll
+      for (int s = 0; s < PER; ++s) zs[s] = mz[((wave * 16 + r) * PER + s) * mstride + (chunk - c0) * SK_BLK + j];   // one group per block
+      sk_h8_t b0[MT], b1[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        b0[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
+        b1[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
+      }
+      SkSlab<NBITS, MT, 0, PER>::run(cur.w[j], zs, b0, b1, acc, magic);
+    }
+  };
+
+  // ---- prologue: x of the first chunk, both units of the ring, then the group constants of the workgroup's whole K range:
+  //      thread (row = tid >> 2, q = tid & 3) copies [zero | scale] x [slab] (PER = 2: one each; PER = 4: two passes) of its row,
+  //      8 bytes (one chunk's four groups) per load — every line of the two tensors is touched once per workgroup, not once per
+  //      chunk as with per-chunk 2-byte loads, which cost more address-path time than the weights themselves ----
+  SkUnit ua, ub;
+  // group constants FIRST (loads return in order; behind 8 KiB of weights per wave they were the last thing to arrive), and as
+  // coalesced as the layout allows: four lanes fetch four consecutive chunks (32 bytes) of one (row, slab, zero | scale) line, so a
+  // wave instruction touches 16 lines and every line of the two tensors is requested once per workgroup.  (One lane per line, 8
+  // bytes per instruction, was 64 line requests per instruction — several times the L1 -> L2 requests of the weights.)
+  constexpr int NRC = SK_ROWS * 2 * PER;        // (row, slab, zero | scale) lines per panel
+  constexpr int NPASS = NRC / 64;
+  constexpr int NROUND = SK_MAX_CPS / 4;
+  u32x2 mv[NROUND][NPASS];
+#pragma unroll
+  for (int rd = 0; rd < NROUND; ++rd)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int id = pass * 64 + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
+      const int cc = rd * 4 + (tid & 3);
+      int pm = (panel - ly.panel0) * SK_ROWS + row;
+      pm = pm < rows_per_slab ? pm : rows_per_slab - 1;
+      const half_t* src = (hi ? ly.scale : ly.zero) + static_cast<int64_t>(pm + s * rows_per_slab) * G + (c0 + (cc < c1 - c0 ? cc : 0)) * SK_BLK;
+      mv[rd][pass] = *reinterpret_cast<const u32x2*>(src);
+    }
+  SK_TS();   // 1: group constants requested
+  xload(c0);
+  issue(ua, c0);
+  issue(ub, c0 + 1);
+  __builtin_amdgcn_sched_barrier(0);
+  SK_TS();   // 2: x + both units requested
+#pragma unroll
+  for (int rd = 0; rd < NROUND; ++rd)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int id = pass * 64 + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
+      const int cc = rd * 4 + (tid & 3);
+      if (cc < c1 - c0) {
+        uint16_t* dst = reinterpret_cast<uint16_t*>(mz + (row * PER + s) * mstride + cc * SK_BLK) + hi;
+        dst[0] = static_cast<uint16_t>(mv[rd][pass].x);
+        dst[2] = static_cast<uint16_t>(mv[rd][pass].x >> 16);
+        dst[4] = static_cast<uint16_t>(mv[rd][pass].y);
+        dst[6] = static_cast<uint16_t>(mv[rd][pass].y >> 16);
+      }
+    }
+  SK_TS();   // 3: group constants in LDS
+  xstore(0);
+  __syncthreads();
+
+  // ---- two chunks per iteration (ping-pong, no register copies).  Per half: request the next x chunk, consume a unit, request
+  //      the unit two chunks ahead into the registers just freed, write x behind the MFMAs, one barrier. ----
+  // (sched_barrier: the machine scheduler knows nothing about what a wait costs — left alone it lifts the first instructions of
+  //  the NEXT consume, which read the unit requested last, to the front of the block, and the wait they drag along serialises the ring)
+  for (int i = c0; i < c1; i += 2) {
+    xload(i + 1);
+    consume(ua, 0, i);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(ua, i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    xstore(1);
+    __syncthreads();
+    SK_TS();   // 5, 7: first half of an iteration done
+    __builtin_amdgcn_sched_barrier(0);
+    xload(i + 2);
+    consume(ub, 1, i + 1 < c1 ? i + 1 : i);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(ub, i + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    xstore(0);
+    __syncthreads();
+    SK_TS();   // 6: second half done
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- D layout: lane (column r = activation row inside the m-tile, rows 4c + i = packed row inside the wave's 16) ----
+  const int p_base = (panel - ly.panel0) * SK_ROWS + wave * 16 + c * 4;
+#pragma unroll
+  for (int s = 0; s < PER; ++s)
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int m = t * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pp = p_base + i;
+        if (pp < rows_per_slab) {
+          const int n = pp + s * rows_per_slab;
+          if (a.KS == 1) {
+            if (m < M) {
+              half_t o = static_cast<half_t>(acc[s][t][i]);
+              if (ly.bias) o = o + ly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+              ly.y[static_cast<int64_t>(m) * ly.N + n] = o;
+            }
+          } else {
+            a.part[(static_cast<int64_t>(ks) * (16 * MT) + m) * a.n_total + ly.n_off + n] = acc[s][t][i];
+          }
+        }
+      }
+    }
+#ifdef SK_LAB_TS
+  SK_TS();
+  if (lane == 0 && a.ts) { const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x) * SK_WAVES + wave; for (int q = 0; q < 8; ++q) a.ts[w * 8 + q] = t_[q]; }
+#endif
+}
+
+// adds the KS partial results in a fixed order, rounds to fp16, adds the bias, stores
+__global__ __launch_bounds__(256) void skinny_finish_kernel(const SkArgs a, int mpad) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t total = static_cast<int64_t>(a.M) * a.n_total;
+  if (idx >= total) return;
+  const int m = static_cast<int>(idx / a.n_total), ng = static_cast<int>(idx - static_cast<int64_t>(m) * a.n_total);
+  int li = 0;
+#pragma unroll
+  for (int i = 1; i < SK_MAXL; ++i) li = (ng >= a.n_off[i] && a.n_off[i] > a.n_off[i - 1]) ? i : li;
+  float v = 0.f;
+  for (int k = 0; k < a.KS; ++k) v += a.part[(static_cast<int64_t>(k) * mpad + m) * a.n_total + ng];
+  const int n = ng - a.n_off[li];
+  half_t o = static_cast<half_t>(v);
+  if (a.bias[li]) o = o + a.bias[li][n];
+  a.y[li][static_cast<int64_t>(m) * a.N[li] + n] = o;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+static int sk_num_cus() {
+  static int n_cus = 0;
+  if (n_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) n_cus = n;
+    else n_cus = 256;
+  }
+  return n_cus;
+}
+
+// per-device scratch for the split-K partials, grown outside stream capture only (no allocation inside a captured call)
+constexpr int SK_MAX_DEV = 16;
+static float* g_sk_part[SK_MAX_DEV] = {};
+static size_t g_sk_part_bytes[SK_MAX_DEV] = {};
+
+static float* sk_scratch(size_t bytes, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SK_MAX_DEV) { set_error("hqq_hip_gemv: device index out of range"); return nullptr; }
+  if (g_sk_part_bytes[dev] >= bytes) return g_sk_part[dev];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  if (cs != hipStreamCaptureStatusNone) {
+    set_error("hqq_hip_gemv: the split-K scratch (%zu bytes) must be allocated by one call of this shape outside stream capture first", bytes);
+    return nullptr;
+  }
+  const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
+  float* pnew = nullptr;
+  if (hipMalloc(&pnew, want) != hipSuccess) { (void)hipGetLastError(); set_error("hqq_hip_gemv: cannot allocate %zu bytes of split-K scratch", want); return nullptr; }
+  if (g_sk_part[dev]) {
+    (void)hipDeviceSynchronize();   // earlier launches may still read the old buffer
+    (void)hipFree(g_sk_part[dev]);
+  }
+  g_sk_part[dev] = pnew;
+  g_sk_part_bytes[dev] = want;
+  return pnew;
+}
+
+template <int NBITS>
+static int sk_launch(SkArgs& a, hipStream_t st) {
+  const int mt = (a.M + 15) / 16;
+  const int nchunks = a.K / SK_KC;
+  // K splits: enough workgroups for ~2 per CU when the layer is small; shape-dependent only (never M): a row's result must not
+  // depend on the batch it is computed in
+  int ks = (2 * sk_num_cus() + a.total_panels - 1) / a.total_panels;
+  ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
+  ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
+  int cps = (nchunks + ks - 1) / ks;
+  cps = cps > SK_MAX_CPS ? SK_MAX_CPS : cps;  // (long K: more splits than the occupancy rule asks for)
+  ks = (nchunks + cps - 1) / cps;             // drop empty splits
+  a.KS = ks;
+  a.cps = cps;
+#ifdef SK_LAB_TS
+  a.ts = g_sk_lab_ts;
+#endif
+  a.part = nullptr;
+  if (ks > 1) {
+    const size_t bytes = static_cast<size_t>(ks) * 16 * mt * a.n_total * sizeof(float);
+    a.part = sk_scratch(bytes, st);
+    if (!a.part) return HQQ_ERR_UNSUPPORTED;
+  }
+  const size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
+  const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
+#define HQQ_SK_CASE(MT)                                                                                       \
+  case MT: {                                                                                                  \
+    auto kern = skinny_f16_kernel<NBITS, MT>;                                                                 \
+    if (lds > 64 * 1024) {                                                                                    \
+      static bool raised = false;                                                                             \
+      if (!raised) {                                                                                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+        if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); } \
+        raised = true;                                                                                        \
+      }                                                                                                       \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                        \
+    break;                                                                                                    \
+  }
+  switch (mt) {
+    HQQ_SK_CASE(1) HQQ_SK_CASE(2) HQQ_SK_CASE(3) HQQ_SK_CASE(4)
+    default: set_error("hqq_hip_gemv: M=%d outside the skinny kernel's range", a.M); return HQQ_ERR_SHAPE;
+  }
+#undef HQQ_SK_CASE
+  int rc = check_launch("hqq_hip_gemv");
+  if (rc) return rc;
+  if (ks > 1) {
+    const int64_t total = static_cast<int64_t>(a.M) * a.n_total;
+    hipLaunchKernelGGL(skinny_finish_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, a, 16 * mt);
+    rc = check_launch("hqq_hip_gemv");
+  }
+  return rc;
+}
+
+// shapes this kernel covers; everything else stays on the tile kernel of gemv_mfma.hip / the library composition
+bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers) {
+  if ((nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
+  const int per = 8 / nbits;
+  for (int i = 0; i < n_layers; ++i)
+    if (N[i] % per != 0 || N[i] / per < 1) return false;
+  return true;
+}
+
+int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st) {
+  const int per = 8 / nbits;
+  SkArgs a;
+  int64_t panels = 0, ntot = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    a.n_off[i] = static_cast<int>(ntot);
+    panels += (N[i] / per + SK_ROWS - 1) / SK_ROWS;
+    ntot += N[i];
+    if (panels > INT32_MAX / 32 || ntot > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    a.Wq[i] = static_cast<const uint8_t*>(Wq[i]);
+    a.scale[i] = static_cast<const half_t*>(scale[i]);
+    a.zero[i] = static_cast<const half_t*>(zero[i]);
+    a.bias[i] = bias ? static_cast<const half_t*>(bias[i]) : nullptr;
+    a.y[i] = static_cast<half_t*>(y[i]);
+    a.N[i] = static_cast<int>(N[i]);
+    a.panel_end[i] = static_cast<int>(panels);
+  }
+  for (int i = n_layers; i < SK_MAXL; ++i) {
+    a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
+    a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.panel_end[i] = a.panel_end[n_layers - 1]; a.n_off[i] = a.n_off[n_layers - 1];
+  }
+  a.K = static_cast<int>(K);
+  a.G = static_cast<int>(K / 64);
+  a.total_panels = static_cast<int>(panels);
+  a.n_total = static_cast<int>(ntot);
+  a.M = static_cast<int>(M);
+  a.x = static_cast<const half_t*>(x);
+  return nbits == 4 ? sk_launch<4>(a, st) : sk_launch<2>(a, st);
+}
+
+}  // namespace hqq

@@ -83,6 +83,7 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * K % 64 == 0.  Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
+#define HQQ_GEMV_MAX_M_SKINNY 64   /* fp16, 4-/2-bit, group_size 64, K % 256 == 0, K >= 512: the skinny-GEMM kernel */
 #define HQQ_GEMV_MAX_GROUP 4
 int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);

@@ -250,6 +250,65 @@ def test_gemv_8bit_1bit_vs_oracle(ops, oracle, nbits, M):
     assert torch.equal(ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0], Wdev[:, 5])
 
 
+@pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("M", [17, 32, 33, 64])
+@pytest.mark.parametrize("NK", [(512, 1024), (200, 2048 + 768), (64, 11008), (4096 + 8, 512)])
+def test_skinny_gemm_vs_oracle(ops, oracle, nbits, M, NK):
+    """decode with a batch of 17..64 rows (skinny.hip: weights streamed once, split-K partials summed in a fixed order)"""
+    N, K = NK
+    gs = 64
+    assert ops.skinny_covers(torch.float16, M, N, K, gs, nbits)
+    U, s, z = _random_layer(N, K, gs, nbits, seed=N + K + nbits + 7)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half() if M % 2 else None
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
+    yo, y32 = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
+    args = (dev(P), s.cuda(), z.cuda(), None if bias is None else bias.cuda(), N, K, gs, nbits)
+    y = ops.forward(x.cuda(), *args)                       # M <= 64 on a covered config: the fused path, not the library composition
+    assert_forward_parity(y, torch.from_numpy(yo.astype(np.float32)), "skinny gemm vs oracle")
+    assert torch.equal(y, ops.gemv(x.cuda(), *args))
+    # reproducible, and a row's result does not depend on the batch it is computed in (5 rows take the same kernel)
+    assert torch.equal(y, ops.forward(x.cuda(), *args))
+    assert torch.equal(y[:5], ops.gemv(x[:5].cuda(), *args))
+    # one-hot probe: y[m, n] = W[n, k] bit for bit
+    e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+    ks = [(3 * K) // 7, 0, K - 1]
+    for i, k in enumerate(ks): e[i * 5, k] = 1.0
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    ye = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)
+    for i, k in enumerate(ks): assert torch.equal(ye[i * 5], Wdev[:, k])
+    assert torch.count_nonzero(ye[1]) == 0
+
+
+def test_skinny_gemm_grouped_and_capture(ops):
+    """grouped launch == single launches; the split-K scratch is never grown inside a stream capture"""
+    K, gs, M, nbits = 1024, 64, 24, 4
+    layers = []
+    for i, N in enumerate([512, 96, 40, 1024]):
+        U, s, z = _random_layer(N, K, gs, nbits, seed=300 + i)
+        b = torch.randn(N, generator=torch.Generator().manual_seed(i)).half().cuda() if i % 2 else None
+        layers.append((ops.pack(nbits, U.cuda()), s.cuda(), z.cuda(), b, N))
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).half().cuda()
+    ys = ops.gemv_grouped(x, layers, K, gs, nbits)
+    for (Wq, s, z, b, N), y in zip(layers, ys):
+        assert torch.equal(y, ops.gemv(x, Wq, s, z, b, N, K, gs, nbits))
+    # captured after a warm-up call of the same shape: replays give the same bits
+    Wq, s, z, b, N = layers[3]
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    want = ops.gemv(x, Wq, s, z, b, N, K, gs, nbits, out=out).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            ops.gemv(x, Wq, s, z, b, N, K, gs, nbits, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 def test_forward_empty_and_shape_errors(ops):
     N, K, gs = 64, 128, 64
     U, s, z = _random_layer(N, K, gs, 4, seed=1)

@@ -39,9 +39,19 @@ static double run_case(int nbits, int n_group, int N, int K, int M, int reps) {
     }
   };
   sweep(); hipStreamSynchronize(st);
+  // eager launches are host-bound below ~3.4 us each: replay the sweep from a graph (LAB_EAGER=1 for the eager number)
+  hipGraphExec_t ge = nullptr;
+  if (!getenv("LAB_EAGER")) {
+    hipGraph_t g;
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    sweep();
+    hipStreamEndCapture(st, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, st);
-  for (int r = 0; r < reps; ++r) sweep();
+  for (int r = 0; r < reps; ++r) { if (ge) hipGraphLaunch(ge, st); else sweep(); }
   hipEventRecord(e1, st);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -55,18 +65,20 @@ static double run_case(int nbits, int n_group, int N, int K, int M, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 3;
+  if (getenv("LAB_FACTORED")) hqq_hip_set_gemv_mode(HQQ_GEMV_FACTORED);
 #ifdef GV_LAB_TS
   {
     const int nw = 1024 * 8;
     hipMalloc(&g_lab_ts, nw * 8 * 8); hipMemset(g_lab_ts, 0, nw * 8 * 8);
+    setenv("LAB_EAGER", "1", 1);
     run_case(4, 1, atoi(argv[1]), atoi(argv[2]), 1, 1);
     std::vector<unsigned long long> h(nw * 8);
     hipMemcpy(h.data(), g_lab_ts, nw * 64, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull; for (int w = 0; w < nw; ++w) if (h[w * 8]) t0 = h[w * 8] < t0 ? h[w * 8] : t0;
-    printf("wave: start issue staged barrier data consumed end (cycles since first wave start)\n");
-    for (int w = 0; w < nw; w += (w < 8 ? 1 : 397)) { if (!h[w * 8]) continue; printf("w%5d:", w); for (int i = 0; i < 7; ++i) printf(" %7lld", h[w*8+i] ? (long long)(h[w * 8 + i] - h[w * 8]) : -1LL); printf("\n"); }
-    unsigned long long tmax = 0; for (int w = 0; w < nw; ++w) if (h[w*8+6] > tmax) tmax = h[w*8+6];
-    printf("last end: %lld cycles\n", (long long)(tmax - t0));
+    printf("wave: start x-issued A-requested B-requested barrier A-consumed(last) end (cycles since the wave's start)\n");
+    for (int w = 0; w < nw; w += (w < 8 ? 1 : 397)) { if (!h[w * 8]) continue; printf("w%5d (+%6lld):", w, (long long)(h[w * 8] - t0)); for (int i = 0; i < 7; ++i) printf(" %7lld", h[w*8+i] ? (long long)(h[w * 8 + i] - h[w * 8]) : -1LL); printf("\n"); }
+    unsigned long long tmax = 0, smax = 0; for (int w = 0; w < nw; ++w) if (h[w * 8]) { if (h[w*8+6] > tmax) tmax = h[w*8+6]; if (h[w*8] > smax) smax = h[w*8]; }
+    printf("last wave start: +%lld cycles, last end: +%lld cycles\n", (long long)(smax - t0), (long long)(tmax - t0));
     return 0;
   }
 #endif

@@ -125,6 +125,31 @@ def bench_gemm():
     print(f"[ref] dequant kernel + torch.matmul  M={M} {N}x{K}: {t * 1e3:.3f} ms  {2.0 * M * N * K / t / 1e12:.1f} TFLOP/s")
 
 
+def bench_batch():
+    """decode with a batch (5 <= M <= 128): fused paths vs dequantise + library GEMM, weights from HBM (pool > 256 MiB)"""
+    print("== small / medium batches, int4 gs=64 fp16: device us per call (graph replay over a pool of distinct layers) ==")
+    for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008)]:
+        nb = gemv_bytes(N, K, 4, 1)
+        pool_n = max(4, int(600e6 / nb) + 1)
+        pool = [rand_layer(N, K, 4) for _ in range(pool_n)]
+        for M in (8, 16, 32, 64, 128):
+            x = torch.randn(M, K, device="cuda", dtype=torch.float16)
+            y = torch.empty(M, N, device="cuda", dtype=torch.float16)
+            res = []
+            for name, fn in (("forward(default)", lambda W: ops.forward(x, W[0], W[1], W[2], None, N, K, 64, 4, out=y)),
+                             ("dequant+matmul", lambda W: torch.matmul(x, ops.dequantize(W[0], W[1].reshape(-1), W[2].reshape(-1), N, K, 64, 4).t()))):
+                def sweep():
+                    for W in pool:
+                        fn(W)
+                try:
+                    t = graph_time(sweep, pool_n)
+                    res.append(f"{name} {t * 1e6:7.2f} us ({gemv_bytes(N, K, 4, M) / t / 1e9:6.0f} GB/s)")
+                except Exception as e:  # noqa: BLE001
+                    res.append(f"{name} failed: {str(e)[:60]}")
+            print(f"{N}x{K} M={M:4d}: " + "   ".join(res))
+        del pool
+
+
 def bench_quant():
     print("== Quantizer.quantize (HQ solver 20 iters + pack), fp16 weights N(0,0.02^2) ==")
     for (N, K) in [(4096, 4096), (11008, 4096)]:
@@ -156,5 +181,5 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), "| torch", torch.__version__)
     t0 = time.time()
     for w in which:
-        {"gemv": bench_gemv, "gemm": bench_gemm, "quant": bench_quant, "pack": bench_pack}[w]()
+        {"gemv": bench_gemv, "gemm": bench_gemm, "quant": bench_quant, "pack": bench_pack, "batch": bench_batch}[w]()
     print(f"[done in {time.time() - t0:.1f}s]")
