@@ -30,6 +30,22 @@ def gemv_time(N, K, nbits, M=1, n_group=1):
     return t, nbytes
 
 
+def lib_time(N, K, M, n_group=1):
+    """what HQQBackend.PYTORCH does on the GPU, minus its temporaries: HIP dequantise kernel + torch.matmul (hipBLASLt)"""
+    nbytes = n_group * gemv_bytes(N, K, 4, M)
+    pool_n = max(3, int(500e6 / nbytes) + 1)
+    pool = [[rand_layer(N, K, 4) for _ in range(n_group)] for _ in range(pool_n)]
+    x = torch.randn(M, K, device="cuda", dtype=torch.float16)
+
+    def sweep():
+        for grp in pool:
+            for (Wq, s, z) in grp:
+                torch.matmul(x, ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, 64, 4).t())
+    t = graph_time(sweep, pool_n)
+    del pool
+    return t
+
+
 def row(*c):
     print("| " + " | ".join(str(v) for v in c) + " |")
 
@@ -51,21 +67,26 @@ def main():
                            ("down 4096x11008", 4096, 11008, 1)):
         t, nb = gemv_time(N, K, 3, 1, g)
         row(3, "exact", label, f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{nb / t / HBM * 100:.1f}")
-    print("\n## small batches (exact mode, int4, 11008x4096)\n")
-    row("M", "µs", "GB/s", "kernel")
-    row("---", "---", "---", "---")
-    for M in (1, 2, 4, 8, 16):
-        t, nb = gemv_time(11008, 4096, 4, M)
-        row(M, f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", "row-per-wave diag-MFMA" if M <= 4 else "16-row tile MFMA")
-    print("\n## configs[4] — Llama-2-70B shapes, per-rank shard of an output-column shard over P GPUs (bs=1, int4, exact)\n")
-    row("layer", "P", "shard N x K", "µs", "GB/s per GPU", "all-gather payload per rank")
-    row("---", "---", "---", "---", "---", "---")
+    print("\n## decode with a batch (exact weights, int4): fused kernels vs dequantise kernel + hipBLASLt\n")
+    row("launch", "M", "fused µs", "GB/s", "tok/s of this launch", "kernel", "dequantise + library GEMM µs")
+    row("---", "---", "---", "---", "---", "---", "---")
+    for label, N, K, g in (("o 4096x4096", 4096, 4096, 1), ("q|k|v 3x4096x4096", 4096, 4096, 3), ("gate|up 2x11008x4096", 11008, 4096, 2),
+                           ("down 4096x11008", 4096, 11008, 1)):
+        for M in (1, 2, 4, 8, 16, 32, 64):
+            t, nb = gemv_time(N, K, 4, M, g)
+            tl = lib_time(N, K, M, g) if M >= 8 else None
+            kern = "row-per-wave diag-MFMA (gemv.hip)" if M <= 4 else "skinny GEMM (skinny.hip)"
+            row(label, M, f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{M / t:.0f}", kern, "-" if tl is None else f"{tl * 1e6:.2f}")
+    print("\n## configs[4] — Llama-2-70B shapes, per-rank shard of an output-column shard over P GPUs (bs=1 and bs=32, int4, exact)\n")
+    row("layer", "P", "shard N x K", "bs=1 µs", "GB/s per GPU", "all-gather payload per rank (bs=1)", "bs=32 µs", "GB/s per GPU")
+    row("---", "---", "---", "---", "---", "---", "---", "---")
     for label, N, K in (("q/o 8192x8192", 8192, 8192), ("k/v 1024x8192", 1024, 8192), ("gate/up 28672x8192", 28672, 8192), ("down 8192x28672", 8192, 28672)):
         for P in (1, 2, 4, 8):
             if (N // 2) % P:
                 continue
             t, nb = gemv_time(N // P, K, 4, 1)
-            row(label, P, f"{N // P}x{K}", f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{2 * N // P} B")
+            t32, nb32 = gemv_time(N // P, K, 4, 32)
+            row(label, P, f"{N // P}x{K}", f"{t * 1e6:.2f}", f"{nb / t / 1e9:.0f}", f"{2 * N // P} B", f"{t32 * 1e6:.2f}", f"{nb32 / t32 / 1e9:.0f}")
     print("\n## configs[3] — pack / dequantise / solver per layer (fp16 weights N(0, 0.02^2))\n")
     row("nbits", "shape", "quantize (solver 20 it + pack) ms", "G elem-iter/s", "dequantize µs", "dequant GB/s")
     row("---", "---", "---", "---", "---", "---")
