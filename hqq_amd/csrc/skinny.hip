@@ -38,6 +38,7 @@
 // CU's L1 issues the misses of 16 rows x 64 B per wave instruction slowly, and x / group constants queue behind them.
 // Several layers that read the same x (q/k/v, gate/up) form one launch: their panels are concatenated.
 #include "hqq_common.h"
+#include <stdlib.h>
 
 #ifdef SK_LAB_TS
 extern unsigned long long* g_sk_lab_ts;
@@ -50,7 +51,7 @@ constexpr int SK_ROWS = 16 * SK_WAVES;   // packed rows per panel
 constexpr int SK_KC = 256;               // k per chunk
 constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
 constexpr int SK_T = SK_WAVES * 64;
-constexpr int SK_MAX_CPS = 8;           // chunks per K split (the group constants of a split are fetched in one batch)
+constexpr int SK_MAX_CPS = 16;          // chunks per K split (the group constants of a split are fetched in one batch)
 
 typedef _Float16 sk_h8_t __attribute__((ext_vector_type(8)));
 
@@ -420,9 +421,13 @@ template <int NBITS>
 static int sk_launch(SkArgs& a, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
   const int nchunks = a.K / SK_KC;
-  // K splits: enough workgroups for ~2 per CU when the layer is small; shape-dependent only (never M): a row's result must not
-  // depend on the batch it is computed in
-  int ks = (2 * sk_num_cus() + a.total_panels - 1) / a.total_panels;
+  // K splits (shape-dependent only, never M: a row's result must not depend on the batch it is computed in).  Measured on 7B / 70B
+  // shapes: about one workgroup per CU and >= 8 chunks per workgroup wins — every split pays the prologue (first data ~5 us after
+  // launch) and writes a partial tile; only layers with few panels are worth cutting finer.
+  const int cus = sk_num_cus();
+  int ks = (a.total_panels * 16 >= cus * 9 && nchunks <= SK_MAX_CPS) ? 1   // >= 0.56 workgroups per CU: one pass, no partials, no second launch
+                                                                     : (cus + a.total_panels - 1) / a.total_panels;
+  if (a.total_panels >= 48) { const int lim = nchunks / 8 > 1 ? nchunks / 8 : 1; ks = ks > lim ? lim : ks; }
   ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
   ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
   int cps = (nchunks + ks - 1) / ks;
