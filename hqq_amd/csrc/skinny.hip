@@ -46,7 +46,10 @@ extern unsigned long long* g_sk_lab_ts;
 namespace hqq {
 
 constexpr int SK_MAXL = HQQ_GEMV_MAX_GROUP;
-constexpr int SK_WAVES = 4;
+#ifndef SK_WAVES_PER_WG
+#define SK_WAVES_PER_WG 4
+#endif
+constexpr int SK_WAVES = SK_WAVES_PER_WG;
 constexpr int SK_ROWS = 16 * SK_WAVES;   // packed rows per panel
 constexpr int SK_KC = 256;               // k per chunk
 constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [2 buffers][MT][SK_BLK][2 halves][64 lanes] x 16 B
   constexpr int XS_BUF = MT * SK_BLK * 2 * 64;  // u32x4 per buffer
   uint32_t* mz = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(2) * XS_BUF * sizeof(u32x4));   // [64 rows][PER][mstride] (zero | scale << 16)
-  constexpr int XP = MT * 2;                    // 16-byte pieces of x per thread and chunk (16 MT rows x 32 octets / 256 threads)
+  constexpr int XP = (MT * 8 + SK_WAVES - 1) / SK_WAVES;   // 16-byte pieces of x per thread and chunk (8 MT fragments of 64 lanes / waves)
 
 #ifdef SK_LAB_TS
   unsigned long long t_[8] = {};
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     chunk = chunk < c1 ? chunk : c1 - 1;   // the loaded value would wait for the load on the spot)
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      const int f = wave + SK_WAVES * i, t = f >> 3, j = (f & 7) >> 1, h = f & 1;
+      int f = wave + SK_WAVES * i;
+      f = f < 8 * MT ? f : 8 * MT - 1;   // (8 MT not a multiple of the wave count: the spare pieces repeat the last fragment)
+      const int t = f >> 3, j = (f & 7) >> 1, h = f & 1;
       const int m = 16 * t + r;
       xr[i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
     }
@@ -218,7 +223,8 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   auto xstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      const int f = wave + SK_WAVES * i;
+      int f = wave + SK_WAVES * i;
+      f = f < 8 * MT ? f : 8 * MT - 1;
       const u32x4 v = sk_permute_x8(xr[i]);
       xs[buf * XS_BUF + f * 64 + lane] = u32x4{v.x & xkeep, v.y & xkeep, v.z & xkeep, v.w & xkeep};
     }
@@ -269,14 +275,14 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   // wave instruction touches 16 lines and every line of the two tensors is requested once per workgroup.  (One lane per line, 8
   // bytes per instruction, was 64 line requests per instruction — several times the L1 -> L2 requests of the weights.)
   constexpr int NRC = SK_ROWS * 2 * PER;        // (row, slab, zero | scale) lines per panel
-  constexpr int NPASS = NRC / 64;
+  constexpr int NPASS = NRC / (SK_T / 4);
   constexpr int NROUND = SK_MAX_CPS / 4;
   u32x2 mv[NROUND][NPASS];
 #pragma unroll
   for (int rd = 0; rd < NROUND; ++rd)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-      const int id = pass * 64 + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
+      const int id = pass * (SK_T / 4) + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
       const int cc = rd * 4 + (tid & 3);
       int pm = (panel - ly.panel0) * SK_ROWS + row;
       pm = pm < rows_per_slab ? pm : rows_per_slab - 1;
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   for (int rd = 0; rd < NROUND; ++rd)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-      const int id = pass * 64 + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
+      const int id = pass * (SK_T / 4) + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
       const int cc = rd * 4 + (tid & 3);
       if (cc < c1 - c0) {
         uint16_t* dst = reinterpret_cast<uint16_t*>(mz + (row * PER + s) * mstride + cc * SK_BLK) + hi;
@@ -390,7 +396,9 @@ static int sk_num_cus() {
   return n_cus;
 }
 
-// per-device scratch for the split-K partials, grown outside stream capture only (no allocation inside a captured call)
+// per-device scratch for the split-K partials, grown outside stream capture only (no allocation inside a captured call).
+// One buffer per device, not per stream: launches on different streams of a device must not overlap (documented in hqq_hip.h);
+// host-side state is not thread-safe (the reference drives the GPU from one Python thread).
 constexpr int SK_MAX_DEV = 16;
 static float* g_sk_part[SK_MAX_DEV] = {};
 static size_t g_sk_part_bytes[SK_MAX_DEV] = {};
