@@ -10,10 +10,12 @@
 //
 // Decomposition chosen: one wave per OUTPUT row.  Row n's G groups are G consecutive packed rows of one slab (two slabs
 // when the row straddles a slab boundary — handled per lane): 256*G contiguous bytes of which the wave uses 3 bits per
-// word.  The other nine users of the same bytes are the rows n + j*step/G; the grid walks n in order, so they are
-// in flight within the same few microseconds and the re-reads are served by L2 / Infinity Cache — HBM sees each packed
-// byte about once, L2->CU traffic is 10x the packed bytes.  That trades L2 bandwidth (plentiful) for a kernel with no
-// atomics, no cross-wave reduction and a deterministic summation order.
+// word.  The other nine users of the same bytes are the rows of the other slabs that start in the same "p-block"; rows are
+// handed out so that those ten readers are neighbouring waves of ONE XCD (g3_row_of): HBM and the fabric see each packed byte
+// about once, L2->CU traffic is 10x the packed bytes.  That trades L2 bandwidth (plentiful) for a kernel with no atomics, no
+// cross-wave reduction and a deterministic summation order.  Round-1 status: 1.15 TB/s of packed bytes (14 % of 8 TB/s; 0.85
+// before the XCD-aware order) — ~10 instructions per weight, of which 4 are the exact dequantisation; next: one load feeding all
+// ten slabs (partial sums per (unit, slab) added in a fixed order by a finishing pass, as skinny.hip does for its K splits).
 //
 // Per wave instruction: 64 lanes x 16 B = four groups; lane (i = lane & 15, j = lane >> 4) holds words 4i..4i+3 of group
 // 4u + j.  Levels of a slab are pulled out two words at a time (v_lshrrev x2, v_perm, v_and_or onto the fp16 exponent
@@ -40,9 +42,9 @@ struct G3Args {
   half_t* y[G3_MAXL];
   int N[G3_MAXL];
   int step[G3_MAXL];       // ceil(N*G / 10)
-  int row_end[G3_MAXL];    // end (exclusive) of layer i's output rows in the group's concatenated row space
+  int e_end[G3_MAXL];      // end (exclusive) of layer i's entries in one XCD's concatenated row stream (see the kernel)
   const half_t* x;
-  int K, G, total_rows;
+  int K, G, total_e;       // total_e: entries per XCD stream over all layers
 };
 
 struct G3Layer {
@@ -51,14 +53,14 @@ struct G3Layer {
   const half_t* zero;
   const half_t* bias;
   half_t* y;
-  int N, step, row0, end;
+  int N, step, e0, end, li;
 };
 
-__device__ __forceinline__ G3Layer g3_select(const G3Args& a, int row) {
-  G3Layer c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], a.step[0], 0, a.row_end[0]};
+__device__ __forceinline__ G3Layer g3_select(const G3Args& a, int e) {
+  G3Layer c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], a.step[0], 0, a.e_end[0], 0};
 #pragma unroll
   for (int i = 1; i < G3_MAXL; ++i) {
-    const bool in = row >= a.row_end[i - 1];
+    const bool in = e >= a.e_end[i - 1];
     c.Wq = in ? a.Wq[i] : c.Wq;
     c.scale = in ? a.scale[i] : c.scale;
     c.zero = in ? a.zero[i] : c.zero;
@@ -66,10 +68,25 @@ __device__ __forceinline__ G3Layer g3_select(const G3Args& a, int row) {
     c.y = in ? a.y[i] : c.y;
     c.N = in ? a.N[i] : c.N;
     c.step = in ? a.step[i] : c.step;
-    c.row0 = in ? a.row_end[i - 1] : c.row0;
-    c.end = in ? a.row_end[i] : c.end;
+    c.e0 = in ? a.e_end[i - 1] : c.e0;
+    c.end = in ? a.e_end[i] : c.end;
+    c.li = in ? i : c.li;
   }
   return c;
+}
+
+// Which output row an entry of an XCD's stream is.  Ten output rows — one per slab — read (almost) the same packed rows: row n of
+// slab t starts at packed row n*G - t*step.  With rows handed out in index order those ten readers sit ~N/10 rows apart, on
+// different XCDs, and every XCD pulls the words through the fabric for itself: v1 ran at 0.85 TB/s of packed bytes = 8.5 TB/s of
+// fabric traffic.  Here entry e of XCD x (workgroup b runs on XCD b % 8 — observed, a speed assumption only) is slab t = e % 10
+// of "p-block" i = 4 * (8 * (q / 4) + x) + q % 4 with q = e / 10, i.e. output row n = i + ceil(t*step / G): the ten readers of a p-block are consecutive
+// entries of ONE XCD's stream, taken by neighbouring waves at the same time, and nine of the ten reads hit that XCD's L2.
+// Returns -1 for the few (i, t) past the end of a slab.
+// `start` = the layer's table in LDS: start[t] = first output row whose groups begin in slab t = ceil(t*step / G), start[10] = N
+__device__ __forceinline__ int g3_row_of(int e_local, int xcd, const int* start) {
+  const int q = e_local / 10, t = e_local - 10 * q;
+  const int n = (((q >> 2) * 8 + xcd) << 2) + (q & 3) + start[t];   // p-blocks go to XCDs four at a time: neighbours overlap by a row's worth
+  return n < start[t + 1] ? n : -1;
 }
 
 __device__ __forceinline__ float g3_wave_sum(float v) {
@@ -104,9 +121,16 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   const int K = a.K, G = a.G;
   const int nunits = (G + 15) >> 4;
   const int kpad = nunits * 1024;
-  const int stride = gridDim.x * G3_WAVES;
-  const int total = a.total_rows;
+  const int xcd = blockIdx.x & 7;                       // see g3_row_of
+  const int stride = (gridDim.x >> 3) * G3_WAVES;       // entries of this XCD's stream taken per sweep of its waves
+  const int total = a.total_e;
 
+  // ---- slab start table of every layer (11 entries each), once per workgroup ----
+  int* start_tab = reinterpret_cast<int*>(smem + static_cast<size_t>(M) * kpad * 2);
+  if (tid < G3_MAXL * 11) {
+    const int l = tid / 11, t = tid - 11 * l;
+    start_tab[l * 12 + t] = t == 10 ? a.N[l] : (t * a.step[l] + G - 1) / G;
+  }
   // ---- stage x (natural k order) ----
   for (int v = tid; v < M * (kpad >> 3); v += G3_WAVES * 64) {
     const int m = v / (kpad >> 3), j = v - m * (kpad >> 3);
@@ -117,7 +141,8 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
 
   // r0 = first group row of output row `row`; groups past G (last unit of a row) re-read group 0 and meet zero x
   auto issue = [&](G3Unit& un, const G3Layer& ly, int row, int unit) {
-    const int n = row - ly.row0;
+    int n = g3_row_of(row - ly.e0, xcd, start_tab + ly.li * 12);
+    n = n < 0 ? 0 : n;                                 // an entry without a row: same loads on row 0, nothing stored
     const int r0 = n * G;
     const int s0 = r0 / ly.step;                       // slab of the row's first group (wave-uniform)
     const int bound = (s0 + 1) * ly.step;              // first group row of the next slab
@@ -137,12 +162,12 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
     un.sc = __builtin_bit_cast(uint16_t, ly.scale[static_cast<int64_t>(r0) + gm]);
   };
 
-  int row = blockIdx.x * G3_WAVES + wave;
+  int row = (blockIdx.x >> 3) * G3_WAVES + wave;         // entry index in this XCD's stream (not an output row)
   int unit = 0;
   G3Layer ly = g3_select(a, row < total ? row : total - 1);
   G3Unit ua, ub;
+  __syncthreads();                                       // x and the start tables are in LDS
   if (row < total) issue(ua, ly, row, 0);
-  __syncthreads();
 
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
       }
     }
     if (unit == nunits - 1) {   // row finished
-      const int n = orow - oly.row0;
+      const int n = g3_row_of(orow - oly.e0, xcd, start_tab + oly.li * 12);
       float mine_out = 0.f;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
         const float v = g3_wave_sum(part);
         mine_out = lane == m ? v : mine_out;
       }
-      if (lane < M) {
+      if (lane < M && n >= 0) {
         half_t o = static_cast<half_t>(mine_out);
         if (oly.bias) o = o + oly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
         oly.y[static_cast<int64_t>(lane) * oly.N + n] = o;
@@ -237,14 +262,14 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
 template <int M>
 static int g3_launch(const G3Args& a, hipStream_t st) {
   const int nunits = (a.G + 15) >> 4;
-  const size_t lds = static_cast<size_t>(M) * nunits * 1024 * 2;
+  const size_t lds = static_cast<size_t>(M) * nunits * 1024 * 2 + G3_MAXL * 12 * sizeof(int);
   if (lds > 144 * 1024) { set_error("hqq_hip_gemv: x[M=%d, K=%d] does not fit the LDS staging budget", M, a.K); return HQQ_ERR_UNSUPPORTED; }
   int n_cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0) n_cus = 256;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
   per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
-  const int tiles = (a.total_rows + G3_WAVES - 1) / G3_WAVES;
-  const int cap = n_cus * per_cu;
+  const int tiles = 8 * ((a.total_e + G3_WAVES - 1) / G3_WAVES);   // per XCD: one wave per entry of its stream
+  const int cap = (n_cus * per_cu) & ~7;
   auto kern = gemv3_f16_kernel<M>;
   if (lds > 64 * 1024) {
     static bool raised = false;
@@ -265,14 +290,13 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
   if (M > G3_MAX_M) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers M <= %d (got %lld)", G3_MAX_M, (long long)M); return HQQ_ERR_UNSUPPORTED; }
   G3Args a;
   const int64_t G = K / 64;
-  int64_t rows = 0;
+  int64_t ents = 0;
   for (int i = 0; i < n_layers; ++i) {
     if (N[i] <= 0) { set_error("hqq_hip_gemv: bad N"); return HQQ_ERR_SHAPE; }
     if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
     if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     const int64_t R = N[i] * G;
     if (R > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
-    rows += N[i];
     a.Wq[i] = static_cast<const int32_t*>(Wq[i]);
     a.scale[i] = static_cast<const half_t*>(scale[i]);
     a.zero[i] = static_cast<const half_t*>(zero[i]);
@@ -280,17 +304,27 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
     a.y[i] = static_cast<half_t*>(y[i]);
     a.N[i] = static_cast<int>(N[i]);
     a.step[i] = static_cast<int>((R + 9) / 10);
-    a.row_end[i] = static_cast<int>(rows);
+    {   // entries per XCD stream: 10 slabs x 4 p-blocks x ceil(max rows starting in one slab / 32)
+      const int64_t st = a.step[i];
+      int64_t most = 0;
+      for (int t = 0; t < 10; ++t) {
+        const int64_t start = (t * st + G - 1) / G, stop = t == 9 ? N[i] : ((t + 1) * st + G - 1) / G;
+        most = stop - start > most ? stop - start : most;
+      }
+      ents += 10 * 4 * ((most + 31) / 32);
+      if (ents > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    }
+    a.e_end[i] = static_cast<int>(ents);
     if (G > a.step[i]) { set_error("hqq_hip_gemv: 3-bit layer with fewer than 10 output rows per slab is not covered"); return HQQ_ERR_UNSUPPORTED; }
   }
   for (int i = n_layers; i < G3_MAXL; ++i) {
     a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
-    a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.row_end[i] = a.row_end[n_layers - 1];
+    a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.e_end[i] = a.e_end[n_layers - 1];
   }
   a.x = static_cast<const half_t*>(x);
   a.K = static_cast<int>(K);
   a.G = static_cast<int>(G);
-  a.total_rows = static_cast<int>(rows);
+  a.total_e = static_cast<int>(ents);
   switch (M) {
     case 1: return g3_launch<1>(a, st);
     case 2: return g3_launch<2>(a, st);
