@@ -368,21 +368,26 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #endif
 }
 
-// adds the KS partial results in a fixed order, rounds to fp16, adds the bias, stores
+// adds the KS partial results in a fixed order, rounds to fp16, adds the bias, stores.  Grid (columns / 512, M): a thread owns two
+// neighbouring columns (every N is even on this path, so a pair never straddles two layers).
 __global__ __launch_bounds__(256) void skinny_finish_kernel(const SkArgs a, int mpad) {
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t total = static_cast<int64_t>(a.M) * a.n_total;
-  if (idx >= total) return;
-  const int m = static_cast<int>(idx / a.n_total), ng = static_cast<int>(idx - static_cast<int64_t>(m) * a.n_total);
+  const int ng = (blockIdx.x * 256 + threadIdx.x) * 2, m = blockIdx.y;
+  if (ng >= a.n_total) return;
   int li = 0;
 #pragma unroll
   for (int i = 1; i < SK_MAXL; ++i) li = (ng >= a.n_off[i] && a.n_off[i] > a.n_off[i - 1]) ? i : li;
-  float v = 0.f;
-  for (int k = 0; k < a.KS; ++k) v += a.part[(static_cast<int64_t>(k) * mpad + m) * a.n_total + ng];
+  const float* src = a.part + static_cast<int64_t>(m) * a.n_total + ng;
+  const int64_t kstride = static_cast<int64_t>(mpad) * a.n_total;
+  float v0 = 0.f, v1 = 0.f;
+  for (int k = 0; k < a.KS; ++k) {
+    const float2 t = *reinterpret_cast<const float2*>(src + k * kstride);
+    v0 += t.x;
+    v1 += t.y;
+  }
   const int n = ng - a.n_off[li];
-  half_t o = static_cast<half_t>(v);
-  if (a.bias[li]) o = o + a.bias[li][n];
-  a.y[li][static_cast<int64_t>(m) * a.N[li] + n] = o;
+  half2_t o = {static_cast<half_t>(v0), static_cast<half_t>(v1)};
+  if (a.bias[li]) o = o + *reinterpret_cast<const half2_t*>(a.bias[li] + n);
+  *reinterpret_cast<half2_t*>(a.y[li] + static_cast<int64_t>(m) * a.N[li] + n) = o;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -476,8 +481,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
   int rc = check_launch("hqq_hip_gemv");
   if (rc) return rc;
   if (ks > 1) {
-    const int64_t total = static_cast<int64_t>(a.M) * a.n_total;
-    hipLaunchKernelGGL(skinny_finish_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, a, 16 * mt);
+    hipLaunchKernelGGL(skinny_finish_kernel, dim3(static_cast<unsigned>((a.n_total + 511) / 512), static_cast<unsigned>(a.M)), dim3(256), 0, st, a, 16 * mt);
     rc = check_launch("hqq_hip_gemv");
   }
   return rc;
