@@ -63,7 +63,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="decode", choices=["decode", "prefill"])
     ap.add_argument("--nbits", type=int, default=4)
-    ap.add_argument("--bs", type=int, default=1, help="decode batch (rows of x), 1..8")
+    ap.add_argument("--bs", type=int, default=1, help="decode batch (rows of x), 1..64 (fp16 int4/int2; 1..4 for int3 and bf16)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="compute dtype (bf16: decode only, bs <= 4, int4/int2)")
     ap.add_argument("--prefill-tokens", type=int, default=8192)
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -81,7 +82,7 @@ class Layer:
     __slots__ = ("name", "N", "K", "Wq", "scale", "zero")
 
 
-def make_layer(ops, name, N, K, nbits, dev, seed, random_codes):
+def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16):
     L = Layer()
     L.name, L.N, L.K = name, N, K
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -92,13 +93,13 @@ def make_layer(ops, name, N, K, nbits, dev, seed, random_codes):
             L.Wq = torch.randint(0, 2 ** 30, (prow, 64), dtype=torch.int32, device=dev, generator=g)
         else:
             L.Wq = torch.randint(0, 256, (prow, 64), dtype=torch.uint8, device=dev, generator=g)
-        L.scale = (torch.rand(R, 1, device=dev, generator=g) * 0.004 + 0.001).half()
-        L.zero = (torch.rand(R, 1, device=dev, generator=g) * (2 ** nbits - 1)).half()
+        L.scale = (torch.rand(R, 1, device=dev, generator=g) * 0.004 + 0.001).to(cd)
+        L.zero = (torch.rand(R, 1, device=dev, generator=g) * (2 ** nbits - 1)).to(cd)
         return L
     W = (torch.randn(N, K, device=dev, generator=g) * 0.02).half()
     Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4))
     # HQQLinear.cuda(): meta is cast to compute_dtype (quantize.py:515-583)
-    L.Wq, L.scale, L.zero = Wq, s.half(), z.half()
+    L.Wq, L.scale, L.zero = Wq, s.to(cd), z.to(cd)
     return L
 
 
@@ -164,6 +165,8 @@ def main():
     ops.set_gemv_mode(ops.GEMV_FACTORED if a.gemv_mode == "factored" else ops.GEMV_EXACT)
     nbits = a.nbits
     decode = a.workload == "decode"
+    cd = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    assert a.dtype == "f16" or (decode and a.bs <= 4 and nbits in (4, 2)), "bf16: decode, bs <= 4, int4 / int2"
     M = a.bs if decode else a.prefill_tokens
     nblocks = a.blocks if decode else 1
 
@@ -173,17 +176,17 @@ def main():
     for b in range(nblocks):
         blk = {}
         for i, (name, N, K) in enumerate(LLAMA2_7B_BLOCK):
-            blk[name] = make_layer(ops, name, N, K, nbits, dev, seed=1000 * rank + 16 * b + i, random_codes=a.random_codes)
+            blk[name] = make_layer(ops, name, N, K, nbits, dev, seed=1000 * rank + 16 * b + i, random_codes=a.random_codes, cd=cd)
         blocks.append(blk)
     gx = torch.Generator(device=dev).manual_seed(1)       # x is replicated: same seed on every rank
-    xs = {K: torch.randn(M, K, device=dev, generator=gx).half() for K in (4096, 11008)}
+    xs = {K: torch.randn(M, K, device=dev, generator=gx).to(cd) for K in (4096, 11008)}
     # per exchange group: local outputs [len(group), M, N] and, for P > 1, the gathered [P, len(group), M, N]
     out_local, out_full = {}, {}
     for grp in EXCHANGE_GROUPS:
         N = dict((n, nn) for n, nn, _ in LLAMA2_7B_BLOCK)[grp[0]]
-        out_local[grp] = torch.empty(len(grp), M, N, device=dev, dtype=torch.float16)
+        out_local[grp] = torch.empty(len(grp), M, N, device=dev, dtype=cd)
         if world > 1:
-            out_full[grp] = torch.empty(world * len(grp) * M, N, device=dev, dtype=torch.float16)   # rank-major concatenation
+            out_full[grp] = torch.empty(world * len(grp) * M, N, device=dev, dtype=cd)   # rank-major concatenation
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
@@ -285,7 +288,7 @@ def main():
     dev_sec_per_step = ev_elapsed / a.steps
     out = {
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec_per_step * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
     }
     if decode:
         gbs = world * bytes_per_step_rank / sec_per_step / 1e9
@@ -294,7 +297,7 @@ def main():
             "value": round(gbs, 2), "unit": "GB/s",
             "tok_s": round(M / sec_per_step, 2),
             "config": {"workload": f"llama2-7b linear stack ({nblocks} blocks x q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, bs={M} decode, "
-                                   f"fp16, {launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" + (", hipGraph replay" if graph is not None else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
+                                   f"{'bf16' if a.dtype == 'bf16' else 'fp16'}, {launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" + (", hipGraph replay" if graph is not None else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather (weak: {world}x wider layers)",
                        "gemv_mode": mode_name, "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
         })
