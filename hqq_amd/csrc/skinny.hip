@@ -275,7 +275,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   // wave instruction touches 16 lines and every line of the two tensors is requested once per workgroup.  (One lane per line, 8
   // bytes per instruction, was 64 line requests per instruction — several times the L1 -> L2 requests of the weights.)
   constexpr int NRC = SK_ROWS * 2 * PER;        // (row, slab, zero | scale) lines per panel
-  constexpr int NPASS = NRC / (SK_T / 4);
+  constexpr int NPASS = NRC / (SK_T / 4);       // 2 PER
   constexpr int NROUND = SK_MAX_CPS / 4;
   u32x2 mv[NROUND][NPASS];
 #pragma unroll
@@ -489,7 +489,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
 
 // shapes this kernel covers; everything else stays on the tile kernel of gemv_mfma.hip / the library composition
 bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers) {
-  if ((nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
+  if ((nbits != 8 && nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
   const int per = 8 / nbits;
   for (int i = 0; i < n_layers; ++i)
     if (N[i] % per != 0 || N[i] / per < 1) return false;
@@ -524,7 +524,7 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
   a.n_total = static_cast<int>(ntot);
   a.M = static_cast<int>(M);
   a.x = static_cast<const half_t*>(x);
-  return nbits == 4 ? sk_launch<4>(a, st) : sk_launch<2>(a, st);
+  return nbits == 4 ? sk_launch<4>(a, st) : nbits == 2 ? sk_launch<2>(a, st) : sk_launch<8>(a, st);
 }
 
 }  // namespace hqq

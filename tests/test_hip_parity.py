@@ -250,7 +250,7 @@ def test_gemv_8bit_1bit_vs_oracle(ops, oracle, nbits, M):
     assert torch.equal(ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0], Wdev[:, 5])
 
 
-@pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("nbits", [8, 4, 2])
 @pytest.mark.parametrize("M", [17, 32, 33, 64])
 @pytest.mark.parametrize("NK", [(512, 1024), (200, 2048 + 768), (64, 11008), (4096 + 8, 512)])
 def test_skinny_gemm_vs_oracle(ops, oracle, nbits, M, NK):
