@@ -15,9 +15,10 @@
 //   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
 //   scale  [N*G], zero [N*G] fp16, G = K/64; output row n uses [n*G, (n+1)*G)
 //
-// Work decomposition.  A *panel* is 64 packed rows (-> 64*per output rows): one workgroup of four waves, 16 packed rows each,
-// so a wave's accumulators are its own and nothing is reduced across waves.  K is walked in chunks of 256: lane (r = lane & 15,
-// c = lane >> 4) loads the 16 packed bytes of row r at k = 256*chunk + 64*j + 16*c for the chunk's four 64-k blocks j
+// Work decomposition.  A *panel* is 64 packed rows (-> 64*per output rows): one workgroup of eight waves — four row groups of 16
+// packed rows, two waves per row group, each dequantising two of a chunk's four 64-k blocks (their partial tiles meet in LDS
+// once, at the end; one wave per row group left the SIMDs half idle).  K is walked in chunks of 256: lane (r = lane & 15,
+// c = lane >> 4) loads the 16 packed bytes of row r at k = 256*chunk + 64*j + 16*c for its blocks j
 // (global_load_dwordx4, non-temporal), two chunks ahead of their use, ping-pong between two register sets; each block is one
 // quantisation group, whose (zero, scale) the workgroup copied to LDS for its whole K range before the loop (requested before
 // anything else, four lanes per 128-byte line of the two tensors: loads return in order, and as one-lane-per-line gathers behind
@@ -46,14 +47,17 @@ extern unsigned long long* g_sk_lab_ts;
 namespace hqq {
 
 constexpr int SK_MAXL = HQQ_GEMV_MAX_GROUP;
-#ifndef SK_WAVES_PER_WG
-#define SK_WAVES_PER_WG 4
+#ifndef SK_BLOCK_SPLIT
+#define SK_BLOCK_SPLIT 2
 #endif
-constexpr int SK_WAVES = SK_WAVES_PER_WG;
-constexpr int SK_ROWS = 16 * SK_WAVES;   // packed rows per panel
+constexpr int SK_RG = 4;                          // row groups of 16 packed rows per panel
+constexpr int SK_SPLIT = SK_BLOCK_SPLIT;          // waves sharing a row group; each takes SK_BLK / SK_SPLIT blocks of every chunk
+constexpr int SK_WAVES = SK_RG * SK_SPLIT;
+constexpr int SK_ROWS = 16 * SK_RG;               // packed rows per panel
 constexpr int SK_KC = 256;               // k per chunk
 constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
 constexpr int SK_T = SK_WAVES * 64;
+constexpr int SK_BPW = SK_BLK / SK_SPLIT;     // blocks per wave and chunk
 constexpr int SK_MAX_CPS = 16;          // chunks per K split (the group constants of a split are fetched in one batch)
 
 typedef _Float16 sk_h8_t __attribute__((ext_vector_type(8)));
@@ -159,8 +163,8 @@ struct SkSlab {
   }
 };
 
-struct SkUnit {   // one chunk of one wave: 4 KiB of packed weights
-  u32x4 w[SK_BLK];
+struct SkUnit {   // one wave's share of one chunk: SK_BPW KiB of packed weights
+  u32x4 w[SK_BPW];
 };
 
 template <int NBITS, int MT>
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, c = lane >> 4;
+  const int rg = wave % SK_RG, hf = wave / SK_RG;   // row group, and which blocks of a chunk this wave dequantises
   const int K = a.K, G = a.G, M = a.M;
   // XCD-aware placement: workgroup b runs on XCD b % 8 (observed; a speed assumption only), and the KS workgroups of one panel all
   // read the same 128-byte lines of zero / scale (a row's 64 groups).  Spread over eight L2s each of those lines was fetched up to
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   const int mstride = cps * SK_BLK + 1;   // dwords per (row, slab) of group constants in LDS; odd: rows fall on different banks
   const SkLayer ly = sk_select(a, panel);
   const int rows_per_slab = ly.N / PER;
-  int p = (panel - ly.panel0) * SK_ROWS + wave * 16 + r;       // packed row inside the layer
+  int p = (panel - ly.panel0) * SK_ROWS + rg * 16 + r;         // packed row inside the layer
   p = p < rows_per_slab ? p : rows_per_slab - 1;               // ragged last panel: duplicate the last row (masked at the store)
   const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * K + c * 16;
 
@@ -203,30 +208,30 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   // f = q >> 6 = (m-tile t, block j, half h), i.e. the k-octet 64 j + 16 c + 8 h of activation row 16 t + r.  Rows >= M repeat
   // row 0 (finite values; their columns of the result are never stored) — zeroing them would put the load under a branch:
   // a wave writes 1 KiB of consecutive LDS (no bank conflicts; a row-major assignment of the pieces put 32 lanes on one bank)
-  u32x4 xr[XP];
-  uint32_t xkeep = ~0u;
-  auto xload = [&](int chunk) {
+  u32x4 xr[2][XP];           // two register sets: a chunk's x is requested a whole half-iteration before the weights requested in
+  uint32_t xkeep[2] = {~0u, ~0u};   // that half, so that its arrival (loads return in order) never waits behind an HBM round trip
+  auto xload = [&](int chunk, int set) {
     // past the range (odd number of chunks): zeros, so that the ring's second unit can be consumed unconditionally (it then holds
     // finite dummy weights and adds exactly 0) — a consume under a branch gets its first instructions hoisted above the branch,
     // in front of the next request, and the wave ends up with one unit in flight instead of two
-    xkeep = chunk < c1 ? ~0u : 0u;   // wave-uniform; applied when the registers are written to LDS (not here: an instruction on
-    chunk = chunk < c1 ? chunk : c1 - 1;   // the loaded value would wait for the load on the spot)
+    xkeep[set] = chunk < c1 ? ~0u : 0u;   // wave-uniform; applied when the registers are written to LDS (not here: an instruction on
+    chunk = chunk < c1 ? chunk : c1 - 1;  // the loaded value would wait for the load on the spot)
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       int f = wave + SK_WAVES * i;
       f = f < 8 * MT ? f : 8 * MT - 1;   // (8 MT not a multiple of the wave count: the spare pieces repeat the last fragment)
       const int t = f >> 3, j = (f & 7) >> 1, h = f & 1;
       const int m = 16 * t + r;
-      xr[i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
+      xr[set][i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
     }
   };
-  auto xstore = [&](int buf) {
+  auto xstore = [&](int buf, int set) {
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       int f = wave + SK_WAVES * i;
       f = f < 8 * MT ? f : 8 * MT - 1;
-      const u32x4 v = sk_permute_x8(xr[i]);
-      xs[buf * XS_BUF + f * 64 + lane] = u32x4{v.x & xkeep, v.y & xkeep, v.z & xkeep, v.w & xkeep};
+      const u32x4 v = sk_permute_x8(xr[set][i]);
+      xs[buf * XS_BUF + f * 64 + lane] = u32x4{v.x & xkeep[set], v.y & xkeep[set], v.z & xkeep[set], v.w & xkeep[set]};
     }
   };
   // Every issue() emits exactly SK_BLK weight loads, in range or not, so that the waits the compiler derives
@@ -235,9 +240,10 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     const bool live = chunk < c1;          // past the range: every lane reads the first bytes of x instead (one cached line,
     chunk = live ? chunk : c1 - 1;         // no HBM traffic); the unit is never consumed
 #pragma unroll
-    for (int j = 0; j < SK_BLK; ++j) {
+    for (int jl = 0; jl < SK_BPW; ++jl) {
+      const int j = hf * SK_BPW + jl;
       const u32x4* src = live ? reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(chunk) * SK_KC + j * 64) : reinterpret_cast<const u32x4*>(a.x);
-      un.w[j] = __builtin_nontemporal_load(src);
+      un.w[jl] = __builtin_nontemporal_load(src);
     }
   };
 
@@ -251,17 +257,18 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 
   auto consume = [&](const SkUnit& cur, int buf, int chunk) {
 #pragma unroll
-    for (int j = 0; j < SK_BLK; ++j) {
+    for (int jl = 0; jl < SK_BPW; ++jl) {
+      const int j = hf * SK_BPW + jl;
       uint32_t zs[PER];
 #pragma unroll
-      for (int s = 0; s < PER; ++s) zs[s] = mz[((wave * 16 + r) * PER + s) * mstride + (chunk - c0) * SK_BLK + j];   // one group per block
+      for (int s = 0; s < PER; ++s) zs[s] = mz[((rg * 16 + r) * PER + s) * mstride + (chunk - c0) * SK_BLK + j];   // one group per block
       sk_h8_t b0[MT], b1[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         b0[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
         b1[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
       }
-      SkSlab<NBITS, MT, 0, PER>::run(cur.w[j], zs, b0, b1, acc, magic);
+      SkSlab<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
     }
   };
 
@@ -290,8 +297,9 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       mv[rd][pass] = *reinterpret_cast<const u32x2*>(src);
     }
   SK_TS();   // 1: group constants requested
-  xload(c0);
+  xload(c0, 0);
   issue(ua, c0);
+  xload(c0 + 1, 1);
   issue(ub, c0 + 1);
   __builtin_amdgcn_sched_barrier(0);
   SK_TS();   // 2: x + both units requested
@@ -310,36 +318,60 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       }
     }
   SK_TS();   // 3: group constants in LDS
-  xstore(0);
+  xstore(0, 0);
   __syncthreads();
 
-  // ---- two chunks per iteration (ping-pong, no register copies).  Per half: request the next x chunk, consume a unit, request
-  //      the unit two chunks ahead into the registers just freed, write x behind the MFMAs, one barrier. ----
+  // ---- two chunks per iteration (ping-pong, no register copies).  Per half: consume a unit, request x and then the weights two
+  //      chunks ahead (x first: in-order return must not park it behind an HBM round trip — with x requested after the previous
+  //      half's weights every half-iteration lasted one memory latency, whatever it computed), write the x requested one half
+  //      earlier to LDS, one barrier. ----
   // (sched_barrier: the machine scheduler knows nothing about what a wait costs — left alone it lifts the first instructions of
   //  the NEXT consume, which read the unit requested last, to the front of the block, and the wait they drag along serialises the ring)
   for (int i = c0; i < c1; i += 2) {
-    xload(i + 1);
     consume(ua, 0, i);
     __builtin_amdgcn_sched_barrier(0);
+    xload(i + 2, 0);
     issue(ua, i + 2);
     __builtin_amdgcn_sched_barrier(0);
-    xstore(1);
+    xstore(1, 1);                       // x of chunk i + 1, requested one half-iteration ago
     __syncthreads();
     SK_TS();   // 5, 7: first half of an iteration done
     __builtin_amdgcn_sched_barrier(0);
-    xload(i + 2);
     consume(ub, 1, i + 1 < c1 ? i + 1 : i);
     __builtin_amdgcn_sched_barrier(0);
+    xload(i + 3, 1);
     issue(ub, i + 3);
     __builtin_amdgcn_sched_barrier(0);
-    xstore(0);
+    xstore(0, 0);                       // x of chunk i + 2
     __syncthreads();
     SK_TS();   // 6: second half done
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  // ---- the SK_SPLIT waves of a row group each hold a partial tile: the upper ones hand theirs over through LDS (the x buffers
+  //      are free now), wave hf = 0 adds them in a fixed order and stores ----
+  if constexpr (SK_SPLIT > 1) {
+    f32x4* red = reinterpret_cast<f32x4*>(smem);   // [SK_SPLIT - 1][SK_RG][PER][MT][64 lanes]
+    if (hf > 0) {
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[((((hf - 1) * SK_RG + rg) * PER + s) * MT + t) * 64 + lane] = acc[s][t];
+    }
+    __syncthreads();
+    if (hf > 0) return;
+#pragma unroll
+    for (int h = 1; h < SK_SPLIT; ++h)
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const f32x4 o = red[((((h - 1) * SK_RG + rg) * PER + s) * MT + t) * 64 + lane];
+          acc[s][t][0] += o[0]; acc[s][t][1] += o[1]; acc[s][t][2] += o[2]; acc[s][t][3] += o[3];
+        }
+  }
   // ---- D layout: lane (column r = activation row inside the m-tile, rows 4c + i = packed row inside the wave's 16) ----
-  const int p_base = (panel - ly.panel0) * SK_ROWS + wave * 16 + c * 4;
+  const int p_base = (panel - ly.panel0) * SK_ROWS + rg * 16 + c * 4;
 #pragma unroll
   for (int s = 0; s < PER; ++s)
 #pragma unroll
