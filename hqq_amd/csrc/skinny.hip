@@ -58,6 +58,10 @@ constexpr int SK_KC = 256;               // k per chunk
 constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
 constexpr int SK_T = SK_WAVES * 64;
 constexpr int SK_BPW = SK_BLK / SK_SPLIT;     // blocks per wave and chunk
+#ifndef SK_RING_DEPTH
+#define SK_RING_DEPTH 2
+#endif
+constexpr int SK_RING = SK_RING_DEPTH;        // units in flight per wave (even: the two x buffers alternate with the halves); 4 measured no better
 constexpr int SK_MAX_CPS = 16;          // chunks per K split (the group constants of a split are fetched in one batch)
 
 typedef _Float16 sk_h8_t __attribute__((ext_vector_type(8)));
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   //      thread (row = tid >> 2, q = tid & 3) copies [zero | scale] x [slab] (PER = 2: one each; PER = 4: two passes) of its row,
   //      8 bytes (one chunk's four groups) per load — every line of the two tensors is touched once per workgroup, not once per
   //      chunk as with per-chunk 2-byte loads, which cost more address-path time than the weights themselves ----
-  SkUnit ua, ub;
+  SkUnit un[SK_RING];   // the wave's ring of units in flight (indexed by constants only: registers)
   // group constants FIRST (loads return in order; behind 8 KiB of weights per wave they were the last thing to arrive), and as
   // coalesced as the layout allows: four lanes fetch four consecutive chunks (32 bytes) of one (row, slab, zero | scale) line, so a
   // wave instruction touches 16 lines and every line of the two tensors is requested once per workgroup.  (One lane per line, 8
@@ -298,9 +302,10 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     }
   SK_TS();   // 1: group constants requested
   xload(c0, 0);
-  issue(ua, c0);
+  issue(un[0], c0);
   xload(c0 + 1, 1);
-  issue(ub, c0 + 1);
+#pragma unroll
+  for (int k = 1; k < SK_RING; ++k) issue(un[k], c0 + k);
   __builtin_amdgcn_sched_barrier(0);
   SK_TS();   // 2: x + both units requested
 #pragma unroll
@@ -321,31 +326,26 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   xstore(0, 0);
   __syncthreads();
 
-  // ---- two chunks per iteration (ping-pong, no register copies).  Per half: consume a unit, request x and then the weights two
-  //      chunks ahead (x first: in-order return must not park it behind an HBM round trip — with x requested after the previous
+  // ---- SK_RING chunks per iteration (register ring, no copies).  Per half: consume a unit, request x two chunks and then the
+  //      weights SK_RING chunks ahead (x first: in-order return must not park it behind an HBM round trip — with x requested after the previous
   //      half's weights every half-iteration lasted one memory latency, whatever it computed), write the x requested one half
   //      earlier to LDS, one barrier. ----
   // (sched_barrier: the machine scheduler knows nothing about what a wait costs — left alone it lifts the first instructions of
   //  the NEXT consume, which read the unit requested last, to the front of the block, and the wait they drag along serialises the ring)
-  for (int i = c0; i < c1; i += 2) {
-    consume(ua, 0, i);
-    __builtin_amdgcn_sched_barrier(0);
-    xload(i + 2, 0);
-    issue(ua, i + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    xstore(1, 1);                       // x of chunk i + 1, requested one half-iteration ago
-    __syncthreads();
-    SK_TS();   // 5, 7: first half of an iteration done
-    __builtin_amdgcn_sched_barrier(0);
-    consume(ub, 1, i + 1 < c1 ? i + 1 : i);
-    __builtin_amdgcn_sched_barrier(0);
-    xload(i + 3, 1);
-    issue(ub, i + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    xstore(0, 0);                       // x of chunk i + 2
-    __syncthreads();
-    SK_TS();   // 6: second half done
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = c0; i < c1; i += SK_RING) {
+#pragma unroll
+    for (int k = 0; k < SK_RING; ++k) {
+      // chunks past the range (the ring is deeper than the remainder) meet zero x: finite dummy weights, exactly 0 added
+      consume(un[k], k & 1, i + k < c1 ? i + k : c1 - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      xload(i + k + 2, k & 1);
+      issue(un[k], i + k + SK_RING);
+      __builtin_amdgcn_sched_barrier(0);
+      xstore((k + 1) & 1, (k + 1) & 1);   // x of chunk i + k + 1, requested one half-iteration ago
+      __syncthreads();
+      SK_TS();   // 5, 6, 7: a half-iteration done
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- the SK_SPLIT waves of a row group each hold a partial tile: the upper ones hand theirs over through LDS (the x buffers
