@@ -590,8 +590,27 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   const size_t xs_bytes = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
   a.red_off = static_cast<int>((xs_bytes + 15) & ~static_cast<size_t>(15));
   const size_t lds = a.red_off + sizeof(float) * GV_WAVES * M * PER;                  // + K-split reduction buffer
+  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16>;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
   per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
+  {
+    // registers bound the residency too (M = 4 exact needs 152 VGPRs: three workgroups per CU, not four): a persistent grid larger
+    // than what is resident runs its surplus workgroups as a second round behind the first
+    static int by_regs = 0;   // per instantiation
+    if (by_regs == 0) {
+      hipFuncAttributes fa;
+      by_regs = GV_WG_PER_CU;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess && fa.numRegs > 0) {
+        const int regs = (fa.numRegs + 7) & ~7;                 // allocation granule
+        const int waves_per_simd = 512 / regs;                  // unified VGPR/AGPR file of 512 per SIMD lane
+        by_regs = waves_per_simd * 4 / GV_WAVES;                // GV_WAVES waves per workgroup over 4 SIMDs
+        by_regs = by_regs < 1 ? 1 : by_regs;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    per_cu = per_cu > by_regs ? by_regs : per_cu;
+  }
   const int cap = num_cus() * per_cu;
   // few rows x long K (e.g. the 1024 x 28672 shard of a 70B down-projection): one row per wave would leave most of the chip idle
   // and each wave with 2-4 KiB in flight; let the workgroup's waves share a row instead
@@ -599,7 +618,6 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   a.ksplit = (nunits >= GV_WAVES && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * GV_WG_PER_CU * GV_WAVES) ? 1 : 0;
   const int tiles = a.ksplit ? a.total_prow : (a.total_prow + GV_WAVES - 1) / GV_WAVES;
   const int grid = tiles < cap ? tiles : cap;
-  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
     if (!raised) {
