@@ -132,7 +132,7 @@ def group_projections(parent: nn.Module, names) -> bool:
     if L0.nbits == 3 and any(L.group_size != 64 for L in layers):
         return False
     state = _GroupState()
-    state.max_rows = 4 if L0.nbits == 3 else ops.GEMV_MAX_M
+    state.max_rows = 4 if (L0.nbits == 3 or L0.in_features % 64) else ops.GEMV_MAX_M   # (5..16 rows need K % 64 == 0)
     if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits) for L in layers):
         state.max_rows = ops.SKINNY_MAX_M   # decode with a batch: still one weight-streaming launch for the group
     for i, (n, L) in enumerate(zip(names, layers)):

@@ -343,7 +343,11 @@ class HQQLinear(nn.Module):
         if x.dtype == float16:
             if m["packing"] == "3bit_32":   # fused 3-bit kernel: decode-sized batches, group_size 64
                 return rows <= 4 and m["group_size"] == 64
-            return m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8")
+            if m["packing"] not in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8"):
+                return False
+            # 5..16 rows run on 16-row MFMA tiles over 64-k blocks: K must be a multiple of 64 (the row-per-wave kernel, <= 4 rows,
+            # and the library route, >= 17 rows, have no such condition)
+            return not (4 < rows <= ops.GEMV_MAX_M and m["shape"][1] % 64)
         # bf16: the fused decode kernel covers 4-/2-bit up to 4 activation rows; everything else dequantises + library GEMM
         return x.dtype == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8") and x.numel() // x.shape[-1] <= 4
 

@@ -524,7 +524,7 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
   if ((nbits != 8 && nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
   const int per = 8 / nbits;
   for (int i = 0; i < n_layers; ++i)
-    if (N[i] % per != 0 || N[i] / per < 1) return false;
+    if (N[i] % per != 0 || N[i] / per < 1 || N[i] % 2 != 0) return false;   // (the finish pass stores column pairs)
   return true;
 }
 

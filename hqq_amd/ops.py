@@ -182,16 +182,33 @@ LIBRARY_GEMM_MIN_M = 17
 def skinny_covers(dtype, M, N, K, group_size, nbits) -> bool:
     """a batch of up to SKINNY_MAX_M rows that the weight-streaming skinny-GEMM kernel serves (csrc/skinny.hip: skinny_covers)"""
     return (dtype == torch.float16 and nbits in (8, 4, 2) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512
-            and N % (8 // nbits) == 0)
+            and N % (8 // nbits) == 0 and N % 2 == 0)
+
+
+def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:
+    """what hqq_hip_gemv serves for M <= GEMV_MAX_M rows (include/hqq_hip.h); everything else is composed in `forward`"""
+    if M > GEMV_MAX_M or not group_size or K % group_size:
+        return False
+    if nbits == 3:
+        return dtype == torch.float16 and group_size == 64 and M <= 4
+    if nbits not in (8, 4, 2, 1) or group_size % 16 or K % 16 or N % (8 // nbits):
+        return False
+    if dtype == torch.bfloat16:
+        return nbits in (4, 2) and M <= 4
+    return dtype == torch.float16 and (M <= 4 or K % 64 == 0)
 
 
 def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None) -> Tensor:
     """y = x @ dequantize(W_q)^T (+ bias).  M <= 16 (<= 64 where the skinny-GEMM kernel applies): weight-streaming decode kernels;
     larger M: fused MFMA dequant-GEMM, or — from LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.
-    Same dequantised weights either way."""
+    Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit or
+    bf16 beyond 4 rows, 5..16 rows with K % 64 != 0); fused=True never composes: an uncovered configuration raises."""
     M = x.numel() // K if K else 0
+    if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
+        raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
     if fused is None:
-        fused = not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M) or skinny_covers(x.dtype, M, N, K, group_size, nbits)
+        fused = decode_covers(x.dtype, M, N, K, group_size, nbits) if not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M) \
+            else skinny_covers(x.dtype, M, N, K, group_size, nbits)
     if fused:
         return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
     W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)

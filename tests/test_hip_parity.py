@@ -334,6 +334,28 @@ def test_skinny_scratch_is_not_grown_inside_a_capture(ops):
     assert isinstance(failed, bool)
 
 
+@pytest.mark.parametrize("case", [(8, 221, 1024, 64, 48), (8, 167, 4352, 64, 5), (4, 786, 224, 16, 7), (2, 1208, 32, 32, 7), (3, 238, 704, 64, 13),
+                                  (1, 4192, 736, 32, 5)])
+def test_forward_decode_cases_outside_the_fused_kernels(ops, case):
+    """found by tools/fuzz_forward.py: odd N at 8 bits (the skinny kernel's finish pass stores column pairs), 5..16 rows with
+    K % 64 != 0, 3-bit beyond 4 rows — `forward` must compose these (HIP dequantise + library GEMM), not fail or mis-store"""
+    nbits, N, K, gs, M = case
+    U, s, z = _random_layer(N, K, gs, nbits, seed=sum(case))
+    P = ops.pack(nbits, U.cuda())
+    s, z = s.cuda(), z.cuda()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).half().cuda()
+    b = torch.randn(N, generator=torch.Generator().manual_seed(6)).half().cuda()
+    y = ops.forward(x, P, s, z, b, N, K, gs, nbits)
+    Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, gs, nbits)
+    ref = (x.double() @ Wd.double().t()).half()
+    want = (ref + b).float()
+    tol = 2.0 ** -10 * (ref.float().abs() + want.abs()).clamp(min=2.0 ** -4) * 1.01 + 4e-7 * (x.float().abs() @ Wd.float().abs().t()) + 1e-4
+    assert bool(((y.float() - want).abs() <= tol).all())
+    if not ops.decode_covers(torch.float16, M, N, K, gs, nbits) and not ops.skinny_covers(torch.float16, M, N, K, gs, nbits) and nbits not in (4, 2):
+        with pytest.raises(NotImplementedError):   # fused=True never composes: the uncovered configuration is reported
+            ops.forward(x, P, s, z, b, N, K, gs, nbits, fused=True)
+
+
 def test_forward_empty_and_shape_errors(ops):
     N, K, gs = 64, 128, 64
     U, s, z = _random_layer(N, K, gs, 4, seed=1)
