@@ -706,7 +706,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
   const bool skinny_ok = N && dtype == HQQ_F16 && skinny_covers(nbits, M, K, group_size, N, n_layers);
   if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
-    set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 4-/2-bit, group_size 64, K %% 256 == 0)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
+    set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 8-/4-/2-bit, group_size 64, K %% 256 == 0, even N)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
     return HQQ_ERR_SHAPE;
   }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
@@ -727,6 +727,20 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
   const bool exact = g_gemv_mode == HQQ_GEMV_EXACT || dtype == HQQ_BF16;
+  if (n_layers > 1 && !skinny_ok && dtype == HQQ_F16 && (exact ? M > GV_EXACT_ROWWISE_MAX_M : M > 8)) {
+    // a group in which only some layers meet the skinny kernel's conditions: launch the layers one by one, so that a layer is
+    // served by the same kernel (same summation order, same bits) whether or not it was grouped
+    bool any = false;
+    for (int i = 0; i < n_layers; ++i) any = any || skinny_covers(nbits, M, K, group_size, N + i, 1);
+    if (any) {
+      for (int i = 0; i < n_layers; ++i) {
+        const void* b1 = bias ? bias[i] : nullptr;
+        const int rc = hqq_hip_gemv_grouped(nbits, 1, x, Wq + i, scale + i, zero + i, bias ? &b1 : nullptr, y + i, N + i, M, K, group_size, dtype, stream);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   if (exact ? M > GV_EXACT_ROWWISE_MAX_M : (M > 8 && skinny_ok)) {   // (FACTORED: the row-per-wave kernel serves M <= 8 per launch)
     // more activation rows than the row-per-wave kernel contracts cheaply: the 16-row-tile MFMA kernel (needs K % 64 == 0)
     if (K % 64) { set_error("hqq_hip_gemv: M=%lld > %d needs K %% 64 == 0 (got K=%lld)", (long long)M, GV_EXACT_ROWWISE_MAX_M, (long long)K); return HQQ_ERR_UNSUPPORTED; }

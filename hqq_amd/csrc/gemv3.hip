@@ -129,7 +129,8 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   int* start_tab = reinterpret_cast<int*>(smem + static_cast<size_t>(M) * kpad * 2);
   if (tid < G3_MAXL * 11) {
     const int l = tid / 11, t = tid - 11 * l;
-    start_tab[l * 12 + t] = t == 10 ? a.N[l] : (t * a.step[l] + G - 1) / G;
+    const int st = (t * a.step[l] + G - 1) / G;          // (zero-padded rows at the end of the last slabs: clamp to N)
+    start_tab[l * 12 + t] = (t == 10 || st > a.N[l]) ? a.N[l] : st;
   }
   // ---- stage x (natural k order) ----
   for (int v = tid; v < M * (kpad >> 3); v += G3_WAVES * 64) {
@@ -308,7 +309,9 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
       const int64_t st = a.step[i];
       int64_t most = 0;
       for (int t = 0; t < 10; ++t) {
-        const int64_t start = (t * st + G - 1) / G, stop = t == 9 ? N[i] : ((t + 1) * st + G - 1) / G;
+        int64_t start = (t * st + G - 1) / G, stop = t == 9 ? N[i] : ((t + 1) * st + G - 1) / G;
+        start = start > N[i] ? N[i] : start;
+        stop = stop > N[i] ? N[i] : stop;
         most = stop - start > most ? stop - start : most;
       }
       ents += 10 * 4 * ((most + 31) / 32);

@@ -375,7 +375,7 @@ def test_forward_empty_and_shape_errors(ops):
 
 
 @pytest.mark.parametrize("M", [1, 2, 4])
-@pytest.mark.parametrize("NK", [(512, 1024), (101, 512), (1001, 4096), (64, 11008), (4096, 4096)])
+@pytest.mark.parametrize("NK", [(512, 1024), (101, 512), (1001, 4096), (64, 11008), (4096, 4096), (12, 128), (33, 192)])
 def test_gemv_3bit_vs_oracle(ops, oracle, M, NK):
     """3-bit containers: ten unrelated rows per int32, step = ceil(R/10) not row-aligned (N = 101 / 1001: output rows
     straddle slab boundaries).  Exact weights: one-hot probe bit-identical to the dequant kernel."""
