@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised shape sweep of the fused forward against HIP dequantise + fp32 matmul (development aid; needs an MI355X).
-    python tools/fuzz_forward.py [cases] [seed]"""
+    python tools/fuzz_forward.py [cases] [seed] [factored]"""
 import random
 import sys
 
@@ -13,14 +13,17 @@ from hqq_amd import ops  # noqa: E402
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    factored = len(sys.argv) > 3 and sys.argv[3] == "factored"
+    if factored:
+        ops.set_gemv_mode(ops.GEMV_FACTORED)
     bad = 0
     for it in range(cases):
         nbits = rnd.choice([8, 4, 4, 4, 2, 2, 1, 3])
         per = 10 if nbits == 3 else 8 // nbits
         gs = 64 if nbits == 3 or rnd.random() < 0.8 else rnd.choice([16, 32, 128])
-        K = gs * rnd.randint(1, 40) if rnd.random() < 0.5 else 256 * rnd.randint(1, 24)
+        K = gs * rnd.randint(1, 40) if rnd.random() < 0.4 else 256 * rnd.randint(1, 24) if rnd.random() < 0.7 else 1024 * rnd.randint(8, 28)
         K = (K // gs) * gs or gs
-        N = (per if nbits != 3 else 1) * rnd.randint(1, 700)
+        N = (per if nbits != 3 else 1) * (rnd.randint(1, 700) if K < 8192 else rnd.randint(1, 90))
         if nbits == 3 and N * (K // 64) < 10 * (K // 64) * 1:
             N = max(N, 16)
         M = rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100])
@@ -49,6 +52,9 @@ def main():
         # one fp16 ulp of the rounded matmul result (and of the sum, with a bias: two roundings) + the fp32 accumulation noise
         mag = (x.float().abs() @ Wd.float().abs().t())
         tol = 2.0 ** -10 * (pre + refh.float().abs()).clamp(min=2.0 ** -4) * 1.01 + 4e-7 * mag + 1e-4
+        if factored:   # weights not rounded to fp16 one by one: the documented tolerance of the FACTORED mode
+            # (each weight deviates from its fp16-rounded value by up to half an ulp: noise ~ 2^-11 * sqrt(sum x^2 w^2), 6 sigma allowed)
+            tol = tol + 1e-3 + 1e-3 * refh.float().abs() + 6 * 2.0 ** -11 * 0.6 * ((x.float() ** 2) @ (Wd.float() ** 2).t()).sqrt()
         ok = bool((err <= tol).all()) and torch.isfinite(y).all()
         if not ok:
             bad += 1
