@@ -605,6 +605,25 @@ def test_quantize_other_supported_bits(ops, oracle, nbits):
     _check_quant(ops, W.numpy(), nbits, 64, oracle.pack(container, o["Wq"]), o["scale"], o["zero"], max_frac=1e-4)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_quantize_random_shapes_vs_oracle(ops, oracle, seed):
+    """solver + packing on random (N, K, group_size, nbits, weight scale, dtype): ragged group counts, tiny layers, outliers,
+    constant groups (the `denom <= 1e-4` guard, quantize.py:128) — same levels / scale / zero as the CPU oracle"""
+    import random
+    rnd = random.Random(seed)
+    nbits = rnd.choice([4, 4, 3, 2, 8, 1])
+    gs = rnd.choice([64, 64, 32, 128, 16, 8])
+    N, K = rnd.randint(1, 40) * 8, gs * rnd.randint(1, 24)
+    g = torch.Generator().manual_seed(100 + seed)
+    W = torch.randn(N, K, generator=g) * rnd.choice([0.02, 1.0, 1e-3, 30.0])
+    if seed % 3 == 0:
+        W[rnd.randrange(N), :gs] = 0.5                       # a constant group
+        W[rnd.randrange(N), rnd.randrange(K)] = 1e3          # an outlier
+    W = W.to(rnd.choice([torch.float32, torch.float16]))
+    o = oracle.quantize(W.float().numpy(), nbits=nbits, group_size=gs)
+    _check_quant(ops, W.numpy(), nbits, gs, oracle.pack(ops.PACK_BITS[nbits], o["Wq"]), o["scale"], o["zero"], max_frac=1e-4)
+
+
 def test_quantize_full_size_properties(ops):
     """4096x4096 N(0,0.02^2): levels in range, dequant error sane, round trip through pack."""
     W = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(0)) * 0.02).half().cuda()
