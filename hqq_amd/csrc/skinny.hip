@@ -50,7 +50,10 @@ constexpr int SK_MAXL = HQQ_GEMV_MAX_GROUP;
 #ifndef SK_BLOCK_SPLIT
 #define SK_BLOCK_SPLIT 2
 #endif
-constexpr int SK_RG = 4;                          // row groups of 16 packed rows per panel
+#ifndef SK_ROW_GROUPS
+#define SK_ROW_GROUPS 4
+#endif
+constexpr int SK_RG = SK_ROW_GROUPS;                        // row groups of 16 packed rows per panel
 constexpr int SK_SPLIT = SK_BLOCK_SPLIT;          // waves sharing a row group; each takes SK_BLK / SK_SPLIT blocks of every chunk
 constexpr int SK_WAVES = SK_RG * SK_SPLIT;
 constexpr int SK_ROWS = 16 * SK_RG;               // packed rows per panel
