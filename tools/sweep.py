@@ -108,6 +108,25 @@ def main():
             b.record(); torch.cuda.synchronize()
             td = a.elapsed_time(b) / 10 * 1e-3
             row(nbits, f"{N}x{K}", f"{tq * 1e3:.2f}", f"{N * K * 20 / tq / 1e9:.0f}", f"{td * 1e6:.1f}", f"{(2 * N * K + Wq.numel() * Wq.element_size()) / td / 1e9:.0f}")
+    print("\n## configs[3] — stand-alone bit-packing kernels (BitPack.pack_* / unpack_*), 4096x4096 (uint8 levels in, fp16 out of unpack)\n")
+    row("nbits", "pack µs", "pack GB/s (read levels + write packed)", "unpack µs", "unpack GB/s (read packed + write fp16)")
+    row("---", "---", "---", "---", "---")
+    R = 4096 * 4096 // 64
+    for nbits in (4, 3, 2):
+        U = torch.randint(0, 2 ** nbits, (R, 64), dtype=torch.uint8, device="cuda")
+        P = ops.pack(nbits, U)
+        res = []
+        for fn, nbytes in ((lambda: ops.pack(nbits, U), U.numel() + P.numel() * P.element_size()),
+                           (lambda: ops.unpack(nbits, P, torch.float16), 2 * U.numel() + P.numel() * P.element_size())):
+            for _ in range(3):
+                fn()
+            a.record()
+            for _ in range(20):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            t = a.elapsed_time(b) / 20 * 1e-3
+            res += [f"{t * 1e6:.1f}", f"{nbytes / t / 1e9:.0f}"]
+        row(nbits, *res)
     print("\n## configs[2] — prefill, M = 8192 tokens (a 4x2048 chunk of the 32x2048 batch), int4\n")
     row("shape", "fused MFMA dequant-GEMM ms", "TFLOP/s", "dequant + hipBLASLt ms", "TFLOP/s")
     row("---", "---", "---", "---", "---")
