@@ -63,8 +63,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="decode", choices=["decode", "prefill"])
     ap.add_argument("--nbits", type=int, default=4)
-    ap.add_argument("--bs", type=int, default=1, help="decode batch (rows of x), 1..64 (fp16 int4/int2; 1..4 for int3 and bf16)")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="compute dtype (bf16: decode only, bs <= 4, int4/int2)")
+    ap.add_argument("--bs", type=int, default=1, help="decode batch (rows of x), 1..64 (int4/int2/int8 from 5 up, fp16 or bf16; 1..4 for int3)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="compute dtype (bf16: decode only)")
     ap.add_argument("--prefill-tokens", type=int, default=8192)
     ap.add_argument("--blocks", type=int, default=N_BLOCKS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -166,7 +166,7 @@ def main():
     nbits = a.nbits
     decode = a.workload == "decode"
     cd = torch.bfloat16 if a.dtype == "bf16" else torch.float16
-    assert a.dtype == "f16" or (decode and a.bs <= 4 and nbits in (4, 2)), "bf16: decode, bs <= 4, int4 / int2"
+    assert a.dtype == "f16" or (decode and (a.bs >= 5 or nbits in (4, 2))), "bf16: decode only; bs <= 4 needs int4 / int2 (bs 5..64: int8/4/2)"
     M = a.bs if decode else a.prefill_tokens
     nblocks = a.blocks if decode else 1
 

@@ -60,7 +60,9 @@ class HQQLinearHIP(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
-        if (self.compute_dtype == torch.bfloat16 or self.nbits == 3) and x.numel() // x.shape[-1] > 4:
+        rows = x.numel() // x.shape[-1]
+        if (self.compute_dtype == torch.bfloat16 or self.nbits == 3) and rows > 4 and \
+                not ops.skinny_covers(x.dtype, rows, self.out_features, self.in_features, self.group_size, self.nbits):
             # bf16 / 3-bit beyond the decode kernels' 4 rows: HIP dequantise kernel + library GEMM
             out = torch.matmul(x, self.dequantize().t())
             if self.bias is not None:

@@ -349,7 +349,10 @@ class HQQLinear(nn.Module):
             # and the library route, >= 17 rows, have no such condition)
             return not (4 < rows <= ops.GEMV_MAX_M and m["shape"][1] % 64)
         # bf16: the fused decode kernel covers 4-/2-bit up to 4 activation rows; everything else dequantises + library GEMM
-        return x.dtype == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8") and x.numel() // x.shape[-1] <= 4
+        if x.dtype != torch.bfloat16 or m["packing"] not in ("4bit_u8", "2bit_u8", "8bit_u8"):
+            return False
+        N, K = m["shape"]
+        return (rows <= 4 and m["packing"] != "8bit_u8") or ops.skinny_covers(x.dtype, rows, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]])
 
     def forward_hip(self, x: Tensor) -> Tensor:
         """Fused unpack -> dequantize -> GEMV / GEMM (one launch).  Configurations the fused kernels do not cover run the

@@ -228,11 +228,13 @@ struct SlabExact {
 };
 
 // bf16 compute dtype: the reference's two roundings are to bf16 (quantize.py:198 on bf16 tensors).  gfx950 has no packed
-// bf16 arithmetic, so the weight goes through fp32: q - z is exact in fp32 (one fma on the biased level), v_cvt_pk_bf16_f32
-// rounds it (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds again.
+// bf16 arithmetic, so the weight goes through fp32: v_cvt_f32_ubyteN lifts the masked byte F q, one fma forms q - z,
+// v_cvt_pk_bf16_f32 rounds it (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds again.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int B>
+__device__ __forceinline__ float ubyte_f32(uint32_t v) { return static_cast<float>((v >> (8 * B)) & 0xFFu); }   // v_cvt_f32_ubyteB
 template <int NBITS, int M, int S, int PER>
 struct SlabExactBF16 {
   static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const bf16x8_t (&b0)[M], const bf16x8_t (&b1)[M],
@@ -240,17 +242,20 @@ struct SlabExactBF16 {
     constexpr int sh = NBITS * (PER - 1 - S);
     constexpr float inv = 1.0f / static_cast<float>(1 << sh);
     const float zf = __uint_as_float(zs[S] << 16);
-    const float c = -(1024.0f * inv) - zf;                                  // exact: z has 8 significant bits
     const bf16x2_t s_lo = __builtin_bit_cast(bf16x2_t, zs[S] >> 16);          // (s, 0)
     const bf16x2_t s_hi = __builtin_bit_cast(bf16x2_t, zs[S] & 0xFFFF0000u);  // (0, s)
+    constexpr uint32_t m1 = ((1u << NBITS) - 1u) << sh;
     uint32_t o[8];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
+      const uint32_t fq = NBITS == 8 ? w[d] : (w[d] & (m1 * 0x01010101u));   // the word's four bytes reduced to slab S's field (F q each)
+      // fma(F q, 1 / F, -z) is q - z with ONE fp32 rounding (none unless z is below 2^-15): a bias folded into the addend
+      // (-(1024 / F) - z) would itself round when z is small and cost an ulp after rounding 1
+      const f32x2_t dq[2] = {{__builtin_fmaf(ubyte_f32<0>(fq), inv, -zf), __builtin_fmaf(ubyte_f32<2>(fq), inv, -zf)},    // bytes (4d+0, 4d+2)
+                             {__builtin_fmaf(ubyte_f32<1>(fq), inv, -zf), __builtin_fmaf(ubyte_f32<3>(fq), inv, -zf)}};   // bytes (4d+1, 4d+3)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const half2_t bl = biased_levels<NBITS, S>(h ? (w[d] >> 8) : w[d], magic);   // fp16 (1024 + F q, 1024 + F q')
-        const f32x2_t dq = {__builtin_fmaf(static_cast<float>(bl.x), inv, c), __builtin_fmaf(static_cast<float>(bl.y), inv, c)};   // q - z, exact
-        const bf16x2_t dr = __builtin_convertvector(dq, bf16x2_t);                    // rounding 1
+        const bf16x2_t dr = __builtin_convertvector(dq[h], bf16x2_t);                 // rounding 1
         const f32x2_t pw = {__builtin_amdgcn_fdot2_f32_bf16(dr, s_lo, 0.f, false), __builtin_amdgcn_fdot2_f32_bf16(dr, s_hi, 0.f, false)};
         o[2 * d + h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, bf16x2_t));   // rounding 2
       }
@@ -687,7 +692,7 @@ int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq,
                   const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
 bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st);
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, hipStream_t st);
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
 static int g_gemv_mode = HQQ_GEMV_EXACT;
@@ -704,7 +709,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   clear_stale_error();
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
-  const bool skinny_ok = N && dtype == HQQ_F16 && skinny_covers(nbits, M, K, group_size, N, n_layers);
+  const bool skinny_ok = N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, N, n_layers);
   if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
     set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 8-/4-/2-bit, group_size 64, K %% 256 == 0, even N)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
     return HQQ_ERR_SHAPE;
@@ -718,7 +723,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   }
   if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
   if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
-  if (dtype == HQQ_BF16 && (M > GV_EXACT_ROWWISE_MAX_M || (nbits != 4 && nbits != 2))) {
+  if (dtype == HQQ_BF16 && !skinny_ok && (M > GV_EXACT_ROWWISE_MAX_M || (nbits != 4 && nbits != 2))) {
     set_error("hqq_hip_gemv: bf16 covers nbits 4/2 and M <= %d (got nbits=%d M=%lld)", GV_EXACT_ROWWISE_MAX_M, nbits, (long long)M);
     return HQQ_ERR_UNSUPPORTED;
   }
@@ -727,7 +732,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
   const bool exact = g_gemv_mode == HQQ_GEMV_EXACT || dtype == HQQ_BF16;
-  if (n_layers > 1 && !skinny_ok && dtype == HQQ_F16 && (exact ? M > GV_EXACT_ROWWISE_MAX_M : M > 8)) {
+  if (n_layers > 1 && !skinny_ok && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (exact ? M > GV_EXACT_ROWWISE_MAX_M : M > 8)) {
     // a group in which only some layers meet the skinny kernel's conditions: launch the layers one by one, so that a layer is
     // served by the same kernel (same summation order, same bits) whether or not it was grouped
     bool any = false;
@@ -751,7 +756,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-    if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, as_stream(stream));
+    if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }
   int m_max = max_m_per_launch(K);

@@ -38,6 +38,8 @@
 // (dequantise + hipBLASLt: 28-30); 11008 x 4096: 20.6 / 29 / 45 (43-46).  The first 5 us of a launch go into the prologue: the
 // CU's L1 issues the misses of 16 rows x 64 B per wave instruction slowly, and x / group constants queue behind them.
 // Several layers that read the same x (q/k/v, gate/up) form one launch: their panels are concatenated.
+#include <type_traits>
+
 #include "hqq_common.h"
 #include <stdlib.h>
 
@@ -170,11 +172,62 @@ struct SkSlab {
   }
 };
 
+// bf16 compute dtype: the reference's two roundings are to bf16 (quantize.py:198 on bf16 tensors).  gfx950 has no packed bf16
+// arithmetic, so the weight goes through fp32: v_cvt_f32_ubyteN lifts the masked byte F q, one fma forms q - z, v_cvt_pk_bf16_f32 rounds it
+// (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds again (as gemv.hip).
+typedef __bf16 sk_bf2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 sk_bf8_t __attribute__((ext_vector_type(8)));
+typedef float sk_f2_t __attribute__((ext_vector_type(2)));
+template <int NBITS, int S>
+__device__ __forceinline__ uint32_t sk_masked(uint32_t word) {   // the four bytes of a word reduced to slab S's field (F q each)
+  constexpr int per = 8 / NBITS;
+  constexpr int sh = NBITS * (per - 1 - S);
+  constexpr uint32_t m1 = ((1u << NBITS) - 1u) << sh;
+  if constexpr (NBITS == 8) return word;
+  return word & (m1 * 0x01010101u);
+}
+template <int B>
+__device__ __forceinline__ float sk_ubyte(uint32_t v) { return static_cast<float>((v >> (8 * B)) & 0xFFu); }   // v_cvt_f32_ubyteB
+template <int NBITS, int MT, int S, int PER>
+struct SkSlabBF16 {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const sk_bf8_t (&b0)[MT], const sk_bf8_t (&b1)[MT],
+                                             f32x4 (&acc)[PER][MT], uint32_t magic) {
+    constexpr int sh = NBITS * (PER - 1 - S);
+    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+    const float zf = __uint_as_float(zs[S] << 16);
+    const sk_bf2_t s_lo = __builtin_bit_cast(sk_bf2_t, zs[S] >> 16);          // (s, 0)
+    const sk_bf2_t s_hi = __builtin_bit_cast(sk_bf2_t, zs[S] & 0xFFFF0000u);  // (0, s)
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t fq = sk_masked<NBITS, S>(w[d]);
+      // fma(F q, 1 / F, -z) is q - z with ONE fp32 rounding (none unless z is below 2^-15): a bias folded into the addend
+      // (-(1024 / F) - z) would itself round when z is small and cost an ulp after rounding 1
+      const sk_f2_t dq[2] = {{__builtin_fmaf(sk_ubyte<0>(fq), inv, -zf), __builtin_fmaf(sk_ubyte<2>(fq), inv, -zf)},    // bytes (4d+0, 4d+2)
+                             {__builtin_fmaf(sk_ubyte<1>(fq), inv, -zf), __builtin_fmaf(sk_ubyte<3>(fq), inv, -zf)}};   // bytes (4d+1, 4d+3)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const sk_bf2_t dr = __builtin_convertvector(dq[h], sk_bf2_t);                 // rounding 1
+        const sk_f2_t pw = {__builtin_amdgcn_fdot2_f32_bf16(dr, s_lo, 0.f, false), __builtin_amdgcn_fdot2_f32_bf16(dr, s_hi, 0.f, false)};
+        o[2 * d + h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, sk_bf2_t));   // rounding 2
+      }
+    }
+    const sk_bf8_t a0 = __builtin_bit_cast(sk_bf8_t, u32x4{o[0], o[1], o[2], o[3]});
+    const sk_bf8_t a1 = __builtin_bit_cast(sk_bf8_t, u32x4{o[4], o[5], o[6], o[7]});
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[t], acc[S][t], 0, 0, 0);
+      acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[t], acc[S][t], 0, 0, 0);
+    }
+    if constexpr (S + 1 < PER) SkSlabBF16<NBITS, MT, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
+  }
+};
+
 struct SkUnit {   // one wave's share of one chunk: SK_BPW KiB of packed weights
   u32x4 w[SK_BPW];
 };
 
-template <int NBITS, int MT>
+template <int NBITS, int MT, bool BF16>
 __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -269,12 +322,15 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       uint32_t zs[PER];
 #pragma unroll
       for (int s = 0; s < PER; ++s) zs[s] = mz[((rg * 16 + r) * PER + s) * mstride + (chunk - c0) * SK_BLK + j];   // one group per block
-      sk_h8_t b0[MT], b1[MT];
+      using frag_t = std::conditional_t<BF16, sk_bf8_t, sk_h8_t>;
+      frag_t b0[MT], b1[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        b0[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
-        b1[t] = __builtin_bit_cast(sk_h8_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
+        b0[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
+        b1[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
       }
+      if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
+      else
       SkSlab<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
     }
   };
@@ -387,9 +443,15 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
           const int n = pp + s * rows_per_slab;
           if (a.KS == 1) {
             if (m < M) {
-              half_t o = static_cast<half_t>(acc[s][t][i]);
-              if (ly.bias) o = o + ly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-              ly.y[static_cast<int64_t>(m) * ly.N + n] = o;
+              if constexpr (BF16) {
+                uint16_t o = f32_to_bf16(acc[s][t][i]);
+                if (ly.bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(ly.bias)[n]));
+                reinterpret_cast<uint16_t*>(ly.y)[static_cast<int64_t>(m) * ly.N + n] = o;
+              } else {
+                half_t o = static_cast<half_t>(acc[s][t][i]);
+                if (ly.bias) o = o + ly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+                ly.y[static_cast<int64_t>(m) * ly.N + n] = o;
+              }
             }
           } else {
             a.part[(static_cast<int64_t>(ks) * (16 * MT) + m) * a.n_total + ly.n_off + n] = acc[s][t][i];
@@ -405,6 +467,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 
 // adds the KS partial results in a fixed order, rounds to fp16, adds the bias, stores.  Grid (columns / 512, M): a thread owns two
 // neighbouring columns (every N is even on this path, so a pair never straddles two layers).
+template <bool BF16>
 __global__ __launch_bounds__(256) void skinny_finish_kernel(const SkArgs a, int mpad) {
   const int ng = (blockIdx.x * 256 + threadIdx.x) * 2, m = blockIdx.y;
   if (ng >= a.n_total) return;
@@ -420,9 +483,19 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const SkArgs a, int 
     v1 += t.y;
   }
   const int n = ng - a.n_off[li];
-  half2_t o = {static_cast<half_t>(v0), static_cast<half_t>(v1)};
-  if (a.bias[li]) o = o + *reinterpret_cast<const half2_t*>(a.bias[li] + n);
-  *reinterpret_cast<half2_t*>(a.y[li] + static_cast<int64_t>(m) * a.N[li] + n) = o;
+  if constexpr (BF16) {
+    uint16_t o0 = f32_to_bf16(v0), o1 = f32_to_bf16(v1);
+    if (a.bias[li]) {
+      const uint16_t* b = reinterpret_cast<const uint16_t*>(a.bias[li]) + n;
+      o0 = f32_to_bf16(bf16_to_f32(o0) + bf16_to_f32(b[0]));
+      o1 = f32_to_bf16(bf16_to_f32(o1) + bf16_to_f32(b[1]));
+    }
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(a.y[li]) + static_cast<int64_t>(m) * a.N[li] + n) = static_cast<uint32_t>(o0) | (static_cast<uint32_t>(o1) << 16);
+  } else {
+    half2_t o = {static_cast<half_t>(v0), static_cast<half_t>(v1)};
+    if (a.bias[li]) o = o + *reinterpret_cast<const half2_t*>(a.bias[li] + n);
+    *reinterpret_cast<half2_t*>(a.y[li] + static_cast<int64_t>(m) * a.N[li] + n) = o;
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -465,7 +538,7 @@ static float* sk_scratch(size_t bytes, hipStream_t st) {
   return pnew;
 }
 
-template <int NBITS>
+template <int NBITS, bool BF16>
 static int sk_launch(SkArgs& a, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
   const int nchunks = a.K / SK_KC;
@@ -496,7 +569,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
 #define HQQ_SK_CASE(MT)                                                                                       \
   case MT: {                                                                                                  \
-    auto kern = skinny_f16_kernel<NBITS, MT>;                                                                 \
+    auto kern = skinny_f16_kernel<NBITS, MT, BF16>;                                                               \
     if (lds > 64 * 1024) {                                                                                    \
       static bool raised = false;                                                                             \
       if (!raised) {                                                                                          \
@@ -516,7 +589,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
   int rc = check_launch("hqq_hip_gemv");
   if (rc) return rc;
   if (ks > 1) {
-    hipLaunchKernelGGL(skinny_finish_kernel, dim3(static_cast<unsigned>((a.n_total + 511) / 512), static_cast<unsigned>(a.M)), dim3(256), 0, st, a, 16 * mt);
+    hipLaunchKernelGGL(skinny_finish_kernel<BF16>, dim3(static_cast<unsigned>((a.n_total + 511) / 512), static_cast<unsigned>(a.M)), dim3(256), 0, st, a, 16 * mt);
     rc = check_launch("hqq_hip_gemv");
   }
   return rc;
@@ -532,7 +605,7 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
 }
 
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st) {
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, hipStream_t st) {
   const int per = 8 / nbits;
   SkArgs a;
   int64_t panels = 0, ntot = 0;
@@ -559,7 +632,8 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
   a.n_total = static_cast<int>(ntot);
   a.M = static_cast<int>(M);
   a.x = static_cast<const half_t*>(x);
-  return nbits == 4 ? sk_launch<4>(a, st) : nbits == 2 ? sk_launch<2>(a, st) : sk_launch<8>(a, st);
+  if (dtype == HQQ_BF16) return nbits == 4 ? sk_launch<4, true>(a, st) : nbits == 2 ? sk_launch<2, true>(a, st) : sk_launch<8, true>(a, st);
+  return nbits == 4 ? sk_launch<4, false>(a, st) : nbits == 2 ? sk_launch<2, false>(a, st) : sk_launch<8, false>(a, st);
 }
 
 }  // namespace hqq

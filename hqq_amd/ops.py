@@ -18,7 +18,7 @@ PER = {8: 1, 4: 2, 2: 4, 1: 8, 3: 10}
 # Quantizer.bit_to_packing (hqq/core/quantize.py:40-49): container width per nbits
 PACK_BITS = {8: 8, 6: 8, 5: 8, 4: 4, 3: 3, 2: 2, 1.58: 2, 1: 1}
 GEMV_MAX_M = 16
-SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512
+SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512, even N
 GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 
@@ -131,7 +131,7 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
 
 
 def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
-    """fused unpack->dequant->GEMV for decode-sized batches: 1 <= M <= 16 (3-bit and bf16: <= 4; FACTORED mode: <= 8)."""
+    """fused unpack->dequant->GEMV for decode-sized batches: 1 <= M <= 16 (3-bit, and bf16 outside the skinny-GEMM kernel: <= 4; FACTORED mode: <= 8); up to SKINNY_MAX_M where skinny_covers()."""
     return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
 
 
@@ -181,7 +181,7 @@ LIBRARY_GEMM_MIN_M = 17
 
 def skinny_covers(dtype, M, N, K, group_size, nbits) -> bool:
     """a batch of up to SKINNY_MAX_M rows that the weight-streaming skinny-GEMM kernel serves (csrc/skinny.hip: skinny_covers)"""
-    return (dtype == torch.float16 and nbits in (8, 4, 2) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512
+    return (dtype in (torch.float16, torch.bfloat16) and nbits in (8, 4, 2) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512
             and N % (8 // nbits) == 0 and N % 2 == 0)
 
 
@@ -201,14 +201,14 @@ def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:
 def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None) -> Tensor:
     """y = x @ dequantize(W_q)^T (+ bias).  M <= 16 (<= 64 where the skinny-GEMM kernel applies): weight-streaming decode kernels;
     larger M: fused MFMA dequant-GEMM, or — from LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.
-    Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit or
-    bf16 beyond 4 rows, 5..16 rows with K % 64 != 0); fused=True never composes: an uncovered configuration raises."""
+    Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit beyond 4 rows,
+    bf16 beyond 4 rows outside the skinny-GEMM kernel, 5..16 rows with K % 64 != 0); fused=True never composes: an uncovered configuration raises."""
     M = x.numel() // K if K else 0
     if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
         raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
     if fused is None:
-        fused = decode_covers(x.dtype, M, N, K, group_size, nbits) if not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M) \
-            else skinny_covers(x.dtype, M, N, K, group_size, nbits)
+        fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
+            (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M))
     if fused:
         return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
     W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)

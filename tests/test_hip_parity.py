@@ -281,6 +281,41 @@ def test_skinny_gemm_vs_oracle(ops, oracle, nbits, M, NK):
     assert torch.count_nonzero(ye[1]) == 0
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+@pytest.mark.parametrize("M", [5, 16, 33, 64])
+@pytest.mark.parametrize("NK", [(512, 1024), (200, 2048 + 768), (64, 11008)])
+def test_skinny_gemm_bf16_vs_oracle(ops, oracle, nbits, M, NK):
+    """the batched-decode kernel in bf16: weights rounded to bf16 twice as the reference does on bf16 tensors (one-hot probe
+    bit-exact vs the dequant kernel), outputs within one bf16 ulp of the double-accumulated oracle"""
+    N, K = NK
+    gs = 64
+    assert ops.skinny_covers(torch.bfloat16, M, N, K, gs, nbits)
+    U, s, z = _random_layer(N, K, gs, nbits, seed=N + K + nbits + 3, dt=torch.bfloat16)
+    z.view(-1)[::5] = 0.00836                                  # zero-points far below one level: q - z must still round once
+    z.view(-1)[1::11] = 2.0 ** -12
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).bfloat16()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).bfloat16() if M % 2 else None
+    raw = lambda t: t.view(torch.int16).numpy().view(np.uint16)                     # noqa: E731  (oracle takes raw bf16 bits)
+    Wd = oracle.dequantize(nbits, P, raw(s), raw(z), N, K, gs, 2)
+    yo, _ = oracle.matmul(raw(x), Wd, None if bias is None else raw(bias), 2)
+    want = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+    args = (dev(P), s.cuda(), z.cuda(), None if bias is None else bias.cuda(), N, K, gs, nbits)
+    y = ops.forward(x.cuda(), *args)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, ops.gemv(x.cuda(), *args))
+    torch.testing.assert_close(y.float().cpu(), want, rtol=2.0 ** -7, atol=2e-3)
+    assert torch.equal(y[:5], ops.gemv(x[:5].cuda(), *args))
+    e = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    ks = [(3 * K) // 7, 0, K - 1]
+    for i, k in enumerate(ks): e[i, k] = 1.0
+    Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
+    ye = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)
+    for i, k in enumerate(ks):
+        assert torch.equal(ye[i], Wdev[:, k])
+        if nbits != 8:   # the row-per-wave kernel too (its bf16 variant covers 4/2-bit)
+            assert torch.equal(ops.gemv(e[i:i + 1], *args[:3], None, N, K, gs, nbits)[0], Wdev[:, k])
+
+
 def test_skinny_gemm_grouped_and_capture(ops):
     """grouped launch == single launches; the split-K scratch is never grown inside a stream capture"""
     K, gs, M, nbits = 1024, 64, 24, 4

@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   hipStream_t st; hipStreamCreate(&st);
   const int64_t Ns[1] = {N};
   auto call = [&](int i) { const void* w1[1] = {wq[i]}; const void* s1[1] = {sc[i]}; const void* z1[1] = {ze[i]}; void* y1[1] = {y};
-    int rc = skinny_run(4, 1, x, w1, s1, z1, nullptr, y1, Ns, M, K, st); if (rc) { printf("rc=%d %s\n", rc, hqq_hip_last_error()); exit(1); } };
+    int rc = skinny_run(4, 1, x, w1, s1, z1, nullptr, y1, Ns, M, K, HQQ_F16, st); if (rc) { printf("rc=%d %s\n", rc, hqq_hip_last_error()); exit(1); } };
 #ifdef SK_LAB_TS
   const int nw = 4096 * 8;
   hipMalloc(&g_sk_lab_ts, nw * 64); hipMemset(g_sk_lab_ts, 0, nw * 64);
