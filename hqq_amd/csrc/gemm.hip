@@ -476,7 +476,7 @@ int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale,
   if (M >= 1 && M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
   // a batch of 17..64 rows is still weight-streaming work: the skinny-GEMM kernel where it applies (same conditions as skinny_covers)
   if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
-      N % (8 / nbits) == 0 && N % 2 == 0)
+      N % (8 / nbits) == 0)
     return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
   return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
 }

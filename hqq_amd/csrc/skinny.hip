@@ -81,7 +81,8 @@ struct SkArgs {
   int panel_end[SK_MAXL];   // end (exclusive) of layer i's panels in the concatenated panel space (unused entries repeat the last)
   int n_off[SK_MAXL];       // first column of layer i in the concatenated output space of the scratch buffer
   const half_t* x;
-  float* part;              // [KS][16 MT][n_total] fp32 partial results (KS > 1 only)
+  float* part;              // [KS][panel][row group][PER][MT][4][64 lanes] fp32 partial tiles in accumulator order (KS > 1 only)
+  int* cnt;                 // [panel][row group] arrival counters of the K splits, zero between launches (KS > 1 only)
   int M, K, G, total_panels, KS, cps, n_total;
 #ifdef SK_LAB_TS
   unsigned long long* ts;   // lab only: per-wave timestamps
@@ -429,6 +430,44 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
           acc[s][t][0] += o[0]; acc[s][t][1] += o[1]; acc[s][t][2] += o[2]; acc[s][t][3] += o[3];
         }
   }
+  // ---- K splits: every split parks its tile in the scratch (accumulator order: a wave stores 256 consecutive bytes per
+  //      instruction), the LAST split of the row group to arrive — a ticket from an atomic counter, no waiting — adds all KS tiles
+  //      in split order and goes on to the store below.  Fixed order, so the bits do not depend on which split finished last;
+  //      no second launch (the finishing kernel this replaces cost one graph-node gap + ~1 us per call). ----
+  if (a.KS > 1) {
+    constexpr int TILE = PER * MT * 4 * 64;   // floats per (split, panel, row group)
+    const int64_t slot = static_cast<int64_t>(panel) * SK_RG + rg;
+    const int64_t kstride = static_cast<int64_t>(a.total_panels) * SK_RG * TILE;
+    float* mine = a.part + ks * kstride + slot * TILE + lane;
+#pragma unroll
+    for (int s = 0; s < PER; ++s)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __hip_atomic_store(mine + ((s * MT + t) * 4 + i) * 64, acc[s][t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Device-scope (sc1) stores and loads for the tiles, a wait for the stores' acknowledgement before the ticket: the tile is
+    // at the device's coherence point before the counter moves, and the finisher's loads go there too.  (A full __threadfence()
+    // on either side writes back / invalidates the whole L2 of the XCD: measured +17 us per launch.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != a.KS - 1) return;
+    const float* all = a.part + slot * TILE + lane;
+#pragma unroll
+    for (int s = 0; s < PER; ++s)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < a.KS; ++k) {
+#pragma unroll
+      for (int s = 0; s < PER; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[s][t][i] += __hip_atomic_load(all + k * kstride + ((s * MT + t) * 4 + i) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_store(a.cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order)
+  }
   // ---- D layout: lane (column r = activation row inside the m-tile, rows 4c + i = packed row inside the wave's 16) ----
   const int p_base = (panel - ly.panel0) * SK_ROWS + rg * 16 + c * 4;
 #pragma unroll
@@ -436,25 +475,20 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int m = t * 16 + r;
+      if (m >= M) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int pp = p_base + i;
         if (pp < rows_per_slab) {
           const int n = pp + s * rows_per_slab;
-          if (a.KS == 1) {
-            if (m < M) {
-              if constexpr (BF16) {
-                uint16_t o = f32_to_bf16(acc[s][t][i]);
-                if (ly.bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(ly.bias)[n]));
-                reinterpret_cast<uint16_t*>(ly.y)[static_cast<int64_t>(m) * ly.N + n] = o;
-              } else {
-                half_t o = static_cast<half_t>(acc[s][t][i]);
-                if (ly.bias) o = o + ly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-                ly.y[static_cast<int64_t>(m) * ly.N + n] = o;
-              }
-            }
+          if constexpr (BF16) {
+            uint16_t o = f32_to_bf16(acc[s][t][i]);
+            if (ly.bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(ly.bias)[n]));
+            reinterpret_cast<uint16_t*>(ly.y)[static_cast<int64_t>(m) * ly.N + n] = o;
           } else {
-            a.part[(static_cast<int64_t>(ks) * (16 * MT) + m) * a.n_total + ly.n_off + n] = acc[s][t][i];
+            half_t o = static_cast<half_t>(acc[s][t][i]);
+            if (ly.bias) o = o + ly.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+            ly.y[static_cast<int64_t>(m) * ly.N + n] = o;
           }
         }
       }
@@ -463,39 +497,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   SK_TS();
   if (lane == 0 && a.ts) { const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x) * SK_WAVES + wave; for (int q = 0; q < 8; ++q) a.ts[w * 8 + q] = t_[q]; }
 #endif
-}
-
-// adds the KS partial results in a fixed order, rounds to fp16, adds the bias, stores.  Grid (columns / 512, M): a thread owns two
-// neighbouring columns (every N is even on this path, so a pair never straddles two layers).
-template <bool BF16>
-__global__ __launch_bounds__(256) void skinny_finish_kernel(const SkArgs a, int mpad) {
-  const int ng = (blockIdx.x * 256 + threadIdx.x) * 2, m = blockIdx.y;
-  if (ng >= a.n_total) return;
-  int li = 0;
-#pragma unroll
-  for (int i = 1; i < SK_MAXL; ++i) li = (ng >= a.n_off[i] && a.n_off[i] > a.n_off[i - 1]) ? i : li;
-  const float* src = a.part + static_cast<int64_t>(m) * a.n_total + ng;
-  const int64_t kstride = static_cast<int64_t>(mpad) * a.n_total;
-  float v0 = 0.f, v1 = 0.f;
-  for (int k = 0; k < a.KS; ++k) {
-    const float2 t = *reinterpret_cast<const float2*>(src + k * kstride);
-    v0 += t.x;
-    v1 += t.y;
-  }
-  const int n = ng - a.n_off[li];
-  if constexpr (BF16) {
-    uint16_t o0 = f32_to_bf16(v0), o1 = f32_to_bf16(v1);
-    if (a.bias[li]) {
-      const uint16_t* b = reinterpret_cast<const uint16_t*>(a.bias[li]) + n;
-      o0 = f32_to_bf16(bf16_to_f32(o0) + bf16_to_f32(b[0]));
-      o1 = f32_to_bf16(bf16_to_f32(o1) + bf16_to_f32(b[1]));
-    }
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(a.y[li]) + static_cast<int64_t>(m) * a.N[li] + n) = static_cast<uint32_t>(o0) | (static_cast<uint32_t>(o1) << 16);
-  } else {
-    half2_t o = {static_cast<half_t>(v0), static_cast<half_t>(v1)};
-    if (a.bias[li]) o = o + *reinterpret_cast<const half2_t*>(a.bias[li] + n);
-    *reinterpret_cast<half2_t*>(a.y[li] + static_cast<int64_t>(m) * a.N[li] + n) = o;
-  }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -513,6 +514,7 @@ static int sk_num_cus() {
 // One buffer per device, not per stream: launches on different streams of a device must not overlap (documented in hqq_hip.h);
 // host-side state is not thread-safe (the reference drives the GPU from one Python thread).
 constexpr int SK_MAX_DEV = 16;
+constexpr size_t SK_CNT_BYTES = size_t(256) << 10;   // head of the scratch: one int per (panel, row group), 64 Ki counters
 static float* g_sk_part[SK_MAX_DEV] = {};
 static size_t g_sk_part_bytes[SK_MAX_DEV] = {};
 
@@ -529,6 +531,8 @@ static float* sk_scratch(size_t bytes, hipStream_t st) {
   const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
   float* pnew = nullptr;
   if (hipMalloc(&pnew, want) != hipSuccess) { (void)hipGetLastError(); set_error("hqq_hip_gemv: cannot allocate %zu bytes of split-K scratch", want); return nullptr; }
+  // the arrival counters at the head of the buffer must read zero before their first launch (every launch leaves them zero again)
+  if (hipMemset(pnew, 0, SK_CNT_BYTES) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pnew); set_error("hqq_hip_gemv: cannot clear the split-K counters"); return nullptr; }
   if (g_sk_part[dev]) {
     (void)hipDeviceSynchronize();   // earlier launches may still read the old buffer
     (void)hipFree(g_sk_part[dev]);
@@ -561,9 +565,12 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
 #endif
   a.part = nullptr;
   if (ks > 1) {
-    const size_t bytes = static_cast<size_t>(ks) * 16 * mt * a.n_total * sizeof(float);
-    a.part = sk_scratch(bytes, st);
-    if (!a.part) return HQQ_ERR_UNSUPPORTED;
+    if (static_cast<size_t>(a.total_panels) * SK_RG * sizeof(int) > SK_CNT_BYTES) { set_error("hqq_hip_gemv: too many row panels for the split-K counters"); return HQQ_ERR_UNSUPPORTED; }
+    const size_t bytes = SK_CNT_BYTES + static_cast<size_t>(ks) * a.total_panels * SK_ROWS * (8 / NBITS) * 16 * mt * sizeof(float);
+    float* buf = sk_scratch(bytes, st);
+    if (!buf) return HQQ_ERR_UNSUPPORTED;
+    a.cnt = reinterpret_cast<int*>(buf);
+    a.part = buf + SK_CNT_BYTES / sizeof(float);
   }
   const size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
@@ -586,13 +593,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
     default: set_error("hqq_hip_gemv: M=%d outside the skinny kernel's range", a.M); return HQQ_ERR_SHAPE;
   }
 #undef HQQ_SK_CASE
-  int rc = check_launch("hqq_hip_gemv");
-  if (rc) return rc;
-  if (ks > 1) {
-    hipLaunchKernelGGL(skinny_finish_kernel<BF16>, dim3(static_cast<unsigned>((a.n_total + 511) / 512), static_cast<unsigned>(a.M)), dim3(256), 0, st, a, 16 * mt);
-    rc = check_launch("hqq_hip_gemv");
-  }
-  return rc;
+  return check_launch("hqq_hip_gemv");
 }
 
 // shapes this kernel covers; everything else stays on the tile kernel of gemv_mfma.hip / the library composition
@@ -600,7 +601,7 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
   if ((nbits != 8 && nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
   const int per = 8 / nbits;
   for (int i = 0; i < n_layers; ++i)
-    if (N[i] % per != 0 || N[i] / per < 1 || N[i] % 2 != 0) return false;   // (the finish pass stores column pairs)
+    if (N[i] % per != 0 || N[i] / per < 1) return false;
   return true;
 }
 

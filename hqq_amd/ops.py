@@ -18,7 +18,7 @@ PER = {8: 1, 4: 2, 2: 4, 1: 8, 3: 10}
 # Quantizer.bit_to_packing (hqq/core/quantize.py:40-49): container width per nbits
 PACK_BITS = {8: 8, 6: 8, 5: 8, 4: 4, 3: 3, 2: 2, 1.58: 2, 1: 1}
 GEMV_MAX_M = 16
-SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512, even N
+SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512
 GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 
@@ -182,7 +182,7 @@ LIBRARY_GEMM_MIN_M = 17
 def skinny_covers(dtype, M, N, K, group_size, nbits) -> bool:
     """a batch of up to SKINNY_MAX_M rows that the weight-streaming skinny-GEMM kernel serves (csrc/skinny.hip: skinny_covers)"""
     return (dtype in (torch.float16, torch.bfloat16) and nbits in (8, 4, 2) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512
-            and N % (8 // nbits) == 0 and N % 2 == 0)
+            and N % (8 // nbits) == 0)
 
 
 def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:

@@ -80,13 +80,13 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * hqq_hip_forward picks one of the two by M.
  * Covered by hqq_hip_gemv: nbits in {8,4,2,1} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0, fp16,
  * M <= 16 (bf16: nbits 4/2, M <= 4; up to HQQ_GEMV_MAX_M_SKINNY = 64 rows for fp16 and bf16, nbits 8/4/2, group_size 64,
- * K % 256 == 0, K >= 512, even N: the weight-streaming skinny-GEMM kernel; its split-K scratch is one buffer per device — allocated by the first call of a
+ * K % 256 == 0, K >= 512: the weight-streaming skinny-GEMM kernel; its split-K scratch (partial tiles + arrival counters) is one buffer per device — allocated by the first call of a
  * shape, which must therefore happen outside stream capture, and shared by all streams: launches of 5..64 rows on DIFFERENT streams
  * of one device must not overlap); nbits 3 with group_size 64, fp16, M <= 4.  hqq_hip_gemm: nbits in {4,2}, fp16,
  * K % 64 == 0.  Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
-#define HQQ_GEMV_MAX_M_SKINNY 64   /* fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512, even N: the skinny-GEMM kernel */
+#define HQQ_GEMV_MAX_M_SKINNY 64   /* fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512: the skinny-GEMM kernel */
 #define HQQ_GEMV_MAX_GROUP 4
 int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);

@@ -252,11 +252,13 @@ def test_gemv_8bit_1bit_vs_oracle(ops, oracle, nbits, M):
 
 @pytest.mark.parametrize("nbits", [8, 4, 2])
 @pytest.mark.parametrize("M", [17, 32, 33, 64])
-@pytest.mark.parametrize("NK", [(512, 1024), (200, 2048 + 768), (64, 11008), (4096 + 8, 512)])
+@pytest.mark.parametrize("NK", [(512, 1024), (200, 2048 + 768), (64, 11008), (4096 + 8, 512), (333, 1024)])
 def test_skinny_gemm_vs_oracle(ops, oracle, nbits, M, NK):
-    """decode with a batch of 17..64 rows (skinny.hip: weights streamed once, split-K partials summed in a fixed order)"""
+    """decode with a batch of 17..64 rows (skinny.hip: weights streamed once, split-K partials summed in a fixed order by the
+    last split to arrive)"""
     N, K = NK
     gs = 64
+    if N % (8 // nbits): N += (8 // nbits) - N % (8 // nbits)   # (333: odd N for 8-bit, a ragged last panel for all)
     assert ops.skinny_covers(torch.float16, M, N, K, gs, nbits)
     U, s, z = _random_layer(N, K, gs, nbits, seed=N + K + nbits + 7)
     P = oracle.pack(nbits, U.numpy())
@@ -314,6 +316,24 @@ def test_skinny_gemm_bf16_vs_oracle(ops, oracle, nbits, M, NK):
         assert torch.equal(ye[i], Wdev[:, k])
         if nbits != 8:   # the row-per-wave kernel too (its bf16 variant covers 4/2-bit)
             assert torch.equal(ops.gemv(e[i:i + 1], *args[:3], None, N, K, gs, nbits)[0], Wdev[:, k])
+
+
+def test_skinny_split_k_reproducible_bits(ops):
+    """the K splits of a panel finish in any order; whichever arrives last adds the partial tiles in split order, so two hundred
+    launches of a heavily split layer (and of a grouped one) give the same bits, and the arrival counters are back at zero"""
+    K, gs, M, nbits = 4096, 64, 32, 4
+    layers = []
+    for i, N in enumerate([4096, 1024, 1024]):
+        U, s, z = _random_layer(N, K, gs, nbits, seed=900 + i)
+        layers.append((ops.pack(nbits, U.cuda()), s.cuda(), z.cuda(), None, N))
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).half().cuda()
+    first = [y.clone() for y in ops.gemv_grouped(x, layers, K, gs, nbits)]
+    single = ops.gemv(x, *layers[0][:4], 4096, K, gs, nbits).clone()
+    # (a grouped call may pick another K split than the single call: same sums in another association, one fp16 ulp apart at most)
+    torch.testing.assert_close(single.float(), first[0].float(), rtol=2.0 ** -10, atol=2e-3)
+    for _ in range(200):
+        for y, want in zip(ops.gemv_grouped(x, layers, K, gs, nbits), first): assert torch.equal(y, want)
+        assert torch.equal(ops.gemv(x, *layers[0][:4], 4096, K, gs, nbits), single)
 
 
 def test_skinny_gemm_grouped_and_capture(ops):
