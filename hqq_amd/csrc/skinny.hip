@@ -30,8 +30,9 @@
 //          The previous tile kernel (gemv_mfma.hip) re-read x from L2 in every wave: twice the weight bytes through the CU's
 //          address path, which held it at 1.0-1.8 TB/s.
 //   split-K  small layers do not have 256 panels: the grid is (8, panels / 8, KS), workgroup (panel, ks) walks the ks-th share of
-//          the chunks (<= 8) and writes its fp32 partial tile to a scratch buffer [KS][16 MT][sum N]; a second, tiny kernel adds
-//          the KS partials in a fixed order, rounds to fp16, adds the bias and stores.  KS depends on the layer shape only.
+//          the chunks (<= 16) and parks its fp32 partial tile in a scratch buffer; the last split of a row group to arrive
+//          (atomic ticket, nobody waits) adds the KS tiles in split order, rounds, adds the bias and stores: fixed order, no
+//          second launch.  KS depends on the shapes of the launch only, never on M.
 //          KS = 1 stores directly.  blockIdx.x is the XCD (workgroup b runs on XCD b % 8 — observed, a speed assumption only):
 //          the KS workgroups of a panel share the lines of zero / scale and the x chunks through one L2.
 // Round-1 status (MI355X, int4, graph replay over > 256 MiB of layers): 4096 x 4096: 11.6 us at M = 8, 15 at M = 32, 21 at M = 64
