@@ -556,6 +556,7 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
   if (a.total_panels >= 48) { const int lim = nchunks / 8 > 1 ? nchunks / 8 : 1; ks = ks > lim ? lim : ks; }
   ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
   ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
+  if (const char* e = getenv("HQQ_HIP_SKINNY_KS")) { const int v = atoi(e); if (v >= 1 && v <= nchunks) ks = v; }   // tuning knob (tools/sweep_ks.py)
   int cps = (nchunks + ks - 1) / ks;
   cps = cps > SK_MAX_CPS ? SK_MAX_CPS : cps;  // (long K: more splits than the occupancy rule asks for)
   ks = (nchunks + cps - 1) / cps;             // drop empty splits
