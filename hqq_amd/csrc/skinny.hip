@@ -241,9 +241,11 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #ifdef SK_LAB_TS
   unsigned long long t_[8] = {};
   int tsn = 0;
-#define SK_TS() do { if (tsn < 8) t_[tsn++] = __builtin_readcyclecounter(); } while (0)
+#define SK_TS() do { if (tsn < 8) t_[tsn++] = __builtin_amdgcn_s_memrealtime(); } while (0)   /* 100 MHz, one clock for the whole device */
+#define SK_TS_FLUSH() do { t_[7] = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && a.ts) { const int w_ = ((blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x) * SK_WAVES + (threadIdx.x >> 6); for (int q = 0; q < 8; ++q) a.ts[w_ * 8 + q] = t_[q]; } } while (0)
 #else
 #define SK_TS()
+#define SK_TS_FLUSH()
 #endif
   SK_TS();
   const int tid = threadIdx.x, lane = tid & 63;
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   int p = (panel - ly.panel0) * SK_ROWS + rg * 16 + r;         // packed row inside the layer
   p = p < rows_per_slab ? p : rows_per_slab - 1;               // ragged last panel: duplicate the last row (masked at the store)
   const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * K + c * 16;
+  SK_TS();   // 1: kernel arguments read, layer selected
 
   // x: the 256 threads fill the chunk's 8 MT fragments in LDS order — piece q = tid + 256 i is lane (q & 63) of fragment
   // f = q >> 6 = (m-tile t, block j, half h), i.e. the k-octet 64 j + 16 c + 8 h of activation row 16 t + r.  Rows >= M repeat
@@ -361,14 +364,14 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       const half_t* src = (hi ? ly.scale : ly.zero) + static_cast<int64_t>(pm + s * rows_per_slab) * G + (c0 + (cc < c1 - c0 ? cc : 0)) * SK_BLK;
       mv[rd][pass] = *reinterpret_cast<const u32x2*>(src);
     }
-  SK_TS();   // 1: group constants requested
+  SK_TS();   // 2: group constants requested
   xload(c0, 0);
   issue(un[0], c0);
   xload(c0 + 1, 1);
 #pragma unroll
   for (int k = 1; k < SK_RING; ++k) issue(un[k], c0 + k);
   __builtin_amdgcn_sched_barrier(0);
-  SK_TS();   // 2: x + both units requested
+  SK_TS();   // 3: x + both units requested
 #pragma unroll
   for (int rd = 0; rd < NROUND; ++rd)
 #pragma unroll
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         dst[6] = static_cast<uint16_t>(mv[rd][pass].y >> 16);
       }
     }
-  SK_TS();   // 3: group constants in LDS
+  SK_TS();   // 4: group constants in LDS
   xstore(0, 0);
   __syncthreads();
 
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       xstore((k + 1) & 1, (k + 1) & 1);   // x of chunk i + k + 1, requested one half-iteration ago
       __syncthreads();
-      SK_TS();   // 5, 6, 7: a half-iteration done
+      SK_TS();   // 5, 6: a half-iteration done
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         for (int t = 0; t < MT; ++t) red[((((hf - 1) * SK_RG + rg) * PER + s) * MT + t) * 64 + lane] = acc[s][t];
     }
     __syncthreads();
-    if (hf > 0) return;
+    if (hf > 0) { SK_TS_FLUSH(); return; }
 #pragma unroll
     for (int h = 1; h < SK_SPLIT; ++h)
 #pragma unroll
@@ -453,19 +456,34 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != a.KS - 1) return;
+    if (ticket != a.KS - 1) { SK_TS_FLUSH(); return; }
     const float* all = a.part + slot * TILE + lane;
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
       for (int t = 0; t < MT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < a.KS; ++k) {
+    // KB tiles per round trip (these loads go to the device's coherence point, ~0.6 us each way): all of a batch's loads are in
+    // flight before the first add.  One tile per trip made the finisher the last wave of the launch by 5 us (KS = 8).
+    constexpr int V = PER * MT * 4;
+    constexpr int KB = V >= 64 ? 1 : 64 / V;
+    for (int k0 = 0; k0 < a.KS; k0 += KB) {
+      float tmp[KB][V];
 #pragma unroll
-      for (int s = 0; s < PER; ++s)
+      for (int kk = 0; kk < KB; ++kk) {
+        const int kc = k0 + kk < a.KS ? k0 + kk : a.KS - 1;   // (past the last split: the last tile again, dropped below)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+        for (int v = 0; v < V; ++v) tmp[kk][v] = __hip_atomic_load(all + kc * kstride + v * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[s][t][i] += __hip_atomic_load(all + k * kstride + ((s * MT + t) * 4 + i) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int kk = 0; kk < KB; ++kk) {
+        const bool keep = k0 + kk < a.KS;
+#pragma unroll
+        for (int s = 0; s < PER; ++s)
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[s][t][i] += keep ? tmp[kk][(s * MT + t) * 4 + i] : 0.f;
+      }
     }
     if (lane == 0) __hip_atomic_store(a.cnt + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order)
   }
@@ -494,10 +512,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         }
       }
     }
-#ifdef SK_LAB_TS
-  SK_TS();
-  if (lane == 0 && a.ts) { const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x) * SK_WAVES + wave; for (int q = 0; q < 8; ++q) a.ts[w * 8 + q] = t_[q]; }
-#endif
+  SK_TS_FLUSH();   // (lab builds only)
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------

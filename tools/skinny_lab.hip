@@ -3,6 +3,7 @@
 unsigned long long* g_sk_lab_ts = nullptr;
 #include "../hqq_amd/csrc/skinny.hip"
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 using namespace hqq;
 int main(int argc, char** argv) {
@@ -33,8 +34,19 @@ int main(int argc, char** argv) {
   hipStreamSynchronize(st);
   std::vector<unsigned long long> h(nw * 8);
   hipMemcpy(h.data(), g_sk_lab_ts, nw * 64, hipMemcpyDeviceToHost);
-  printf("wave: stamps relative to its start: requested | prologue done | half ... | end\n");
-  for (int w = 0; w < nw; w += (w < 8 ? 1 : 331)) { if (!h[w * 8]) continue; printf("w%5d:", w); for (int i = 1; i < 8; ++i) printf(" %7lld", h[w * 8 + i] ? (long long)(h[w * 8 + i] - h[w * 8]) : -1LL); printf("\n"); }
+  // the LAST launch of the loop is what the buffer holds: stamps against the earliest wave start of that launch (one clock for all CUs)
+  unsigned long long t0 = ~0ull;
+  int live = 0;
+  for (int w = 0; w < nw; ++w) if (h[w * 8]) { t0 = h[w * 8] < t0 ? h[w * 8] : t0; ++live; }
+  printf("%d waves; time since the first wave start in units of 10 ns (s_memrealtime): min / median / max over the waves\n", live);
+  const char* names[8] = {"wave start", "arguments read", "group constants requested", "x + both units requested", "group constants in LDS", "half-iteration 1", "half-iteration 2", "wave end"};
+  for (int i = 0; i < 8; ++i) {
+    std::vector<unsigned long long> v;
+    for (int w = 0; w < nw; ++w) if (h[w * 8] && h[w * 8 + i]) v.push_back(h[w * 8 + i] - t0);
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end());
+    printf("  %-28s n=%5zu  %7llu %7llu %7llu\n", names[i], v.size(), v.front(), v[v.size() / 2], v.back());
+  }
   return 0;
 #endif
   for (int i = 0; i < pool; ++i) call(i);
