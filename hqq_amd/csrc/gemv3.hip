@@ -14,13 +14,16 @@
 // handed out so that those ten readers are neighbouring waves of ONE XCD (g3_row_of): HBM and the fabric see each packed byte
 // about once, L2->CU traffic is 10x the packed bytes.  That trades L2 bandwidth (plentiful) for a kernel with no atomics, no
 // cross-wave reduction and a deterministic summation order.  Round-1 status: 1.15 TB/s of packed bytes (14 % of 8 TB/s; 0.85
-// before the XCD-aware order) — ~10 instructions per weight, of which 4 are the exact dequantisation; next: one load feeding all
-// ten slabs (partial sums per (unit, slab) added in a fixed order by a finishing pass, as skinny.hip does for its K splits).
+// before the XCD-aware order) — ~10 instructions per weight, of which 4 are the exact dequantisation.  Launches of >= 19 MB go to
+// gemv3s.hip (one load feeding all ten slabs, partial sums added in a fixed order by a finishing pass); this kernel keeps the
+// small ones, where its ~4 us of fixed cost beats the other's ~10.
 //
 // Per wave instruction: 64 lanes x 16 B = four groups; lane (i = lane & 15, j = lane >> 4) holds words 4i..4i+3 of group
 // 4u + j.  Levels of a slab are pulled out two words at a time (v_lshrrev x2, v_perm, v_and_or onto the fp16 exponent
 // 0x6400), then rebuilt exactly as Quantizer.dequantize does (-1024, -zero, *scale: two fp16 roundings) and contracted on
 // the matrix core with the diagonal trick of gemv.hip (all lanes hold the same output row; D[i][i] are the partial sums).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "hqq_common.h"
@@ -284,6 +287,10 @@ static int g3_launch(const G3Args& a, hipStream_t st) {
   return check_launch("hqq_hip_gemv(3-bit)");
 }
 
+bool gemv3s_covers(int64_t M, int64_t K, int64_t group_size);   // gemv3s.hip: each packed word loaded once for all ten slabs
+int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st);
+
 // called by hqq_hip_gemv_grouped (gemv.hip) for nbits == 3 after the common argument checks
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st) {
@@ -319,6 +326,15 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
     }
     a.e_end[i] = static_cast<int>(ents);
     if (G > a.step[i]) { set_error("hqq_hip_gemv: 3-bit layer with fewer than 10 output rows per slab is not covered"); return HQQ_ERR_UNSUPPORTED; }
+  }
+  // Large launches go to the slab-sharing kernel (gemv3s.hip): 2.2 TB/s of packed bytes at the margin against 1.2 here, but ~10 us
+  // of fixed cost (a task is a 4 us chain of instructions in one wave, plus the finishing launch) against ~4 us — measured
+  // crossover on MI355X around 19 MB per launch (tools/sweep_int3.py).  HQQ_HIP_GEMV3_V1 / _V2 force one or the other (tests).
+  {
+    int64_t packed = 0;
+    for (int i = 0; i < n_layers; ++i) packed += static_cast<int64_t>(a.step[i]) * 256;
+    const bool want = getenv("HQQ_HIP_GEMV3_V2") || (packed >= (int64_t(19) << 20) && !getenv("HQQ_HIP_GEMV3_V1"));
+    if (want && gemv3s_covers(M, K, group_size)) return gemv3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, st);
   }
   for (int i = n_layers; i < G3_MAXL; ++i) {
     a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];

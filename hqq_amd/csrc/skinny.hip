@@ -558,6 +558,12 @@ static float* sk_scratch(size_t bytes, hipStream_t st) {
   return pnew;
 }
 
+// the same scratch for other kernels' partial sums (gemv3s.hip): behind the counters, which must stay zero
+float* gemv_scratch(size_t bytes, hipStream_t st) {
+  float* buf = sk_scratch(SK_CNT_BYTES + bytes, st);
+  return buf ? buf + SK_CNT_BYTES / sizeof(float) : nullptr;
+}
+
 template <int NBITS, bool BF16>
 static int sk_launch(SkArgs& a, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
