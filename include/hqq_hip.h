@@ -80,10 +80,13 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * hqq_hip_forward picks one of the two by M.
  * Covered by hqq_hip_gemv: nbits in {8,4,2,1} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0, fp16,
  * M <= 16 (bf16: nbits 4/2, M <= 4; up to HQQ_GEMV_MAX_M_SKINNY = 64 rows for fp16 and bf16, nbits 8/4/2, group_size 64,
- * K % 256 == 0, K >= 512: the weight-streaming skinny-GEMM kernel; its split-K scratch (partial tiles + arrival counters) is one buffer per device — allocated by the first call of a
- * shape, which must therefore happen outside stream capture, and shared by all streams: launches of 5..64 rows on DIFFERENT streams
- * of one device must not overlap); nbits 3 with group_size 64, fp16, M <= 4.  hqq_hip_gemm: nbits in {4,2}, fp16,
- * K % 64 == 0.  Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
+ * K % 256 == 0, K >= 512: the weight-streaming skinny-GEMM kernel); nbits 3 with group_size 64, fp16, M <= 4.
+ * Scratch: launches of 5..64 rows that split K, and 3-bit launches of >= 19 MB of packed weights, park fp32 partial sums in ONE
+ * buffer per device (partial tiles + arrival counters).  It is allocated / grown by the first call that needs more — which must
+ * therefore happen outside stream capture (a captured call that would have to grow it fails with HQQ_ERR_UNSUPPORTED) — and is
+ * shared by all streams: such launches on DIFFERENT streams of one device must not overlap.
+ * hqq_hip_gemm: nbits in {4,2}, fp16, K % 64 == 0.
+ * Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
 #define HQQ_GEMV_MAX_M_SKINNY 64   /* fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512: the skinny-GEMM kernel */
