@@ -48,7 +48,9 @@ def main():
                 for Ls in pool:
                     ops.gemv_grouped(x, [(W, s, z, None, N) for (W, s, z), (N, _) in zip(Ls, shapes)], K, 64, 3, outs=outs)
             os.environ.pop("HQQ_HIP_GEMV3_V1", None)
+            os.environ["HQQ_HIP_GEMV3_V2"] = "1"     # force each kernel in turn (the library picks by launch size otherwise)
             t2 = timed(sweep, pool_n)
+            os.environ.pop("HQQ_HIP_GEMV3_V2", None)
             os.environ["HQQ_HIP_GEMV3_V1"] = "1"
             t1 = timed(sweep, pool_n)
             os.environ.pop("HQQ_HIP_GEMV3_V1", None)
