@@ -304,8 +304,9 @@ def main():
         avg_launch_s = dev_sec_per_step / launches_per_step
         ach = (bytes_per_step_rank / launches_per_step) / avg_launch_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": _pmc_traffic(nbits),
-                           "kernel": f"hqq::gemv_f16_kernel<{nbits}, {M}, gs64, {mode_name}>", "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                           # PMC traffic is committed for the configuration it was measured on only (bs=1 fp16, exact mode)
+                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and mode_name == "exact") else None,
+                           "kernel": _decode_kernel_name(nbits, M, a.dtype, mode_name), "avg_launch_us": round(avg_launch_s * 1e6, 3),
                            "bytes_per_launch": bytes_per_step_rank // launches_per_step,
                            "note": "avg launch = HIP-event time of the timed region / launches (includes inter-kernel gaps)"}
     else:
@@ -325,6 +326,15 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _decode_kernel_name(nbits, M, dtype, mode_name):
+    """the kernel hqq_hip_gemv dispatches the bench's launches to (gemv.hip / skinny.hip / gemv3*.hip)"""
+    if nbits == 3:
+        return "hqq::gemv3s_kernel + gemv3s_finish_kernel (launches >= 19 MB) / hqq::gemv3_f16_kernel"
+    if M >= 5:
+        return f"hqq::skinny_f16_kernel<{nbits}, {(M + 15) // 16}, {'bf16' if dtype == 'bf16' else 'f16'}>"
+    return f"hqq::gemv_f16_kernel<{nbits}, {M}, gs64, {mode_name}, {'bf16' if dtype == 'bf16' else 'f16'}>"
 
 
 def _pmc_traffic(nbits):
