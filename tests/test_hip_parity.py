@@ -624,6 +624,33 @@ def test_forward_70b_shard_shapes_properties(ops):
         assert torch.equal(ops.forward(e, P, s, z, None, N, K, 64, 4)[0], Wd[:, K - 3])
 
 
+def test_forward_3bit_large_launches_properties(ops):
+    """3-bit launches of >= 19 MB take the slab-sharing kernel by default (8192 x 8192 alone; gate|up of the 7B block as one
+    grouped launch): agreement with the dequantise kernel, one-hot exactness, batch independence, grouped == single"""
+    def make(N, K, seed):
+        U, s, z = _random_layer(N, K, 64, 3, seed=seed)
+        P = ops.pack(3, U.cuda())
+        s, z = s.cuda(), z.cuda()
+        return P, s, z, ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, 3)
+    N, K = 8192, 8192
+    P, s, z, Wd = make(N, K, 1)
+    x = torch.randn(3, K, generator=torch.Generator().manual_seed(1)).half().cuda()
+    y = ops.forward(x, P, s, z, None, N, K, 64, 3)
+    torch.testing.assert_close(y.float(), x.float() @ Wd.float().t(), rtol=1e-3, atol=2e-3)
+    assert torch.equal(ops.forward(x[:1], P, s, z, None, N, K, 64, 3)[0], y[0])
+    e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, K - 3] = 1.0
+    assert torch.equal(ops.forward(e, P, s, z, None, N, K, 64, 3)[0], Wd[:, K - 3])
+    del P, s, z, Wd
+    N, K = 11008, 4096
+    A, B = make(N, K, 2), make(N, K, 3)
+    x = torch.randn(1, K, generator=torch.Generator().manual_seed(2)).half().cuda()
+    ya, yb = ops.gemv_grouped(x, [(A[0], A[1], A[2], None, N), (B[0], B[1], B[2], None, N)], K, 64, 3)
+    for (P, s, z, Wd), yg in ((A, ya), (B, yb)):
+        torch.testing.assert_close(yg.float(), x.float() @ Wd.float().t(), rtol=1e-3, atol=2e-3)
+        # alone this layer is 18 MB and takes the row-per-wave kernel: same exact weights, another summation order
+        torch.testing.assert_close(ops.gemv(x, P, s, z, None, N, K, 64, 3).float(), yg.float(), rtol=2.0 ** -10, atol=1e-3)
+
+
 def test_forward_unsupported_is_loud(ops):
     # 3-bit with a group size the fused kernel does not cover: reported, never silently computed elsewhere
     x = torch.zeros(1, 128, dtype=torch.float16, device="cuda")
