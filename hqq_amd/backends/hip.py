@@ -135,6 +135,11 @@ def group_projections(parent: nn.Module, names) -> bool:
         return False
     state = _GroupState()
     state.max_rows = 4 if (L0.nbits == 3 or L0.in_features % 64) else ops.GEMV_MAX_M   # (5..16 rows need K % 64 == 0)
+    if L0.nbits == 3:   # long K: fewer rows of x fit the kernel's LDS staging (70B down_proj: 2)
+        while state.max_rows and not all(ops.decode_covers(torch.float16, state.max_rows, L.out_features, L.in_features, 64, 3) for L in layers):
+            state.max_rows -= 1
+        if not state.max_rows:
+            return False
     if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits) for L in layers):
         state.max_rows = ops.SKINNY_MAX_M   # decode with a batch: still one weight-streaming launch for the group
     for i, (n, L) in enumerate(zip(names, layers)):

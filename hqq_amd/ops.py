@@ -189,8 +189,10 @@ def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:
     """what hqq_hip_gemv serves for M <= GEMV_MAX_M rows (include/hqq_hip.h); everything else is composed in `forward`"""
     if M > GEMV_MAX_M or not group_size or K % group_size:
         return False
-    if nbits == 3:
-        return dtype == torch.float16 and group_size == 64 and M <= 4
+    if nbits == 3:   # x (+ a 16-group tail) is staged in LDS: 144 KiB bound M * K; a row's groups must fit inside one slab
+        G = K // 64
+        return (dtype == torch.float16 and group_size == 64 and M <= 4 and M * (K + 1024) * 2 + 256 <= 144 * 1024
+                and (N * G + 9) // 10 >= G)
     if nbits not in (8, 4, 2, 1) or group_size % 16 or K % 16 or N % (8 // nbits):
         return False
     if dtype == torch.bfloat16:

@@ -651,6 +651,21 @@ def test_forward_3bit_large_launches_properties(ops):
         torch.testing.assert_close(ops.gemv(x, P, s, z, None, N, K, 64, 3).float(), yg.float(), rtol=2.0 ** -10, atol=1e-3)
 
 
+def test_forward_3bit_long_k_rows_beyond_the_lds_budget_compose(ops):
+    """the 3-bit decode kernels stage x in LDS: with K = 27648 (a 70B-sized down_proj shard) three rows no longer fit — `forward`
+    must compose (HIP dequantise + library GEMM) instead of raising; two rows stay fused"""
+    N, K = 40, 27648
+    U, s, z = _random_layer(N, K, 64, 3, seed=77)
+    P, s, z = ops.pack(3, U.cuda()), s.cuda(), z.cuda()
+    Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, 3)
+    assert ops.decode_covers(torch.float16, 2, N, K, 64, 3) and not ops.decode_covers(torch.float16, 3, N, K, 64, 3)
+    for M in (2, 3, 4):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().cuda()
+        torch.testing.assert_close(ops.forward(x, P, s, z, None, N, K, 64, 3).float(), x.float() @ Wd.float().t(), rtol=2e-3, atol=4e-3)
+    with pytest.raises(NotImplementedError):
+        ops.gemv(torch.zeros(3, K, dtype=torch.float16, device="cuda"), P, s, z, None, N, K, 64, 3)   # the kernel itself says so
+
+
 def test_forward_unsupported_is_loud(ops):
     # 3-bit with a group size the fused kernel does not cover: reported, never silently computed elsewhere
     x = torch.zeros(1, 128, dtype=torch.float16, device="cuda")
