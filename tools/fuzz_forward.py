@@ -24,11 +24,7 @@ def main():
         K = gs * rnd.randint(1, 40) if rnd.random() < 0.4 else 256 * rnd.randint(1, 24) if rnd.random() < 0.7 else 1024 * rnd.randint(8, 28)
         K = (K // gs) * gs or gs
         N = (per if nbits != 3 else 1) * (rnd.randint(1, 700) if K < 8192 else rnd.randint(1, 90))
-        if nbits == 3 and N * (K // 64) < 10 * (K // 64) * 1:
-            N = max(N, 16)
         M = rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100])
-        if nbits == 3 and (N * (K // gs) + 9) // 10 < K // gs:
-            continue
         g = torch.Generator().manual_seed(it)
         R = N * K // gs
         U = torch.randint(0, 2 ** nbits, (R, gs), generator=g, dtype=torch.uint8)
@@ -39,8 +35,9 @@ def main():
         b = torch.randn(N, generator=g).half().cuda() if rnd.random() < 0.4 else None
         try:
             y = ops.forward(x, P, s, z, b, N, K, gs, nbits)
-        except NotImplementedError as e:
-            print(f"[{it}] int{nbits} N={N} K={K} gs={gs} M={M}: unsupported ({str(e)[:70]})")
+        except NotImplementedError as e:   # forward() composes whatever the fused kernels do not cover: raising is a failure
+            bad += 1
+            print(f"[{it}] FAIL int{nbits} N={N} K={K} gs={gs} M={M}: raised ({str(e)[:90]})")
             continue
         Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, gs, nbits)
         ref = x.double() @ Wd.double().t()
