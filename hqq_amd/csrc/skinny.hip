@@ -548,7 +548,8 @@ static float* sk_scratch(size_t bytes, hipStream_t st) {
   float* pnew = nullptr;
   if (hipMalloc(&pnew, want) != hipSuccess) { (void)hipGetLastError(); set_error("hqq_hip_gemv: cannot allocate %zu bytes of split-K scratch", want); return nullptr; }
   // the arrival counters at the head of the buffer must read zero before their first launch (every launch leaves them zero again)
-  if (hipMemset(pnew, 0, SK_CNT_BYTES) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pnew); set_error("hqq_hip_gemv: cannot clear the split-K counters"); return nullptr; }
+  // (synchronised: the caller's stream may be a non-blocking one that does not order itself after the null stream's memset)
+  if (hipMemset(pnew, 0, SK_CNT_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pnew); set_error("hqq_hip_gemv: cannot clear the split-K counters"); return nullptr; }
   if (g_sk_part[dev]) {
     (void)hipDeviceSynchronize();   // earlier launches may still read the old buffer
     (void)hipFree(g_sk_part[dev]);
