@@ -268,7 +268,9 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   }
 }
 
-// y[m][n] = sum of row n's partials: ascending slab, ascending task — a fixed order
+// y[m][n] = sum of row n's partials: ascending slab, ascending task — a fixed order.  A row has G / 16 + 1 contributions per slab
+// (5 at K = 4096, 29 at K = 28672): they are fetched eight at a time, all loads of a batch in flight before the first add (one
+// load per loop iteration made this kernel five dependent memory round trips long: 4.9 us per call).
 template <int M>
 __global__ __launch_bounds__(256) void gemv3s_finish_kernel(const S3Args a) {
   const int l = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
@@ -279,14 +281,27 @@ __global__ __launch_bounds__(256) void gemv3s_finish_kernel(const S3Args a) {
   float sum[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) sum[m] = 0.f;
+  constexpr int B = 8;
   for (int t = r0 / step; t <= r1 / step; ++t) {
     const int ts = t * step;
     const int lo = (r0 > ts ? r0 : ts) - ts, hi = (r1 < ts + step - 1 ? r1 : ts + step - 1) - ts;
-    for (int j = lo / S3_ROWS; j <= hi / S3_ROWS; ++j) {
-      const int seg = n - (j * S3_ROWS + ts) / G;   // 0: the task's first output row of this slab, 1: its second
-      const float* p = a.part + ((static_cast<int64_t>(task0 + j) * 10 + t) * 2 + seg) * M;
+    const int jhi = hi / S3_ROWS;
+    for (int j0 = lo / S3_ROWS; j0 <= jhi; j0 += B) {
+      float v[B][M];
 #pragma unroll
-      for (int m = 0; m < M; ++m) sum[m] += p[m];
+      for (int u = 0; u < B; ++u) {
+        const int j = j0 + u <= jhi ? j0 + u : jhi;        // past the end: the last one again, dropped below
+        const int seg = (j * S3_ROWS + ts >= r0) ? 0 : 1;   // 0: row n is the task's first output row in this slab, 1: its second
+        const float* p = a.part + ((static_cast<int64_t>(task0 + j) * 10 + t) * 2 + seg) * M;
+#pragma unroll
+        for (int m = 0; m < M; ++m) v[u][m] = p[m];
+      }
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const bool keep = j0 + u <= jhi;
+#pragma unroll
+        for (int m = 0; m < M; ++m) sum[m] += keep ? v[u][m] : 0.f;
+      }
     }
   }
 #pragma unroll
