@@ -115,3 +115,26 @@ def test_custom_ops_registered_with_fake_kernels():
         y = torch.ops.hqq_hip.forward(x, Wq, s, s, None, 512, 512, 64, 4)
         W = torch.ops.hqq_hip.dequantize(Wq, s, s, 512, 512, 64, 4, 1)
     assert tuple(y.shape) == (2, 3, 512) and y.dtype == torch.float16 and tuple(W.shape) == (512, 512)
+
+
+def test_decode_coverage_predicates_mirror_the_header():
+    """what `forward` sends to the fused decode kernels (include/hqq_hip.h, coverage paragraph); everything else is composed"""
+    import torch
+    from hqq_amd import ops
+    f16, bf16 = torch.float16, torch.bfloat16
+    # row-per-wave / tile kernels: up to 16 rows in fp16, 5..16 need K % 64 == 0; bf16 up to 4 rows, 4-/2-bit
+    assert ops.decode_covers(f16, 1, 4096, 4096, 64, 4) and ops.decode_covers(f16, 16, 4096, 4096, 64, 4)
+    assert ops.decode_covers(f16, 4, 40, 176, 16, 4) and not ops.decode_covers(f16, 5, 40, 176, 16, 4)
+    assert not ops.decode_covers(f16, 17, 4096, 4096, 64, 4)
+    assert ops.decode_covers(bf16, 4, 4096, 4096, 64, 2) and not ops.decode_covers(bf16, 5, 4096, 4096, 64, 2)
+    assert not ops.decode_covers(bf16, 1, 4096, 4096, 64, 8)
+    # 3-bit: group_size 64, <= 4 rows, x (+ 16 groups) within 144 KiB of LDS, at least one output row's groups per slab
+    assert ops.decode_covers(f16, 4, 4096, 4096, 64, 3) and not ops.decode_covers(f16, 5, 4096, 4096, 64, 3)
+    assert ops.decode_covers(f16, 2, 8192, 28672, 64, 3) and not ops.decode_covers(f16, 3, 8192, 28672, 64, 3)
+    assert not ops.decode_covers(f16, 1, 8, 4096, 64, 3) and not ops.decode_covers(f16, 1, 4096, 4096, 128, 3)
+    # skinny GEMM: 5..64 rows, fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512 (odd N allowed)
+    assert ops.skinny_covers(f16, 5, 4096, 4096, 64, 4) and ops.skinny_covers(bf16, 64, 333, 1024, 64, 8)
+    assert not ops.skinny_covers(f16, 4, 4096, 4096, 64, 4) and not ops.skinny_covers(f16, 65, 4096, 4096, 64, 4)
+    assert not ops.skinny_covers(f16, 32, 4096, 4096 + 64, 64, 4) and not ops.skinny_covers(f16, 32, 4096, 256, 64, 4)
+    assert not ops.skinny_covers(f16, 32, 4096, 4096, 128, 4) and not ops.skinny_covers(f16, 32, 4096, 4096, 64, 3)
+    assert not ops.skinny_covers(f16, 32, 4095, 4096, 64, 4)      # N must be a multiple of the values per byte
