@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-codes", action="store_true", help="skip the solver: random packed codes + meta (faster setup)")
-    ap.add_argument("--gemv-mode", default="exact", choices=["exact", "factored"],
+    ap.add_argument("--gemv-mode", default="exact", choices=["exact", "factored", "sub"],
                     help="exact: reference-identical weights (default); factored: fp32 affine map factored out of the dot product")
     return ap.parse_args()
 
@@ -162,7 +162,7 @@ def main():
 
     from hqq_amd import ops
     assert ops.is_available(), "libhqq_hip.so must be built (python -c 'import __graft_entry__ as g; g.build()')"
-    ops.set_gemv_mode(ops.GEMV_FACTORED if a.gemv_mode == "factored" else ops.GEMV_EXACT)
+    ops.set_gemv_mode({"factored": ops.GEMV_FACTORED, "exact": ops.GEMV_EXACT, "sub": 2}[a.gemv_mode])
     nbits = a.nbits
     decode = a.workload == "decode"
     cd = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -256,7 +256,7 @@ def main():
             graph = None
             torch.cuda.synchronize()
     run = graph.replay if graph is not None else step
-    mode_name = {ops.GEMV_EXACT: "exact", ops.GEMV_FACTORED: "factored"}[ops.get_gemv_mode()]
+    mode_name = {ops.GEMV_EXACT: "exact", ops.GEMV_FACTORED: "factored", 2: "exact-sub"}[ops.get_gemv_mode()]
 
     for _ in range(a.warmup):
         run()

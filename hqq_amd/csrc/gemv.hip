@@ -40,7 +40,7 @@
 //           less than its own weight-rounding noise (<= 2^-10 * sum|x_k w_k|; tests state the tolerance).  ~20 % faster.
 #include <type_traits>
 
-#include "hqq_common.h"
+#include "decode_common.h"
 
 namespace hqq {
 
@@ -108,56 +108,6 @@ __device__ __forceinline__ LayerCtx select_layer(const GvArgs& a, int prow) {
   return c;
 }
 
-// sum over the 64 lanes, result valid in every lane: four DPP adds inside each row of 16, then the four row totals
-// through SGPRs.  No LDS traffic (a ds_bpermute butterfly costs ~100 cycles of latency per step).
-__device__ __forceinline__ float wave_sum(float v) {
-  auto dpp_add = [](float x, auto ctrl) {
-    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true);
-    return x + __builtin_bit_cast(float, y);
-  };
-  v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-  v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-  v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-  v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
-
-__device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
-
-// biased levels of slab S for the byte pairs (b0,b2) [word] / (b1,b3) [word >> 8] of one packed dword: the fp16 pair
-// (1024 + F q, 1024 + F q'), F = 2^shift(S) — the masked nibbles OR-ed onto the exponent 0x6400, one VALU op.
-template <int NBITS, int S>
-__device__ __forceinline__ half2_t biased_levels(uint32_t word_or_shifted, uint32_t magic /* 0x64006400 held in a VGPR */) {
-  constexpr int per = 8 / NBITS;
-  constexpr int sh = NBITS * (per - 1 - S);
-  constexpr uint32_t m1 = ((NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u)) << sh;
-  constexpr uint32_t m = m1 | (m1 << 16);
-  uint32_t b;
-  // hipcc emits v_and + v_or for (w & m) | magic (GFX9 VOP3 takes no literals); the mask rides in an SGPR here
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(word_or_shifted), "s"(m), "v"(magic));
-  return as_h2(b);
-}
-template <int NBITS, int S> struct SlabF {   // F and 1/F of slab S
-  static constexpr int sh = NBITS * (8 / NBITS - 1 - S);
-  static constexpr float F = static_cast<float>(1 << sh);
-  static constexpr float invF = 1.0f / static_cast<float>(1 << sh);
-};
-
-// x staging order: a lane's chunk of 16 k-values is kept as two 16-byte planes (conflict-free ds_read_b128);
-// inside a plane the 8 halfs are (k0,k2,k1,k3,k4,k6,k5,k7) so that half2 j pairs with the levels<> of byte pair j.
-__device__ __forceinline__ u32x4 permute_x8(u32x4 v) {
-  u32x4 r;
-  r.x = (v.x & 0xFFFFu) | (v.y << 16);
-  r.y = (v.x >> 16) | (v.y & 0xFFFF0000u);
-  r.z = (v.z & 0xFFFFu) | (v.w << 16);
-  r.w = (v.z >> 16) | (v.w & 0xFFFF0000u);
-  return r;
-}
-
 // one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
 template <int NBITS, int M, int S, int PER>
 struct SlabLoop {
@@ -181,49 +131,6 @@ struct SlabLoop {
     for (int m = 0; m < M; ++m)
       acc[m][S] = __builtin_fmaf(c1[S], __builtin_fmaf(-c2[S], xsum[m], dot[m][0] + dot[m][1]), acc[m][S]);
     if constexpr (S + 1 < PER) SlabLoop<NBITS, M, S + 1, PER>::run(w, c1, c2, xr, xsum, acc, magic);
-  }
-};
-
-// EXACT mode: the lane's 16 weights of slab S are rebuilt exactly as Quantizer.dequantize does (two fp16 roundings, 4 packed
-// ops per pair) and contracted on the matrix core.  With all 64 lanes holding the SAME output row, lane l = (i = l & 15,
-// o = l >> 4) supplies row i / k-octet o of the A operand and column i / k-octet o of the B operand (its own 8 x-values):
-// D[i][i] is then the partial dot product of the four lanes {i + 16 o}, and the row's result is the sum of the diagonal.
-// 15/16 of the MFMA's flops are discarded — the matrix pipe is idle otherwise — but no VALU slot is spent on the dot
-// product, which keeps the kernel under the VALU ceiling (see gemv_mfma.hip for the rates).
-typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-template <int NBITS, int M, int S, int PER>
-struct SlabExact {
-  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const h8_t (&b0)[M], const h8_t (&b1)[M],
-                                             f32x4 (&acc)[M][PER], uint32_t magic) {
-    constexpr int sh = NBITS * (PER - 1 - S);
-    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
-    const half2_t k1 = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
-    const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
-    const half2_t pr = as_h2(zs[S]);
-    const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
-    // stage-wise over the eight weight pairs (not pair by pair): eight independent chains keep the packed-fp16 pipe busy
-    // instead of stalling on each fma -> add -> mul dependency
-    half2_t q[8];
-    uint32_t o[8];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      q[2 * d] = biased_levels<NBITS, S>(w[d], magic);            // bytes (4d+0, 4d+2)
-      q[2 * d + 1] = biased_levels<NBITS, S>(w[d] >> 8, magic);   // bytes (4d+1, 4d+3)
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], k1, k2);   // exact integer level
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = q[i] - zz;                                  // rounding 1
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = __builtin_bit_cast(uint32_t, q[i] * ss);    // rounding 2
-    const h8_t a0 = __builtin_bit_cast(h8_t, u32x4{o[0], o[1], o[2], o[3]});
-    const h8_t a1 = __builtin_bit_cast(h8_t, u32x4{o[4], o[5], o[6], o[7]});
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[m], acc[m][S], 0, 0, 0);
-      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[m], acc[m][S], 0, 0, 0);
-    }
-    if constexpr (S + 1 < PER) SlabExact<NBITS, M, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
   }
 };
 
@@ -293,9 +200,10 @@ struct Unit {
   uint16_t sc[GS64 ? PER : GV_U * PER];
 };
 
-template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false>
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a) {
   static_assert(EXACT || !BF16, "bf16 is served by the exact-weights path only");
+  static_assert(!SUB || (EXACT && !BF16), "the subnormal-field sequence is an fp16 exact-weights variant");
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
@@ -434,10 +342,12 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
 #pragma unroll
         for (int s = 0; s < PER; ++s) {
           if constexpr (GS64) {
-            const uint32_t mine = static_cast<uint32_t>(cur.z[s]) | (static_cast<uint32_t>(cur.sc[s]) << 16);
+            uint32_t mine = static_cast<uint32_t>(cur.z[s]) | (static_cast<uint32_t>(cur.sc[s]) << 16);
+            if constexpr (SUB) mine = scale_meta_sub<NBITS>(mine, s);
             zs[s] = __builtin_amdgcn_ds_bpermute((u * 16 + (lane >> 2)) << 2, mine);
           } else {
             zs[s] = static_cast<uint32_t>(cur.z[u * PER + s]) | (static_cast<uint32_t>(cur.sc[u * PER + s]) << 16);
+            if constexpr (SUB) zs[s] = scale_meta_sub<NBITS>(zs[s], s);
           }
         }
         if (step < nsteps) {
@@ -450,7 +360,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
             b1[m] = __builtin_bit_cast(frag_t, xs[m * planes_per_m + (step * 2 + 1) * 64 + lane]);
           }
           if constexpr (BF16) SlabExactBF16<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
-          else SlabExact<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
+          else SlabExact<NBITS, M, 0, PER, SUB>::run(cur.w[u], zs, b0, b1, acc, magic);
         }
       }
     } else {
@@ -586,7 +496,7 @@ static int num_cus() {
   return g_num_cus;
 }
 
-template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false>
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false>
 static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   constexpr int PER = 8 / NBITS;
   GvArgs a = args;
@@ -595,7 +505,7 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   const size_t xs_bytes = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
   a.red_off = static_cast<int>((xs_bytes + 15) & ~static_cast<size_t>(15));
   const size_t lds = a.red_off + sizeof(float) * GV_WAVES * M * PER;                  // + K-split reduction buffer
-  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16>;
+  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16, SUB>;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
   per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   {
@@ -635,13 +545,13 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   return check_launch("hqq_hip_gemv");
 }
 
-template <int NBITS, bool GS64, bool EXACT>
+template <int NBITS, bool GS64, bool EXACT, bool SUB = false>
 static int dispatch_m(int M, const GvArgs& a, hipStream_t st) {
   switch (M) {
-    case 1: return launch_gemv_f16<NBITS, 1, GS64, EXACT>(a, st);
-    case 2: return launch_gemv_f16<NBITS, 2, GS64, EXACT>(a, st);
-    case 3: return launch_gemv_f16<NBITS, 3, GS64, EXACT>(a, st);
-    case 4: return launch_gemv_f16<NBITS, 4, GS64, EXACT>(a, st);
+    case 1: return launch_gemv_f16<NBITS, 1, GS64, EXACT, false, SUB>(a, st);
+    case 2: return launch_gemv_f16<NBITS, 2, GS64, EXACT, false, SUB>(a, st);
+    case 3: return launch_gemv_f16<NBITS, 3, GS64, EXACT, false, SUB>(a, st);
+    case 4: return launch_gemv_f16<NBITS, 4, GS64, EXACT, false, SUB>(a, st);
   }
   if constexpr (!EXACT) {
     switch (M) {
@@ -666,14 +576,14 @@ static int dispatch_bf16(int nbits, int M, const GvArgs& a, hipStream_t st) {
   return HQQ_ERR_UNSUPPORTED;
 }
 
-template <bool EXACT>
+template <bool EXACT, bool SUB = false>
 static int dispatch(int nbits, int M, const GvArgs& a, hipStream_t st) {
   const bool gs64 = a.gs == 64;
   switch (nbits) {
-    case 8: return dispatch_m<8, false, EXACT>(M, a, st);
-    case 4: return gs64 ? dispatch_m<4, true, EXACT>(M, a, st) : dispatch_m<4, false, EXACT>(M, a, st);
-    case 2: return gs64 ? dispatch_m<2, true, EXACT>(M, a, st) : dispatch_m<2, false, EXACT>(M, a, st);
-    case 1: return dispatch_m<1, false, EXACT>(M, a, st);
+    case 8: return dispatch_m<8, false, EXACT, SUB>(M, a, st);
+    case 4: return gs64 ? dispatch_m<4, true, EXACT, SUB>(M, a, st) : dispatch_m<4, false, EXACT, SUB>(M, a, st);
+    case 2: return gs64 ? dispatch_m<2, true, EXACT, SUB>(M, a, st) : dispatch_m<2, false, EXACT, SUB>(M, a, st);
+    case 1: return dispatch_m<1, false, EXACT, SUB>(M, a, st);
   }
   return HQQ_ERR_NBITS;
 }
@@ -731,7 +641,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   const int per = 8 / nbits;
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
-  const bool exact = g_gemv_mode == HQQ_GEMV_EXACT || dtype == HQQ_BF16;
+  const bool exact = g_gemv_mode != HQQ_GEMV_FACTORED || dtype == HQQ_BF16;
   if (n_layers > 1 && !skinny_ok && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (exact ? M > GV_EXACT_ROWWISE_MAX_M : M > 8)) {
     // a group in which only some layers meet the skinny kernel's conditions: launch the layers one by one, so that a layer is
     // served by the same kernel (same summation order, same bits) whether or not it was grouped
@@ -798,14 +708,14 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
     GvArgs b = a;
     b.x = static_cast<const half_t*>(x) + m0 * K;
     for (int i = 0; i < GV_MAXL; ++i) b.y[i] = a.y[i] + m0 * a.N[i];
-    const int rc = dtype == HQQ_BF16 ? dispatch_bf16(nbits, mm, b, st) : exact ? dispatch<true>(nbits, mm, b, st) : dispatch<false>(nbits, mm, b, st);
+    const int rc = dtype == HQQ_BF16 ? dispatch_bf16(nbits, mm, b, st) : exact ? (g_gemv_mode == 2 ? dispatch<true, true>(nbits, mm, b, st) : dispatch<true>(nbits, mm, b, st)) : dispatch<false>(nbits, mm, b, st);
     if (rc) return rc;
   }
   return 0;
 }
 
 extern "C" int hqq_hip_set_gemv_mode(int mode) {
-  if (mode != HQQ_GEMV_EXACT && mode != HQQ_GEMV_FACTORED) { set_error("hqq_hip_set_gemv_mode: unknown mode %d", mode); return HQQ_ERR_SHAPE; }
+  if (mode != HQQ_GEMV_EXACT && mode != HQQ_GEMV_FACTORED && mode != 2) { set_error("hqq_hip_set_gemv_mode: unknown mode %d", mode); return HQQ_ERR_SHAPE; }
   g_gemv_mode = mode;
   return 0;
 }
