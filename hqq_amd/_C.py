@@ -30,6 +30,10 @@ SYMBOLS = {
     "hqq_hip_get_gemv_mode": (_i32, []),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "hqq_hip_decode_plan_bytes": (_sz, [_i32]),
+    "hqq_hip_decode_plan_init": (_i32, [_vp, _sz, _i32, _i64, _i32, _i64, ctypes.c_uint32, _vp, _i32, _i32]),
+    "hqq_hip_decode_run": (_i32, [_vp, _vp, _sz, _vp]),
+    "hqq_hip_decode_plan_status_offset": (_sz, [_vp]),
     "hqq_hip_quantize_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "hqq_hip_quantize": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -166,6 +166,73 @@ def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=No
     return [o.reshape(*x.shape[:-1], L[4]) for o, L in zip(outs, layers)]
 
 
+OPT_META_SCALABLE = 2
+
+
+class _StageDesc(__import__("ctypes").Structure):
+    """hqq_hip_decode_stage (include/hqq_hip.h)"""
+    import ctypes as _ct
+    _fields_ = [("x", _ct.c_void_p), ("K", _ct.c_int64), ("n_layers", _ct.c_int32), ("reserved", _ct.c_int32),
+                ("Wq", _ct.c_void_p * GEMV_MAX_GROUP), ("scale", _ct.c_void_p * GEMV_MAX_GROUP), ("zero", _ct.c_void_p * GEMV_MAX_GROUP),
+                ("bias", _ct.c_void_p * GEMV_MAX_GROUP), ("y", _ct.c_void_p * GEMV_MAX_GROUP), ("N", _ct.c_int64 * GEMV_MAX_GROUP)]
+
+
+class DecodePlan:
+    """One launch for a whole list of dependent decode stages (csrc/engine.hip; include/hqq_hip.h "persistent decode engine").
+
+    stages: sequence of (x [1, K], layers) with layers = sequence of (W_q, scale, zero, bias_or_None, N, y [1, N]); stage s + 1 may
+    read an output buffer of stage s.  All tensors stay owned by the caller (this object keeps references)."""
+
+    def __init__(self, stages, nbits: int, group_size: int = 64, opts: int = 0, grid: int = 0):
+        import ctypes
+        L = _C.lib()
+        n = len(stages)
+        if n < 1:
+            raise ValueError("hqq_amd: a decode plan needs at least one stage")
+        descs = (_StageDesc * n)()
+        self._keep = []
+        dev = None
+        for i, (x, layers) in enumerate(stages):
+            if not 1 <= len(layers) <= GEMV_MAX_GROUP:
+                raise ValueError(f"hqq_amd: a stage holds 1..{GEMV_MAX_GROUP} layers, got {len(layers)}")
+            K = x.shape[-1]
+            if x.numel() != K or not x.is_contiguous():
+                raise ValueError("hqq_amd: the decode engine takes one dense activation row per stage")
+            _dev(x)
+            dev = x.device if dev is None else dev
+            d = descs[i]
+            d.x, d.K, d.n_layers = x.data_ptr(), K, len(layers)
+            for j, (W_q, s, z, b, N, y) in enumerate(layers):
+                _dev(W_q, s, z, b, y)
+                if x.dtype != s.dtype or z.dtype != s.dtype or y.dtype != s.dtype or (b is not None and b.dtype != s.dtype):
+                    raise TypeError("hqq_amd: x / scale / zero / bias / y must share the compute dtype")
+                if y.numel() != N or not y.is_contiguous():
+                    raise ValueError("hqq_amd: y must be a dense [1, N] buffer")
+                d.Wq[j], d.scale[j], d.zero[j], d.bias[j], d.y[j], d.N[j] = _p(W_q), _p(s), _p(z), _p(b), _p(y), int(N)
+                self._keep += [W_q, s, z, b, y]
+            self._keep.append(x)
+        self.device = dev
+        self.nbytes = int(L.hqq_hip_decode_plan_bytes(n))
+        self._host = ctypes.create_string_buffer(self.nbytes)
+        rc = L.hqq_hip_decode_plan_init(ctypes.addressof(self._host), self.nbytes, int(nbits), int(group_size), _dt(stages[0][0].dtype), 1, int(opts),
+                                        ctypes.addressof(descs), n, int(grid))
+        _C.check(rc, "hqq_hip_decode_plan_init")
+        self._dev = torch.frombuffer(bytearray(self._host.raw), dtype=torch.uint8).to(dev)
+        assert self._dev.data_ptr() % 256 == 0
+        self._status_off = int(L.hqq_hip_decode_plan_status_offset(ctypes.addressof(self._host)))
+        self.n_stages = n
+
+    def run(self) -> None:
+        import ctypes
+        with torch.cuda.device(self.device):
+            rc = _C.lib().hqq_hip_decode_run(ctypes.addressof(self._host), self._dev.data_ptr(), self.nbytes, _stream())
+        _C.check(rc, "hqq_hip_decode_run")
+
+    def status(self) -> int:
+        """0 after a run in which every inter-workgroup hand-off completed (synchronises)"""
+        return int(self._dev[self._status_off:self._status_off + 4].view(torch.int32).item())
+
+
 def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
     """fused unpack->dequant->MFMA GEMM (prefill)."""
     return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)

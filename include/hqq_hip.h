@@ -109,6 +109,41 @@ int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* con
 enum { HQQ_GEMV_EXACT = 0, HQQ_GEMV_FACTORED = 1 };
 int hqq_hip_set_gemv_mode(int mode);
 int hqq_hip_get_gemv_mode(void);
+/* ---------------------------------------------------------------------------------------------
+ * The persistent decode engine: one launch walks a whole list of DEPENDENT stages, one activation row (bs = 1).
+ * A stage is what one hqq_hip_gemv_grouped call computes — up to HQQ_GEMV_MAX_GROUP layers reading the same x[1,K] — and stage
+ * s + 1 may read what stage s wrote: the engine publishes a stage's outputs device-wide before any workgroup reads the next x,
+ * while the packed weights of the following stages are already streaming.  It replaces the per-layer launch sequence of a decode
+ * step (the loop around HQQLinear.forward in hqq/utils/generation_hf.py:117-540; forward itself: quantize.py:880-898).
+ * Covered: nbits in {8,4,2}, group_size 64, fp16, M = 1, N % (8/nbits) == 0, K % 64 == 0.
+ *
+ * The plan is a caller-owned blob of hqq_hip_decode_plan_bytes(n_stages) bytes: hqq_hip_decode_plan_init fills a HOST buffer
+ * (descriptors of every stage + launch geometry for the current device); the caller copies it once to a 256-byte aligned
+ * DEVICE buffer of the same size and passes both to hqq_hip_decode_run, which enqueues a clear of the plan's sync words and
+ * the engine launch on `stream` (capturable).  The library keeps no pointer.  The word at
+ * hqq_hip_decode_plan_status_offset() of the device buffer is 0 after a run in which every hand-off completed (else 1 + the
+ * stage whose wait gave up: the outputs are then undefined).  One run of a given device plan at a time.
+ * ------------------------------------------------------------------------------------------- */
+#define HQQ_OPT_META_SCALABLE 2u   /* every layer passed hqq_hip_meta_check: the three-op exact weight rebuild may be used */
+typedef struct hqq_hip_decode_stage {
+  const void* x;            /* [1, K] activations of this stage (may be an output buffer of an earlier stage) */
+  int64_t K;
+  int32_t n_layers;         /* 1..HQQ_GEMV_MAX_GROUP */
+  int32_t reserved;
+  const void* Wq[HQQ_GEMV_MAX_GROUP];
+  const void* scale[HQQ_GEMV_MAX_GROUP];
+  const void* zero[HQQ_GEMV_MAX_GROUP];
+  const void* bias[HQQ_GEMV_MAX_GROUP];   /* entries may be NULL */
+  void* y[HQQ_GEMV_MAX_GROUP];            /* [1, N[i]] */
+  int64_t N[HQQ_GEMV_MAX_GROUP];
+} hqq_hip_decode_stage;
+size_t hqq_hip_decode_plan_bytes(int n_stages);
+/* grid: workgroups to launch, 0 = one per compute unit of the current device (anything larger would not be co-resident) */
+int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int nbits, int64_t group_size, int dtype, int64_t M, uint32_t opts,
+                             const hqq_hip_decode_stage* stages, int n_stages, int grid);
+int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t plan_bytes, void* stream);
+size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
+
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
