@@ -12,7 +12,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhqq_hip.so")
+LIB_PATH = os.environ.get("HQQ_AMD_LIB") or os.path.join(_HERE, "lib", "libhqq_hip.so")   # the override serves lab builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/hqq_hip.h declares, with its ctypes signature

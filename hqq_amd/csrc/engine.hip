@@ -137,16 +137,18 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
   // ---- after the workgroup's streaming waves have left their partials: 16 lanes per output, partials added in wave order ----
   auto reduce_stage = [&](const EnGeo& g) {
     const int nout = g.nrows * PER;
-    const int j = tid & 15;
+    const int j = tid & 15;                       // lane j of a row of 16 lanes adds what streaming wave j left for the output
+    const int fr = tab[j], lr = tab[16 + j];      // (j = 15: the control wave's slots hold an empty range)
     for (int o = tid >> 4; o < nout; o += EN_WAVES * 4) {
       const int rl = o / PER, slab = o - rl * PER;
       float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < EN_NSW; ++w) {
-        const int fr = tab[w], lr = tab[16 + w];
-        if (rl >= fr && rl <= lr) sum += part[((w * maxf + (rl - fr)) * PER + slab) * 16 + j];
+      if (rl >= fr && rl <= lr) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(part + ((j * maxf + (rl - fr)) * PER + slab) * 16);
+        const f32x4 v0 = p4[0], v1 = p4[1], v2 = p4[2], v3 = p4[3];
+        sum = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+        sum += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v3[0] + v3[1]) + (v3[2] + v3[3]));
       }
-      sum = row16_sum(sum);
+      sum = row16_sum(sum);                       // fixed tree over the waves: reproducible
       if (j == 0) ybuf[o] = __builtin_bit_cast(uint16_t, static_cast<half_t>(sum));
     }
   };
@@ -157,16 +159,17 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       // x[K] -> LDS in the order the weight rebuild produces values; reads past K return 0 (buffer bounds)
       const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(st->x), 0, st->K * 2, 0x00020000);
       const int nsteps = st->spr;
-      for (int s0 = 0; s0 < nsteps; s0 += 4) {
-        u32x4 v[4][2];
+      constexpr int XB = 6;   // steps per batch: 12 loads of 16 bytes in flight per lane
+      for (int s0 = 0; s0 < nsteps; s0 += XB) {
+        u32x4 v[XB][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < XB; ++u) {
           const int off = ((s0 + u) * 64 + lane) * 32;
           v[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 16 /* sc1 */);
           v[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16, 0, 16);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < XB; ++u)
           if (s0 + u < nsteps) {
             xs[((s0 + u) * 2 + 0) * 64 + lane] = permute_x8(v[u][0]);
             xs[((s0 + u) * 2 + 1) * 64 + lane] = permute_x8(v[u][1]);
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
 #else
 #define EN_TS(s, i)
 #endif
+    if (lane == 0) { tab[EN_NSW] = 1; tab[16 + EN_NSW] = 0; }   // reduce_stage: "wave 15" contributes to no row
     stage_x(stages);
     lds_barrier();   // B0
     for (int s = 0; s < n_stages; ++s) {
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       ++is;
     }
   };
-  auto dma16 = [&](const uint8_t EN_GLOBAL* g, uint32_t lds) {
+  auto dma16 = [&](const uint8_t EN_GLOBAL* sbase, uint32_t voff, uint32_t lds) {   // wave-uniform base + 32-bit lane offset
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
   };
   auto dma4 = [&](const uint8_t EN_GLOBAL* g, uint32_t lds) {
     uint32_t keep;
@@ -309,19 +313,23 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
   };
   // exactly two vector-memory operations per call, whatever the cursor state: the consumer's wait is s_waitcnt vmcnt(2 (D - 1))
   auto issue = [&](int slot) {
-    int k0 = ikstep * EN_STEP + lane_k;
-    k0 = (ilive && k0 < iK) ? k0 : 0;      // lanes past K re-read the row start: their x is zero in LDS
-    int g0 = ikstep * 16 + 2 * m_i;
-    g0 = (ilive && g0 < iG) ? g0 : 0;      // G is even: a pair of groups is inside the row or outside it
     const uint32_t dst = ring_base + static_cast<uint32_t>(slot) * EN_SLOT;
-    dma4(imeta + g0 * 2, dst + EN_STEP);
-    dma16(iwrow + k0, dst);
-    // advance (past the last stage the cursor stays where it is: the slots it keeps "refilling" are never consumed)
-    if (ilive) {
-      ++it;
-      if (it == it_end) { ++is; iss_stage(); }
-      else if (++ikstep == ispr) { ikstep = 0; ++irow; iss_row(); }
+    if (!ilive) {   // past the last stage: slots that will never be consumed re-read the start of a valid row
+      dma4(imeta, dst + EN_STEP);
+      dma16(iwrow, static_cast<uint32_t>(lane_k), dst);
+      return;
     }
+    uint32_t koff = static_cast<uint32_t>(ikstep * EN_STEP + lane_k);
+    uint32_t goff = static_cast<uint32_t>(ikstep * 32 + 4 * m_i);   // bytes: group pair (2 i, 2 i + 1) of the step
+    if (ikstep == ispr - 1 && (iK & (EN_STEP - 1))) {   // the row's last, partial step: lanes past K re-read the row start (their x is zero in LDS)
+      koff = static_cast<int>(koff) < iK ? koff : 0u;
+      goff = static_cast<int>(goff) < iG * 2 ? goff : 0u;   // G is even: a pair of groups is inside the row or outside it
+    }
+    dma4(imeta + goff, dst + EN_STEP);
+    dma16(iwrow, koff, dst);
+    ++it;
+    if (it == it_end) { ++is; iss_stage(); }
+    else if (++ikstep == ispr) { ikstep = 0; ++irow; iss_row(); }
   };
 
   // ---- consume cursor ----
@@ -396,6 +404,12 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
   cons_stage();
   lds_barrier();   // B0
 
+#ifdef EN_LAB_TS
+  unsigned long long* wts = (a.ts && (wave == 0 || wave == EN_NSW - 1)) ? a.ts + static_cast<size_t>(c) * n_stages * 8 : nullptr;
+#define EN_WTS(s, i) if (wts && lane == 0) wts[(s) * 8 + (i) + (wave == 0 ? 0 : 1)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define EN_WTS(s, i)
+#endif
   int slot = 0;   // ring position of the next step to consume
   for (;;) {
     while (ct < ct_end) {
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
     }
     // ---- end of this wave's part of stage cs ----
     if (cany && ckstep != 0) flush();   // a row this wave shares with the next one
+    EN_WTS(cs, 5)
     lds_barrier();   // B1
     reduce_stage(cg);
     lds_barrier();   // B1'
