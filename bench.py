@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — the contract benchmark of the HQQ forward hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload decode|prefill] [--nbits 4|2|3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|decode|decode70b|prefill] [--nbits 4|2|3] [--bs M]
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Headline (N = 1; BASELINE.json configs[1], the configuration the metric is quoted on):
   one *step* = one token (bs=1) through every quantised linear of a Llama-2-7B decoder stack —
   32 blocks x {q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008}, nbits=4 group_size=64 axis=1,
-  224 fused unpack->dequantize->GEMV launches streaming 3.65 GB of packed weights + meta from HBM
-  (far beyond the 256 MiB Infinity Cache, so every step is HBM traffic).  Weights are synthetic
-  N(0, 0.02^2) fp16 tensors quantised on the GPU by the HIP half-quadratic solver before timing.
-  `--workload prefill` runs configs[2] instead: M tokens (default 8192 = 4 x 2048) through one block's
-  seven linears on the MFMA dequant-GEMM.
+  128 dependent fused unpack->dequantize->GEMV launches (q|k|v, o, gate|up, down grouped) replayed from one
+  hipGraph, streaming 3.65 GB of packed weights + meta from HBM (far beyond the 256 MiB Infinity Cache, so
+  every step is HBM traffic).  Weights are synthetic N(0, 0.02^2) fp16 tensors quantised on the GPU by the
+  HIP half-quadratic solver before timing.  Arithmetic: exact weights (round16(round16(q - z) * s), the
+  reference's), in the three-op form wherever hqq_hip_meta_check allows it.
+  `legs` adds the other shapes the metric names (bs=32; one 4096x4096 layer at bs=1 / bs=32) and the persistent
+  engine (csrc/engine.hip) on the same stack; `cpu_baseline` times the reference's per-call arithmetic
+  (unpack -> (W_r - zero) * scale -> matmul, hqq/core/bitpack.py:31-38, quantize.py:183-199, :880-882) restated
+  in torch eager on the host cores of this box.
+  `--workload prefill` runs configs[2]: M tokens (default 8192 = 4 x 2048) through one block's seven linears.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): output-column shard.  Rank r
-owns output rows [r*N, (r+1)*N) of an N*P-row layer (weak scaling: the per-GPU shard is exactly the
-N=1 workload), x is replicated, and every exchange point (after q/k/v, o, gate/up, down) is one RCCL
-all-gather of the fp16 shard outputs over xGMI.  `value` is the whole-job rate over all ranks.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL).  Default for N > 1 (`auto`) is BASELINE
+configs[4]: the Llama-2-70B linear shapes (q,o 8192x8192; k,v 1024x8192; gate,up 28672x8192; down 8192x28672),
+nbits=4, every layer's output columns sharded over the N ranks (packed-row blocks of the reference layout,
+hqq_amd/shard.py) — STRONG scaling of fixed layers: x is replicated, every exchange point (after q|k|v, o,
+gate|up, down) is one RCCL all-gather of the fp16 shard outputs over xGMI followed by the un-permute to the
+reference's column order, both inside the timed region; the all-gathers are also timed on their own.
+`--workload decode --gpus N` keeps round 1's weak-scaling variant (every rank streams a 7B-stack-sized shard).
 
-Prints ONE JSON line on rank 0.  `value` = algorithmic GB/s streamed by the whole job (SURVEY.md §8d
-bytes: W_q + scale + zero + x + y); tok/s is reported next to it.
+Prints ONE JSON line on rank 0.  `value` = algorithmic GB/s streamed by the whole job (SURVEY.md §8d bytes:
+W_q + scale + zero + x + y); tok/s is reported next to it.
 """
 from __future__ import annotations
 
@@ -39,9 +47,11 @@ MFMA_PEAK_TFLOPS = 2500.0  # fp16/bf16 dense
 
 LLAMA2_7B_BLOCK = [("q", 4096, 4096), ("k", 4096, 4096), ("v", 4096, 4096), ("o", 4096, 4096),
                    ("gate", 11008, 4096), ("up", 11008, 4096), ("down", 4096, 11008)]
+LLAMA2_70B_BLOCK = [("q", 8192, 8192), ("k", 1024, 8192), ("v", 1024, 8192), ("o", 8192, 8192),
+                    ("gate", 28672, 8192), ("up", 28672, 8192), ("down", 8192, 28672)]
 # exchange points of a column-sharded block: outputs that are consumed together are gathered together
 EXCHANGE_GROUPS = [("q", "k", "v"), ("o",), ("gate", "up"), ("down",)]
-N_BLOCKS = 32
+N_BLOCKS_7B, N_BLOCKS_70B = 32, 80
 
 
 def wq_bytes(N, K, nbits, gs=64):
@@ -61,28 +71,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="decode", choices=["decode", "prefill"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "decode", "decode70b", "prefill"],
+                    help="auto: the 7B stack on one GPU, the column-sharded 70B stack (configs[4]) on several")
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--bs", type=int, default=1, help="decode batch (rows of x), 1..64 (int4/int2/int8 from 5 up, fp16 or bf16; 1..4 for int3)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="compute dtype (bf16: decode only)")
     ap.add_argument("--prefill-tokens", type=int, default=8192)
-    ap.add_argument("--blocks", type=int, default=N_BLOCKS)
+    ap.add_argument("--blocks", type=int, default=0, help="decoder blocks (default: 32 for the 7B stack, 80 for the 70B one)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
     ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
+    ap.add_argument("--engine", action="store_true", help="headline through the persistent decode engine (one launch per token) instead of 128 launches")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (bs=32, single layer, engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-codes", action="store_true", help="skip the solver: random packed codes + meta (faster setup)")
-    ap.add_argument("--gemv-mode", default="exact", choices=["exact", "factored", "sub"],
-                    help="exact: reference-identical weights (default); factored: fp32 affine map factored out of the dot product")
+    ap.add_argument("--gemv-mode", default="exact", choices=["exact", "exact4", "factored"],
+                    help="exact: reference-identical weights, three-op rebuild where the meta allows it (default); exact4: always the "
+                         "general four-op rebuild; factored: fp32 affine map factored out of the dot product (not the reference's weights)")
     return ap.parse_args()
 
 
 class Layer:
-    __slots__ = ("name", "N", "K", "Wq", "scale", "zero")
+    __slots__ = ("name", "N", "K", "Wq", "scale", "zero", "opts")
 
 
-def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16):
+def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16, rows=None):
+    """one synthetic quantised layer; rows = (first, count) keeps only that packed-row block of it (a column shard, hqq_amd/shard.py)"""
     L = Layer()
     L.name, L.N, L.K = name, N, K
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -95,46 +110,144 @@ def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16
             L.Wq = torch.randint(0, 256, (prow, 64), dtype=torch.uint8, device=dev, generator=g)
         L.scale = (torch.rand(R, 1, device=dev, generator=g) * 0.004 + 0.001).to(cd)
         L.zero = (torch.rand(R, 1, device=dev, generator=g) * (2 ** nbits - 1)).to(cd)
-        return L
-    W = (torch.randn(N, K, device=dev, generator=g) * 0.02).half()
-    Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4))
-    # HQQLinear.cuda(): meta is cast to compute_dtype (quantize.py:515-583)
-    L.Wq, L.scale, L.zero = Wq, s.to(cd), z.to(cd)
+    else:
+        W = (torch.randn(N, K, device=dev, generator=g) * 0.02).half()
+        Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4))
+        # HQQLinear.cuda(): meta is cast to compute_dtype (quantize.py:515-583)
+        L.Wq, L.scale, L.zero = Wq, s.to(cd), z.to(cd)
+    L.opts = ops.OPT_META_SCALABLE if (cd == torch.float16 and nbits in (8, 4, 2) and ops.meta_scalable(L.scale, L.zero, N, K, 64, nbits)) else 0
     return L
 
 
-def cpu_baseline(nbits):
-    """The oracle's dequantize+matmul (the per-call work of HQQBackend.PYTORCH) on this box's host cores, bounded to ~10 s."""
-    import numpy as np
-    from oracle import hqq_oracle as orc
-    N = K = 4096
-    rng = np.random.default_rng(0)
-    R = N * K // 64
-    U = rng.integers(0, 2 ** nbits, size=(R, 64), dtype=np.uint8)
-    P = orc.pack(nbits, U)
-    s = orc.to_cd((rng.random((R, 1), dtype=np.float32) * 0.004 + 0.001), orc.F16)
-    z = orc.to_cd((rng.random((R, 1), dtype=np.float32) * (2 ** nbits - 1)), orc.F16)
-    x = orc.to_cd(rng.standard_normal((1, K), dtype=np.float32), orc.F16)
-    orc.forward(nbits, P, s, z, None, x, N, K, 64, orc.F16)   # warm-up
+def _timed(run, steps, warmup, dist=None, dev=None):
+    """K timed steps bracketed by barrier + synchronize; returns (wall s/step, HIP-event s/step), MAX over ranks"""
+    for _ in range(warmup):
+        run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    reps = 0
-    while True:
-        orc.forward(nbits, P, s, z, None, x, N, K, 64, orc.F16)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 200:
-            break
-    t = el / reps
+    ev0.record()
+    for _ in range(steps):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev_elapsed = ev0.elapsed_time(ev1) * 1e-3
+    if dist is not None:
+        t = torch.tensor([elapsed, ev_elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_elapsed = float(t[0]), float(t[1])
+    return elapsed / steps, ev_elapsed / steps
+
+
+def _graphed(step, use_graph, rank=0):
+    """run `step` once eagerly on a side stream (lazy loads, workspace growth, communicator set-up), then capture it"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if not use_graph:
+        return step, False
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            step()
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph.replay, True
+    except Exception as e:   # capture unsupported for some op: run eagerly, say so
+        if rank == 0:
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return step, False
+
+
+def cpu_baseline(nbits):
+    """HQQBackend.PYTORCH's per-call arithmetic on this box's host cores, bounded to ~10 s each:
+    (1) restated in torch eager with the reference's own ops — BitPack.unpack (bitpack.py:31-38 / :53-64 / :14-22), Quantizer.dequantize
+        ((W_r - zero) * scale, quantize.py:183-199), torch.matmul(x, W.t()) (quantize.py:880-882), fp16, all host threads;
+    (2) the C oracle (oracle/hqq_oracle.c, OpenMP, double accumulation) as a second figure."""
+    import numpy as np
+    N = K = 4096
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     nb = gemv_bytes(N, K, nbits)
-    return {"value": round(nb / t / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
-            "tok_s_7b_stack_equiv": round(1.0 / (t * (sum(gemv_bytes(n, k, nbits) for _, n, k in LLAMA2_7B_BLOCK) * N_BLOCKS / nb)), 4),
-            "ms_per_layer_call": round(t * 1e3, 3),
-            "sample": f"oracle/hqq_oracle.c forward (unpack+dequantize+matmul, OpenMP) of one 4096x4096 int{nbits} gs=64 layer, bs=1, "
-                      f"{reps} calls in {el:.1f} s"}
+    stack_calls = sum(gemv_bytes(n, k, nbits) for _, n, k in LLAMA2_7B_BLOCK) * N_BLOCKS_7B / nb
+    out = {"unit": "GB/s", "cores": cores, "kind": "port"}
+    # ---- (1) torch eager ----
+    if nbits in (8, 4, 2):
+        torch.set_num_threads(cores)
+        g = torch.Generator().manual_seed(0)
+        per = 8 // nbits
+        R = N * K // 64
+        Wq = torch.randint(0, 256, (R // per, 64), dtype=torch.uint8, generator=g)
+        scale = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).half()
+        zero = (torch.rand(R, 1, generator=g) * (2 ** nbits - 1)).half()
+        x = torch.randn(1, K, generator=g).half()
+        mask = (1 << nbits) - 1
+
+        def fwd():
+            step = Wq.shape[0]
+            tmp = torch.empty([per * step, 64], dtype=torch.float16)
+            for s in range(per):
+                tmp[s * step:(s + 1) * step] = (Wq >> (nbits * (per - 1 - s))) & mask
+            W = ((tmp - zero) * scale).reshape(N, K)
+            return torch.matmul(x, W.t())
+
+        with torch.no_grad():
+            fwd()
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                fwd()
+                reps += 1
+                el = time.perf_counter() - t0
+                if el > 10.0 or reps >= 500:
+                    break
+        t = el / reps
+        out.update({"value": round(nb / t / 1e9, 4), "ms_per_layer_call": round(t * 1e3, 3),
+                    "tok_s_7b_stack_equiv": round(1.0 / (t * stack_calls), 4),
+                    "sample": f"torch {torch.__version__} CPU eager restatement of HQQBackend.PYTORCH's forward (unpack -> (W_r - zero) * scale -> matmul, fp16, "
+                              f"torch.set_num_threads({cores})) on one 4096x4096 int{nbits} gs=64 layer, bs=1: {reps} calls in {el:.1f} s"})
+    # ---- (2) C oracle ----
+    try:
+        from oracle import hqq_oracle as orc
+        rng = np.random.default_rng(0)
+        R = N * K // 64
+        U = rng.integers(0, 2 ** nbits, size=(R, 64), dtype=np.uint8)
+        P = orc.pack(nbits, U)
+        s = orc.to_cd((rng.random((R, 1), dtype=np.float32) * 0.004 + 0.001), orc.F16)
+        z = orc.to_cd((rng.random((R, 1), dtype=np.float32) * (2 ** nbits - 1)), orc.F16)
+        xo = orc.to_cd(rng.standard_normal((1, K), dtype=np.float32), orc.F16)
+        orc.forward(nbits, P, s, z, None, xo, N, K, 64, orc.F16)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            orc.forward(nbits, P, s, z, None, xo, N, K, 64, orc.F16)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 6.0 or reps >= 200:
+                break
+        t = el / reps
+        c = {"value": round(nb / t / 1e9, 4), "ms_per_layer_call": round(t * 1e3, 3),
+             "sample": f"oracle/hqq_oracle.c forward (unpack+dequantize+matmul, OpenMP, double accumulation), same layer: {reps} calls in {el:.1f} s"}
+        if "value" in out:
+            out["c_port"] = c
+        else:
+            out.update(c)
+            out["tok_s_7b_stack_equiv"] = round(1.0 / (t * stack_calls), 4)
+    except Exception as e:   # the oracle is optional here (it is the checker, not the product)
+        out["c_port"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -162,46 +275,91 @@ def main():
 
     from hqq_amd import ops
     assert ops.is_available(), "libhqq_hip.so must be built (python -c 'import __graft_entry__ as g; g.build()')"
-    ops.set_gemv_mode({"factored": ops.GEMV_FACTORED, "exact": ops.GEMV_EXACT, "sub": 2}[a.gemv_mode])
     nbits = a.nbits
-    decode = a.workload == "decode"
+    workload = a.workload
+    if workload == "auto":
+        workload = "decode" if world == 1 else "decode70b"
+    decode = workload in ("decode", "decode70b")
+    big = workload == "decode70b"
     cd = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     assert a.dtype == "f16" or (decode and (a.bs >= 5 or nbits in (4, 2))), "bf16: decode only; bs <= 4 needs int4 / int2 (bs 5..64: int8/4/2)"
     M = a.bs if decode else a.prefill_tokens
-    nblocks = a.blocks if decode else 1
+    BLOCK = LLAMA2_70B_BLOCK if big else LLAMA2_7B_BLOCK
+    nblocks = (a.blocks or (N_BLOCKS_70B if big else N_BLOCKS_7B)) if decode else 1
+    strong = big and world > 1
+    if strong:
+        per = 1 if nbits == 3 else 8 // nbits
+        for _, N, _ in BLOCK:
+            assert N % (per * world) == 0, f"column shard: N={N} must divide by {per} * {world} (hqq_amd/shard.py)"
 
     # ---- the resident stack: every layer distinct in HBM ----
     t_setup = time.perf_counter()
     blocks = []
     for b in range(nblocks):
         blk = {}
-        for i, (name, N, K) in enumerate(LLAMA2_7B_BLOCK):
-            blk[name] = make_layer(ops, name, N, K, nbits, dev, seed=1000 * rank + 16 * b + i, random_codes=a.random_codes, cd=cd)
+        for i, (name, N, K) in enumerate(BLOCK):
+            # strong scaling: rank r holds N / P output columns of the layer (as a layer of its own: the shard of a packed-row
+            # block of the reference layout is exactly the reference layout of a layer with N / P rows — hqq_amd/shard.py —
+            # so a synthetic shard is quantised directly; tests/test_shard.py proves the slicing against whole layers)
+            n_loc = N // world if strong else N
+            blk[name] = make_layer(ops, name, n_loc, K, nbits, dev, seed=(1000 * rank if not strong else 7919 * rank) + 16 * b + i,
+                                   random_codes=a.random_codes, cd=cd)
         blocks.append(blk)
     gx = torch.Generator(device=dev).manual_seed(1)       # x is replicated: same seed on every rank
-    xs = {K: torch.randn(M, K, device=dev, generator=gx).to(cd) for K in (4096, 11008)}
-    # per exchange group: local outputs [len(group), M, N] and, for P > 1, the gathered [P, len(group), M, N]
-    out_local, out_full = {}, {}
-    for grp in EXCHANGE_GROUPS:
-        N = dict((n, nn) for n, nn, _ in LLAMA2_7B_BLOCK)[grp[0]]
-        out_local[grp] = torch.empty(len(grp), M, N, device=dev, dtype=cd)
-        if world > 1:
-            out_full[grp] = torch.empty(world * len(grp) * M, N, device=dev, dtype=cd)   # rank-major concatenation
+    xs = {K: torch.randn(M, K, device=dev, generator=gx).to(cd) for K in sorted({K for _, _, K in BLOCK})}
+    dimN = {n: blocks[0][n].N for n, _, _ in BLOCK}
+    # per exchange group: local outputs [len(group)][M, N_loc] and, for P > 1, the gathered + un-permuted [M, N] per layer
+    out_local = {grp: [torch.empty(M, dimN[n], device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+    out_flat, out_gath, out_full = {}, {}, {}
+    if world > 1:
+        for grp in EXCHANGE_GROUPS:
+            tot = sum(dimN[n] for n in grp)
+            out_flat[grp] = torch.empty(M * tot, device=dev, dtype=cd)            # this rank's outputs of the group, back to back
+            out_gath[grp] = torch.empty(world * M * tot, device=dev, dtype=cd)    # rank-major concatenation
+            out_full[grp] = [torch.empty(M, world * dimN[n], device=dev, dtype=cd) for n in grp]
+            off = 0
+            views = []
+            for n in grp:   # the kernels write straight into the flat send buffer
+                views.append(out_flat[grp][off:off + M * dimN[n]].view(M, dimN[n]))
+                off += M * dimN[n]
+            out_local[grp] = views
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
     grouped = decode and not a.no_group and nbits in (4, 3, 2, 8, 1)
+    base_opts = ops.OPT_FACTORED if a.gemv_mode == "factored" else 0
+
+    def group_opts(Ls):
+        if a.gemv_mode != "exact":
+            return base_opts
+        return ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0
+
+    per_slab = 1 if nbits == 3 else 8 // nbits
+
+    def exchange(grp):
+        """all-gather the group's shard outputs, then restore the reference's column order: rank r's packed-row block holds,
+        per slab s, output columns s * N/per + [r * n', (r + 1) * n'), n' = N / (per * P)  (hqq_amd/shard.py)"""
+        dist.all_gather_into_tensor(out_gath[grp], out_flat[grp])
+        tot = sum(dimN[n] for n in grp)
+        g = out_gath[grp].view(world, M * tot)
+        off = 0
+        for j, n in enumerate(grp):
+            nl = dimN[n]
+            src = g[:, off:off + M * nl].view(world, M, per_slab, nl // per_slab)          # [P, M, per, n']
+            out_full[grp][j].view(M, per_slab, world, nl // per_slab).copy_(src.permute(1, 2, 0, 3))
+            off += M * nl
 
     # --streams S > 1 (study mode, not the headline): the step's launches are dealt over S parallel graph branches, i.e. the
-    # dependency chain q|k|v -> o -> gate|up -> down of a real decoder is NOT modelled and consecutive launches may overlap;
-    # it shows what the kernels sustain once launch boundaries are hidden.  Outputs then need one buffer per launch in flight.
+    # dependency chain q|k|v -> o -> gate|up -> down of a real decoder is NOT modelled and consecutive launches may overlap.
     S = max(1, a.streams)
     branch_streams = [torch.cuda.Stream() for _ in range(S - 1)] if S > 1 else []
     if S > 1:
-        out_local_s = [{g: torch.empty_like(t) for g, t in out_local.items()} for _ in range(S)]
+        out_local_s = [{g: [torch.empty_like(t) for t in ts] for g, ts in out_local.items()} for _ in range(S)]
 
-    def step():
-        if S > 1:
+    def step(bs_x=None, outs_by_grp=None, only_exchange=False):
+        X = xs if bs_x is None else bs_x
+        OL = out_local if outs_by_grp is None else outs_by_grp
+        if S > 1 and bs_x is None:
             main = torch.cuda.current_stream()
             for st in branch_streams:
                 st.wait_stream(main)
@@ -211,104 +369,92 @@ def main():
                     b = i % S
                     i += 1
                     with torch.cuda.stream(main if b == 0 else branch_streams[b - 1]):
-                        ol = out_local_s[b][grp]
                         Ls = [blk[name] for name in grp]
-                        ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
-                                         outs=[ol[j] for j in range(len(grp))])
+                        ops.gemv_grouped(X[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
+                                         outs=out_local_s[b][grp], opts=group_opts(Ls))
             for st in branch_streams:
                 main.wait_stream(st)
             return
         for blk in blocks:
             for grp in EXCHANGE_GROUPS:
-                ol = out_local[grp]
-                if grouped:   # q/k/v and gate/up read the same x: one launch per exchange group
-                    Ls = [blk[name] for name in grp]
-                    ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
-                                     outs=[ol[j] for j in range(len(grp))])
-                else:
-                    for j, name in enumerate(grp):
-                        L = blk[name]
-                        ops.forward(xs[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=ol[j], fused=(not a.library_gemm))
-                if world > 1:
-                    dist.all_gather_into_tensor(out_full[grp], ol.view(len(grp) * M, -1))
+                Ls = [blk[name] for name in grp]
+                if not only_exchange:
+                    if grouped:   # q/k/v and gate/up read the same x: one launch per exchange group
+                        ops.gemv_grouped(X[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
+                                         outs=OL[grp], opts=group_opts(Ls))
+                    else:
+                        for j, L in enumerate(Ls):
+                            ops.forward(X[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=OL[grp][j], fused=(not a.library_gemm),
+                                        opts=group_opts([L]))
+                if world > 1 and bs_x is None:
+                    exchange(grp)
 
-    # ---- graph capture (launch-bound inner loop -> one hipGraph replay per step) ----
-    # hipGraph capture of the whole step (incl. the RCCL all-gathers for N > 1; torch captures NCCL collectives).  Backends
-    # that stage through the host (gloo debug mode) cannot be captured: launch eagerly there.
+    # ---- the persistent engine on the same stack (one launch per token) ----
+    def make_plan():
+        stages = []
+        for blk in blocks:
+            for grp in EXCHANGE_GROUPS:
+                Ls = [blk[name] for name in grp]
+                stages.append((xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N, out_local[grp][j]) for j, L in enumerate(Ls)]))
+        allsc = all(L.opts & ops.OPT_META_SCALABLE for blk in blocks for L in blk.values())
+        return ops.DecodePlan(stages, nbits, opts=(ops.OPT_META_SCALABLE if (allsc and a.gemv_mode == "exact") else 0))
+
     use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0" and (world == 1 or dist.get_backend() == "nccl")
-    graph = None
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        step()          # eager once: communicator set-up, lazy module loads
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:   # capture unsupported for some op: run eagerly, say so
-            if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
-    mode_name = {ops.GEMV_EXACT: "exact", ops.GEMV_FACTORED: "factored", 2: "exact-sub"}[ops.get_gemv_mode()]
+    engine = a.engine and decode and world == 1 and M == 1 and a.dtype == "f16" and nbits in (8, 4, 2) and a.gemv_mode != "factored"
+    plan = make_plan() if engine else None
+    run, graphed = _graphed(plan.run if engine else step, use_graph, rank)
+    mode_name = {"exact": "exact", "exact4": "exact (four-op rebuild forced)", "factored": "factored"}[a.gemv_mode]
 
-    for _ in range(a.warmup):
-        run()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
-        run()
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev_elapsed = ev0.elapsed_time(ev1) * 1e-3
-    if dist is not None:
-        t = torch.tensor([elapsed, ev_elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ev_elapsed = float(t[0]), float(t[1])
+    sec_per_step, dev_sec_per_step = _timed(run, a.steps, a.warmup, dist, dev)
+    if engine:
+        assert plan.status() == 0, f"decode engine: a hand-off timed out (status {plan.status()})"
 
     # ---- accounting ----
-    launches_per_step = nblocks * (len(EXCHANGE_GROUPS) if grouped else len(LLAMA2_7B_BLOCK))
-    bytes_per_step_rank = nblocks * sum(gemv_bytes(N, K, nbits, M) for _, N, K in LLAMA2_7B_BLOCK)
-    flops_per_step_rank = nblocks * sum(2.0 * M * N * K for _, N, K in LLAMA2_7B_BLOCK)
-    sec_per_step = elapsed / a.steps
-    dev_sec_per_step = ev_elapsed / a.steps
+    launches_per_step = 1 if engine else nblocks * (len(EXCHANGE_GROUPS) if grouped else len(BLOCK))
+    stages_per_step = nblocks * len(EXCHANGE_GROUPS)
+    bytes_per_step_rank = nblocks * sum(gemv_bytes(dimN[n], K, nbits, M) for n, _, K in BLOCK)
+    flops_per_step_rank = nblocks * sum(2.0 * M * dimN[n] * K for n, _, K in BLOCK)
     out = {
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(sec_per_step * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
     }
+    model = "llama2-70b" if big else "llama2-7b"
     if decode:
         gbs = world * bytes_per_step_rank / sec_per_step / 1e9
+        n_scal = sum(1 for blk in blocks for L in blk.values() if L.opts & ops.OPT_META_SCALABLE)
         out.update({
-            "metric": f"int{nbits} gs=64 dequant-GEMV decode throughput, Llama-2-7B linear stack bs={M} (algorithmic GB/s; tok/s alongside)",
+            "metric": f"int{nbits} gs=64 dequant-GEMV decode throughput, {model} linear stack bs={M} (algorithmic GB/s; tok/s alongside)",
             "value": round(gbs, 2), "unit": "GB/s",
             "tok_s": round(M / sec_per_step, 2),
-            "config": {"workload": f"llama2-7b linear stack ({nblocks} blocks x q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, bs={M} decode, "
-                                   f"{'bf16' if a.dtype == 'bf16' else 'fp16'}, {launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" + (", hipGraph replay" if graph is not None else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
-                       "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather (weak: {world}x wider layers)",
-                       "gemv_mode": mode_name, "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
+            "config": {"workload": f"{model} linear stack ({nblocks} blocks x q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, bs={M} decode, "
+                                   f"{'bf16' if a.dtype == 'bf16' else 'fp16'}, " +
+                                   (f"persistent decode engine: 1 launch / {stages_per_step} dependent stages per step" if engine else
+                                    f"{launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})") +
+                                   (", hipGraph replay" if graphed else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
+                       "global_batch": M,
+                       "parallelism": "single-gpu" if world == 1 else
+                                      (f"output-column shard x{world} of fixed layers (strong scaling) + RCCL all-gather + un-permute per exchange point, in the timed region"
+                                       if strong else f"column-shard x{world} + RCCL all-gather (weak: {world}x wider layers)"),
+                       "gemv_mode": mode_name, "layers_with_three_op_rebuild": f"{n_scal}/{nblocks * len(BLOCK)}",
+                       "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
         })
-        avg_launch_s = dev_sec_per_step / launches_per_step
-        ach = (bytes_per_step_rank / launches_per_step) / avg_launch_s / 1e9
+        unit_launches = stages_per_step   # the unit the roofline is quoted per: one dependent stage (= one launch on the launch path)
+        avg_launch_s = dev_sec_per_step / unit_launches
+        ach = (bytes_per_step_rank / unit_launches) / avg_launch_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           # PMC traffic is committed for the configuration it was measured on only (bs=1 fp16, exact mode)
-                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and mode_name == "exact") else None,
-                           "kernel": _decode_kernel_name(nbits, M, a.dtype, mode_name), "avg_launch_us": round(avg_launch_s * 1e6, 3),
-                           "bytes_per_launch": bytes_per_step_rank // launches_per_step,
-                           "note": "avg launch = HIP-event time of the timed region / launches (includes inter-kernel gaps)"}
+                           # PMC traffic is committed for the configuration it was measured on only (7B, bs=1 fp16, exact mode)
+                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and a.gemv_mode != "factored" and not big and not engine) else None,
+                           "kernel": ("hqq::decode_engine_kernel" if engine else _decode_kernel_name(nbits, M, a.dtype, a.gemv_mode)),
+                           "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                           "bytes_per_launch": bytes_per_step_rank // unit_launches,
+                           "note": "avg launch = HIP-event time of the timed region / dependent stages (includes inter-kernel gaps"
+                                   + ("; and the all-gathers" if world > 1 else "") + ")"}
+        if world > 1:   # the exchange alone (same graph structure without the GEMV launches)
+            xrun, _ = _graphed(lambda: step(only_exchange=True), use_graph, rank)
+            xs_, _ = _timed(xrun, max(5, a.steps // 2), 3, dist, dev)
+            out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5), "all_gathers_per_step": stages_per_step,
+                               "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK),
+                               "note": "all-gather + un-permute of every exchange point, timed without the GEMV launches"}
     else:
         tfl = world * flops_per_step_rank / sec_per_step / 1e12
         out.update({
@@ -320,6 +466,44 @@ def main():
         ach = flops_per_step_rank / dev_sec_per_step / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                            "traffic": None, "kernel": "hqq::dequant + hipBLASLt" if a.library_gemm else "hqq::gemm_f16_kernel"}
+
+    # ---- the other shapes the metric names, same resident weights (N = 1, default decode only) ----
+    if decode and world == 1 and not a.no_legs and not big and M == 1 and a.dtype == "f16" and S == 1 and nbits in (4, 2, 8):
+        legs = []
+
+        def leg(name, fn, nbytes, rows, launches, kernel):
+            r, g_ = _graphed(fn, use_graph, rank)
+            w, d = _timed(r, max(5, a.steps // 2), 3)
+            legs.append({"name": name, "ms_per_step": round(w * 1e3, 5), "value": round(nbytes / w / 1e9, 2), "unit": "GB/s", "tok_s": round(rows / w, 2),
+                         "launches_per_step": launches, "avg_launch_us": round(d / launches * 1e6, 3),
+                         "roofline_frac": round(nbytes / d / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel, "graph": g_})
+
+        xs32 = {K: torch.randn(32, K, device=dev, generator=gx).to(cd) for K in xs}
+        ol32 = {grp: [torch.empty(32, dimN[n], device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+        leg("7b-stack bs=32", lambda: step(bs_x=xs32, outs_by_grp=ol32), nblocks * sum(gemv_bytes(N, K, nbits, 32) for _, N, K in BLOCK), 32,
+            nblocks * len(EXCHANGE_GROUPS), _decode_kernel_name(nbits, 32, a.dtype, a.gemv_mode))
+        qs = [blk["q"] for blk in blocks]   # 32 distinct 4096x4096 layers (268 MB packed: beyond the Infinity Cache)
+        y1 = torch.empty(1, 4096, device=dev, dtype=cd)
+        y32 = torch.empty(32, 4096, device=dev, dtype=cd)
+
+        def single(xin, y):
+            for L in qs:
+                ops.gemv(xin, L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=y, opts=group_opts([L]))
+        leg("4096x4096 bs=1 (one layer per launch)", lambda: single(xs[4096], y1), len(qs) * gemv_bytes(4096, 4096, nbits, 1), 1, len(qs),
+            _decode_kernel_name(nbits, 1, a.dtype, a.gemv_mode))
+        leg("4096x4096 bs=32 (one layer per launch)", lambda: single(xs32[4096], y32), len(qs) * gemv_bytes(4096, 4096, nbits, 32), 32, len(qs),
+            _decode_kernel_name(nbits, 32, a.dtype, a.gemv_mode))
+        if not engine and a.gemv_mode != "factored":
+            try:
+                p2 = make_plan()
+                leg("7b-stack bs=1, persistent decode engine (1 launch/token, stage hand-offs in-kernel)", p2.run, bytes_per_step_rank, 1, stages_per_step,
+                    "hqq::decode_engine_kernel")
+                legs[-1]["launches_per_step"] = 1
+                legs[-1]["status"] = p2.status()
+            except Exception as e:
+                legs.append({"name": "persistent decode engine", "error": repr(e)})
+        out["legs"] = legs
+
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nbits)
@@ -328,13 +512,14 @@ def main():
         dist.destroy_process_group()
 
 
-def _decode_kernel_name(nbits, M, dtype, mode_name):
+def _decode_kernel_name(nbits, M, dtype, mode):
     """the kernel hqq_hip_gemv dispatches the bench's launches to (gemv.hip / skinny.hip / gemv3*.hip)"""
     if nbits == 3:
         return "hqq::gemv3s_kernel + gemv3s_finish_kernel (launches >= 19 MB) / hqq::gemv3_f16_kernel"
     if M >= 5:
         return f"hqq::skinny_f16_kernel<{nbits}, {(M + 15) // 16}, {'bf16' if dtype == 'bf16' else 'f16'}>"
-    return f"hqq::gemv_f16_kernel<{nbits}, {M}, gs64, {mode_name}, {'bf16' if dtype == 'bf16' else 'f16'}>"
+    arith = "factored" if mode == "factored" else ("exact, three-op rebuild" if mode == "exact" and dtype == "f16" else "exact")
+    return f"hqq::gemv_f16_kernel<{nbits}, {M}, gs64, {arith}, {'bf16' if dtype == 'bf16' else 'f16'}>"
 
 
 def _pmc_traffic(nbits):

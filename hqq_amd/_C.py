@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HQQ_AMD_LIB") or os.path.join(_HERE, "lib", "libhqq_h
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/hqq_hip.h declares, with its ctypes signature
-_i64, _i32, _vp, _f32, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t
+_i64, _i32, _vp, _f32, _sz, _u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint32
 SYMBOLS = {
     "hqq_hip_abi_version": (_i32, []),
     "hqq_hip_last_error": (ctypes.c_char_p, []),
@@ -24,14 +24,14 @@ SYMBOLS = {
     "hqq_hip_pack": (_i32, [_i32, _vp, _i32, _i64, _i64, _vp, _vp]),
     "hqq_hip_unpack": (_i32, [_i32, _vp, _i64, _i64, _vp, _i32, _vp]),
     "hqq_hip_dequantize": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
-    "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "hqq_hip_set_gemv_mode": (_i32, [_i32]),
-    "hqq_hip_get_gemv_mode": (_i32, []),
-    "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "hqq_hip_meta_check": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
+    "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
+    "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
+    "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp]),
+    "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_decode_plan_bytes": (_sz, [_i32]),
-    "hqq_hip_decode_plan_init": (_i32, [_vp, _sz, _i32, _i64, _i32, _i64, ctypes.c_uint32, _vp, _i32, _i32]),
+    "hqq_hip_decode_plan_init": (_i32, [_vp, _sz, _i32, _i64, _i32, _i64, _u32, _vp, _i32, _i32]),
     "hqq_hip_decode_run": (_i32, [_vp, _vp, _sz, _vp]),
     "hqq_hip_decode_plan_status_offset": (_sz, [_vp]),
     "hqq_hip_quantize_workspace_bytes": (_sz, [_i64, _i64, _i32]),
@@ -39,7 +39,7 @@ SYMBOLS = {
                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -90,4 +90,6 @@ def check(rc: int, what: str) -> None:
     msg = last_error()
     if rc == -4:
         raise NotImplementedError(f"{what}: {msg}")
+    if rc == -5:
+        raise RuntimeError(f"{what}: {msg} (workspace)")
     raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

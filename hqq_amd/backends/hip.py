@@ -35,6 +35,9 @@ class HQQLinearHIP(nn.Module):
         self.register_buffer("scale", m["scale"].reshape(-1).contiguous(), persistent=True)
         self.register_buffer("zero", m["zero"].reshape(-1).contiguous(), persistent=True)
         self.bias = None if hqq_layer.bias is None else hqq_layer.bias.to(device=W_q.device, dtype=self.compute_dtype)
+        # checked once, here: may the exact weight rebuild use its three-op form on this layer's (zero, scale)?  (include/hqq_hip.h)
+        self.opts = ops.OPT_META_SCALABLE if (self.compute_dtype == torch.float16 and self.nbits in (8, 4, 2, 1) and
+                                               ops.meta_scalable(self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits)) else 0
 
     @staticmethod
     def check(hqq_layer: HQQLinear) -> bool:
@@ -68,7 +71,8 @@ class HQQLinearHIP(nn.Module):
             if self.bias is not None:
                 out += self.bias
             return out
-        return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, self.nbits)
+        return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, self.nbits,
+                           opts=self.opts)
 
 
 def patch_hqq_to_hip(layer, patch_params=None):
@@ -103,23 +107,27 @@ class _GroupedMember(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         g = self._group
-        if g.x is x and g.version == x._version and g.outs[self._index] is not None:
+        # inference tensors (torch.inference_mode) carry no version counter: identity alone keys the parked outputs there
+        ver = None if x.is_inference() else x._version
+        if g.x is x and g.version == ver and g.outs[self._index] is not None:
             out, g.outs[self._index] = g.outs[self._index], None
+            if all(o is None for o in g.outs):
+                g.x = None   # every sibling served: do not keep the activation alive
             return out
         rows = x.numel() // x.shape[-1]
         if rows > g.max_rows or x.dtype != torch.float16:
             return self.layer(x)
         layers = [m.layer for m in g.members]
         outs = ops.gemv_grouped(x, [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers], self.in_features,
-                                layers[0].group_size, layers[0].nbits)
-        g.x, g.version, g.outs = x, x._version, list(outs)
+                                layers[0].group_size, layers[0].nbits, opts=g.opts)
+        g.x, g.version, g.outs = x, ver, list(outs)
         out, g.outs[self._index] = g.outs[self._index], None
         return out
 
 
 class _GroupState:
     def __init__(self):
-        self.members, self.x, self.version, self.outs, self.max_rows = [], None, -1, [], 4
+        self.members, self.x, self.version, self.outs, self.max_rows, self.opts = [], None, -1, [], 4, 0
 
 
 def group_projections(parent: nn.Module, names) -> bool:
@@ -142,6 +150,7 @@ def group_projections(parent: nn.Module, names) -> bool:
             return False
     if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits) for L in layers):
         state.max_rows = ops.SKINNY_MAX_M   # decode with a batch: still one weight-streaming launch for the group
+    state.opts = ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0
     for i, (n, L) in enumerate(zip(names, layers)):
         m = _GroupedMember(L, state, i)
         state.members.append(m)

@@ -219,7 +219,21 @@ class HQQLinear(nn.Module):
         self.W_q = nn.Parameter(W_q, requires_grad=False)
         self.device = device
         self.in_gpu = True
+        self._hip_opts = self._meta_opts()
         return self
+
+    def _meta_opts(self) -> int:
+        """per-call option bits of the fused forward that depend on this layer's meta only (checked once, when it lands on the GPU)"""
+        m = self.meta
+        try:
+            if (m["axis"] == 1 and m["scale"].dtype == float16 and m["packing"] in ("8bit_u8", "4bit_u8", "2bit_u8", "1bit_u8")
+                    and m["scale"].is_cuda and bool(m["group_size"])):
+                N, K = m["shape"]
+                if ops.meta_scalable(m["scale"].reshape(-1), m["zero"].reshape(-1), N, K, m["group_size"], Quantizer._packing_bits[m["packing"]]):
+                    return ops.OPT_META_SCALABLE
+        except (KeyError, TypeError, AttributeError):
+            pass
+        return 0
 
     # HF calls .to()/.half()/... on whole models; packed weights must not be touched (quantize.py:585-613)
     def to(self, *args, **kwargs):
@@ -366,7 +380,8 @@ class HQQLinear(nn.Module):
             m = self.meta
             N, K = m["shape"]
             W_q = self.W_q.view(m["unpack_view_dtype"]) if m["view_as_float"] else self.W_q
-            return ops.forward(x, W_q, m["scale"], m["zero"], bias, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]])
+            return ops.forward(x, W_q, m["scale"], m["zero"], bias, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]],
+                               opts=getattr(self, "_hip_opts", 0))
         out = self.matmul(x, transpose=transpose)
         if bias is not None:
             out += bias

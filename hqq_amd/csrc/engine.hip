@@ -17,11 +17,12 @@
 //            one global_load_dwordx4 per lane) are cut into 15 contiguous ranges, one per streaming wave: every wave of the chip
 //            gets the same number of bytes (+-1 step) whatever the layer shape (the row-per-wave grid of gemv.hip hands a wave
 //            1 or 2 rows of q|k|v: 75 % balance).
-//   ring     each streaming wave keeps D (8/6/4/2, what LDS allows) steps in flight — LDS-DMA (global_load_lds) into its own ring
-//            in LDS, no registers held — and refills a slot as soon as it has consumed it.  The
+//   units    each streaming wave keeps two units of 4 steps (2 x 4 KiB) in flight in two register sets and requests the unit after
+//            next as soon as it has consumed one (the ping-pong of gemv.hip; an LDS-DMA ring was tried first: the DMA issue
+//            path tops out near 4.5 TB/s with one 256-byte and one 1-KiB piece per step, tools/engine_ts.py).  The
 //            issue cursor runs ahead of the consume cursor ACROSS stage boundaries: weights and group constants do not depend
 //            on x, so while a stage's results are published and the next x is awaited the HBM pipe keeps serving the next
-//            stage's first 90-120 KiB per CU (23-30 MB chip-wide).
+//            stage's first 120 KiB per CU (30 MB chip-wide).
 //   partials a wave leaves one 16-float partial per (row, slab) it touched in LDS; after the workgroup barrier 16 lanes per
 //            output add the partials of a row in wave order (fixed order: reproducible), round once to fp16 (+ bias).
 //   hand-off (MI355X_MICROARCH.md, inter-workgroup visibility) y is stored write-through (sc1) by the control wave, which then
@@ -41,7 +42,10 @@ constexpr int EN_WAVES = 16;
 constexpr int EN_NSW = EN_WAVES - 1;   // streaming waves
 constexpr int EN_LDS_MAX = 160 * 1024;
 constexpr int EN_STEP = 1024;          // k per step
-constexpr int EN_SLOT = EN_STEP + 256; // LDS bytes of one ring slot: packed weights + one dword per lane of group constants
+#ifndef EN_UNIT
+#define EN_UNIT 4
+#endif
+constexpr int EN_U = EN_UNIT;          // steps per unit; two units (2 x EN_U KiB per wave, 120 KiB per CU at 4) are in flight
 constexpr int EN_SHARDS = 8;           // arrival counters (one 128-byte line each)
 constexpr int EN_SYNC_WORDS = (EN_SHARDS + 1) * 32;   // + the time-out word
 constexpr uint32_t EN_SPIN_LIMIT = 1u << 21;
@@ -66,7 +70,7 @@ struct EnArgs {
   const EnStage* stages;
   uint32_t* sync;       // EN_SYNC_WORDS words, zero at launch
   int n_stages;
-  int ring_off, part_off, tab_off, ybuf_off;   // LDS byte offsets behind the x buffer
+  int part_off, tab_off, ybuf_off;   // LDS byte offsets behind the x buffer
   int maxf;             // most rows a streaming wave touches in one stage
 #ifdef EN_LAB_TS
   unsigned long long* ts;   // lab: [workgroup][stage][8] control-wave time stamps
@@ -116,9 +120,15 @@ __device__ __forceinline__ void en_range(int S, int w, int& a, int& b) {
   b = a + qs + (w < rs ? 1 : 0);
 }
 
-template <int NBITS, bool SUB, int D>
+template <int U>
+struct EnUnit {        // one unit in flight: U steps of 16 bytes of packed weights per lane + the raw group constants this lane fetched
+  u32x4 w[U];
+  uint16_t z[U], sc[U];
+};
+
+template <int NBITS, bool SUB, int U>
 __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnArgs a) {
-  static_assert(D >= 2 && D <= 16, "ring depth");
+  static_assert(U >= 1 && U <= 8, "steps per unit");
   constexpr int PER = 8 / NBITS;
   static_assert(PER * 16 <= 64, "one dword per lane fetches the step's group constants (two arrays, PER slabs, 16 groups)");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -244,25 +254,30 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
   // =============================== streaming waves ===============================
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
-  // this wave's ring in LDS: D slots of [1 KiB packed weights | 256 B group constants]
-  const uint32_t ring_base = static_cast<uint32_t>(a.ring_off) + static_cast<uint32_t>(wave) * (D * EN_SLOT);
-  const uint8_t* ring = smem + a.ring_off + wave * (D * EN_SLOT);
+  // SUB: the lane that fetches a step's group constants scales them once, (z, s) -> (z 2^-J, s 2^J), J by the slab it fetched for
+  half2_t f_lane = {static_cast<half_t>(1.0f), static_cast<half_t>(1.0f)};
+  if constexpr (SUB) {
+    const int slab = (lane >> 4) < PER ? (lane >> 4) : 0;
+    const int J = 9 - NBITS * (PER - 1 - slab);
+    f_lane = half2_t{static_cast<half_t>(1.0f / static_cast<float>(1 << J)), static_cast<half_t>(static_cast<float>(1 << J))};
+  }
 
-  // ---- issue cursor: the next step to request (runs up to D steps ahead of the consume cursor, across stages) ----
-  // Per step two LDS-DMA loads: one dword per lane that together fetch the step's 16 group constants (zero, scale) of every
-  // slab — lane = (array * PER + slab) * 8 + i reads groups (2i, 2i+1) — and the 1 KiB of packed weights.
+  // ---- issue cursor: the next unit to request (two units are in flight at any time, across stage boundaries) ----
+  // A unit is the next min(U, steps left in this wave's range of the stage) steps; every issue() emits exactly 3 U loads
+  // (weights, zero, scale per step; steps the unit does not have re-read a valid address), so the wait before a unit is consumed
+  // is the exact s_waitcnt vmcnt(3 U) the compiler derives.
   const int lane_k = lane * 16;                               // byte (= k) offset of this lane inside a step
-  const int m_arr = (lane >> 3) / PER, m_slab = (lane >> 3) % PER, m_i = lane & 7;   // lanes >= 16 * PER duplicate (array 0 / 1 wraps)
-  const bool m_scale = (m_arr & 1) != 0;
+  const int lane_g = lane & 15;
+  const int lane_slab = (lane >> 4) < PER ? (lane >> 4) : 0;  // lanes >= 16 * PER duplicate slab 0 (never consumed)
   int is = 0, it = 0, it_end = 0, ikstep = 0, irow = 0;
   bool ilive = true;
   int iK = 0, iG = 0, ispr = 1;
   en_stage_p ist = stages;
   const uint8_t EN_GLOBAL* iwrow = nullptr;      // first byte of the current packed row
-  const uint8_t EN_GLOBAL* imeta = nullptr;      // per lane: first byte of (array, packed row, slab)'s group constants
   const uint8_t EN_GLOBAL* iWq = nullptr;
   const half_t EN_GLOBAL *izero = nullptr, *iscale = nullptr;
   int irow0 = 0, iend = 0, irps = 1;   // the layer the row belongs to: first / end row in the stage's row space, rows per slab
+  int ibase_r = 0;                     // per lane: (p + lane_slab * rows_per_slab) * G
 
   auto iss_layer = [&]() {   // irow left the current layer (or a new stage began): pick the layer
     const int pe0 = ist->prow_end[0], pe1 = ist->prow_end[1], pe2 = ist->prow_end[2];
@@ -278,8 +293,7 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
     if (irow >= iend) iss_layer();
     const int p = irow - irow0;
     iwrow = iWq + static_cast<int64_t>(p) * iK;
-    const int r = (p + m_slab * irps) * iG;
-    imeta = reinterpret_cast<const uint8_t EN_GLOBAL*>((m_scale ? iscale : izero) + r);
+    ibase_r = (p + lane_slab * irps) * iG;
   };
   auto iss_stage = [&]() {   // position the cursor on this wave's first step of stage `is` (skipping stages it has no step in)
     for (;;) {
@@ -301,35 +315,25 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       ++is;
     }
   };
-  auto dma16 = [&](const uint8_t EN_GLOBAL* sbase, uint32_t voff, uint32_t lds) {   // wave-uniform base + 32-bit lane offset
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
-  };
-  auto dma4 = [&](const uint8_t EN_GLOBAL* g, uint32_t lds) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
-  };
-  // exactly two vector-memory operations per call, whatever the cursor state: the consumer's wait is s_waitcnt vmcnt(2 (D - 1))
-  auto issue = [&](int slot) {
-    const uint32_t dst = ring_base + static_cast<uint32_t>(slot) * EN_SLOT;
-    if (!ilive) {   // past the last stage: slots that will never be consumed re-read the start of a valid row
-      dma4(imeta, dst + EN_STEP);
-      dma16(iwrow, static_cast<uint32_t>(lane_k), dst);
-      return;
+  auto issue = [&](EnUnit<U>& un) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool real = ilive && it < it_end;   // wave-uniform
+      int koff = ikstep * EN_STEP + lane_k;
+      int g = ikstep * 16 + lane_g;
+      if (!real) { koff = lane_k; g = lane_g; }
+      koff = koff < iK ? koff : 0;               // lanes past K re-read the row start: their x is zero in LDS
+      g = g < iG ? g : 0;
+      const int r = ibase_r + g;
+      un.z[u] = __builtin_bit_cast(uint16_t, izero[r]);
+      un.sc[u] = __builtin_bit_cast(uint16_t, iscale[r]);
+      un.w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 EN_GLOBAL*>(iwrow + koff));
+      if (real) {
+        ++it;
+        if (it < it_end && ++ikstep == ispr) { ikstep = 0; ++irow; iss_row(); }
+      }
     }
-    uint32_t koff = static_cast<uint32_t>(ikstep * EN_STEP + lane_k);
-    uint32_t goff = static_cast<uint32_t>(ikstep * 32 + 4 * m_i);   // bytes: group pair (2 i, 2 i + 1) of the step
-    if (ikstep == ispr - 1 && (iK & (EN_STEP - 1))) {   // the row's last, partial step: lanes past K re-read the row start (their x is zero in LDS)
-      koff = static_cast<int>(koff) < iK ? koff : 0u;
-      goff = static_cast<int>(goff) < iG * 2 ? goff : 0u;   // G is even: a pair of groups is inside the row or outside it
-    }
-    dma4(imeta + goff, dst + EN_STEP);
-    dma16(iwrow, koff, dst);
-    ++it;
-    if (it == it_end) { ++is; iss_stage(); }
-    else if (++ikstep == ispr) { ikstep = 0; ++irow; iss_row(); }
+    if (ilive && it == it_end) { ++is; iss_stage(); }   // the next unit starts the wave's range of a later stage
   };
 
   // ---- consume cursor ----
@@ -368,66 +372,63 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       acc[0][s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto consume = [&](int slot) {
-    // the oldest step in flight has landed once at most 2 (D - 1) younger loads are outstanding (loads return in order)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-    const uint8_t* sl = ring + slot * EN_SLOT;
-    const u32x4 w = *reinterpret_cast<const u32x4*>(sl + lane * 16);
-    const uint16_t* meta = reinterpret_cast<const uint16_t*>(sl + EN_STEP);
-    uint32_t zs[PER];
+  // the next min(U, ct_end - ct) steps of this wave's range are in `un`
+  auto consume = [&](const EnUnit<U>& un) {
 #pragma unroll
-    for (int s = 0; s < PER; ++s) {
-      // (zero, scale) of the group this lane's 16 k-values belong to (group lane >> 2 of the step), slab s
-      const half2_t m = {__builtin_bit_cast(half_t, meta[s * 16 + (lane >> 2)]), __builtin_bit_cast(half_t, meta[(PER + s) * 16 + (lane >> 2)])};
-      if constexpr (SUB) {
-        const int J = 9 - NBITS * (PER - 1 - s);
-        const half2_t f = {static_cast<half_t>(1.0f / static_cast<float>(1 << J)), static_cast<half_t>(static_cast<float>(1 << J))};
-        zs[s] = __builtin_bit_cast(uint32_t, m * f);   // (z 2^-J, s 2^J)
-      } else {
-        zs[s] = __builtin_bit_cast(uint32_t, m);
+    for (int u = 0; u < U; ++u) {
+      if (ct < ct_end) {
+        uint32_t mine = static_cast<uint32_t>(un.z[u]) | (static_cast<uint32_t>(un.sc[u]) << 16);
+        if constexpr (SUB) mine = __builtin_bit_cast(uint32_t, as_h2(mine) * f_lane);
+        uint32_t zs[PER];
+#pragma unroll
+        for (int s = 0; s < PER; ++s) zs[s] = __builtin_amdgcn_ds_bpermute((s * 16 + (lane >> 2)) << 2, mine);
+        h8_t b0[1], b1[1];
+        b0[0] = __builtin_bit_cast(h8_t, xs[(ckstep * 2 + 0) * 64 + lane]);
+        b1[0] = __builtin_bit_cast(h8_t, xs[(ckstep * 2 + 1) * 64 + lane]);
+        SlabExact<NBITS, 1, 0, PER, SUB>::run(un.w[u], zs, b0, b1, acc, magic);
+        ++ct;
+        if (++ckstep == cspr) { flush(); ckstep = 0; ++crow; }
       }
     }
-    h8_t b0[1], b1[1];
-    b0[0] = __builtin_bit_cast(h8_t, xs[(ckstep * 2 + 0) * 64 + lane]);
-    b1[0] = __builtin_bit_cast(h8_t, xs[(ckstep * 2 + 1) * 64 + lane]);
-    SlabExact<NBITS, 1, 0, PER, SUB>::run(w, zs, b0, b1, acc, magic);
-    ++ct;
-    if (++ckstep == cspr) { flush(); ckstep = 0; ++crow; }
   };
-
-  // ---- prologue: fill the ring before anything else, then wait for x of stage 0 ----
-  // (a wave without a single step in the whole plan still requests something valid: row 0 of stage 0)
-  iK = ist->K; iG = ist->G; irow = 0; iend = -1;
-  iss_row();
-  iss_stage();
-  for (int k = 0; k < D; ++k) issue(k);
-  cons_stage();
-  lds_barrier();   // B0
-
 #ifdef EN_LAB_TS
   unsigned long long* wts = (a.ts && (wave == 0 || wave == EN_NSW - 1)) ? a.ts + static_cast<size_t>(c) * n_stages * 8 : nullptr;
 #define EN_WTS(s, i) if (wts && lane == 0) wts[(s) * 8 + (i) + (wave == 0 ? 0 : 1)] = __builtin_amdgcn_s_memrealtime();
 #else
 #define EN_WTS(s, i)
 #endif
-  int slot = 0;   // ring position of the next step to consume
-  for (;;) {
-    while (ct < ct_end) {
-      consume(slot);
-      // every lane's reads of the slot are done (their values were used above) before the slot is requested again
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      issue(slot);
-      slot = slot + 1 == D ? 0 : slot + 1;
-    }
-    // ---- end of this wave's part of stage cs ----
+  // this wave's part of stage cs is done: partials -> outputs -> (next stage's x); false after the last stage
+  auto next_stage = [&]() -> bool {
     if (cany && ckstep != 0) flush();   // a row this wave shares with the next one
     EN_WTS(cs, 5)
     lds_barrier();   // B1
     reduce_stage(cg);
     lds_barrier();   // B1'
-    if (++cs == n_stages) return;
+    if (++cs == n_stages) return false;
     lds_barrier();   // B2
     cons_stage();
+    return true;
+  };
+
+  // ---- prologue: two units in flight before anything else, then wait for x of stage 0 ----
+  // (a wave without a single step in the whole plan still requests something valid: row 0 of stage 0)
+  iK = ist->K; iG = ist->G; irow = 0; iend = -1;
+  iss_row();
+  iss_stage();
+  EnUnit<U> ua, ub;
+  issue(ua);
+  issue(ub);
+  cons_stage();
+  lds_barrier();   // B0
+
+  // ---- ping-pong: consume the older unit, request the unit after the younger one into its registers ----
+  for (;;) {
+    while (ct == ct_end) if (!next_stage()) return;
+    consume(ua);
+    issue(ua);
+    while (ct == ct_end) if (!next_stage()) return;
+    consume(ub);
+    issue(ub);
   }
 }
 
@@ -438,7 +439,7 @@ constexpr uint32_t EN_MAGIC = 0x48515145u;   // "EQQH"
 struct alignas(256) EnPlanHeader {
   uint32_t magic, version;
   int n_stages, nbits, sub, grid;
-  int xs_bytes, ring_off, depth, part_off, tab_off, ybuf_off, maxf, lds_bytes;
+  int xs_bytes, part_off, tab_off, ybuf_off, maxf, lds_bytes;
   uint64_t stages_off, sync_off, total;
 };
 static_assert(sizeof(EnPlanHeader) == 256, "header record");
@@ -455,13 +456,7 @@ static int en_launch(const EnPlanHeader& h, const EnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(h.grid), dim3(EN_WAVES * 64), h.lds_bytes, st, a);
     return check_launch("hqq_hip_decode_run");
   };
-#define HQQ_EN_CASE(DD) case DD: return h.sub ? launch(decode_engine_kernel<NBITS, true, DD>) : launch(decode_engine_kernel<NBITS, false, DD>);
-  switch (h.depth) {
-    HQQ_EN_CASE(8) HQQ_EN_CASE(6) HQQ_EN_CASE(4) HQQ_EN_CASE(2)
-  }
-#undef HQQ_EN_CASE
-  set_error("hqq_hip_decode_run: plan with ring depth %d", h.depth);
-  return HQQ_ERR_SHAPE;
+  return h.sub ? launch(decode_engine_kernel<NBITS, true, EN_U>) : launch(decode_engine_kernel<NBITS, false, EN_U>);
 }
 
 }  // namespace hqq
@@ -503,7 +498,6 @@ extern "C" int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int 
     const int64_t K = in.K;
     if (in.n_layers < 1 || in.n_layers > EN_MAXL) { set_error("hqq_hip_decode_plan_init: stage %d has %d layers (1..%d)", s, in.n_layers, EN_MAXL); return HQQ_ERR_SHAPE; }
     if (K <= 0 || K % 64 || K > (1 << 20)) { set_error("hqq_hip_decode_plan_init: stage %d: K=%lld must be a multiple of the group size (<= 2^20)", s, (long long)K); return HQQ_ERR_SHAPE; }
-    if (K % 128) { set_error("hqq_hip_decode_plan_init: stage %d: K=%lld: the engine fetches group constants in aligned pairs (K %% 128 == 0)", s, (long long)K); return HQQ_ERR_UNSUPPORTED; }
     if (!in.x || !aligned16(in.x)) { set_error("hqq_hip_decode_plan_init: stage %d: x null or not 16-byte aligned", s); return in.x ? HQQ_ERR_ALIGN : HQQ_ERR_SHAPE; }
     int64_t total = 0;
     for (int i = 0; i < in.n_layers; ++i) {
@@ -546,17 +540,11 @@ extern "C" int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int 
   h->n_stages = n_stages; h->nbits = nbits; h->sub = (opts & HQQ_OPT_META_SCALABLE) ? 1 : 0; h->grid = grid;
   h->xs_bytes = max_spr * 2 * 64 * 16;
   h->maxf = maxf;
-  const int fixed = h->xs_bytes + static_cast<int>(en_align256(sizeof(float) * EN_NSW * maxf * per * 16)) + 256 +
-                    static_cast<int>(en_align256(sizeof(uint16_t) * static_cast<size_t>(max_rows) * per));
-  h->depth = 0;
-  for (int d : {8, 6, 4, 2})
-    if (fixed + EN_NSW * d * EN_SLOT <= EN_LDS_MAX) { h->depth = d; break; }
-  if (!h->depth) { set_error("hqq_hip_decode_plan_init: %d bytes of LDS needed besides the rings (K too long / chunks too tall for one workgroup)", fixed); return HQQ_ERR_UNSUPPORTED; }
-  h->ring_off = h->xs_bytes;
-  h->part_off = h->ring_off + EN_NSW * h->depth * EN_SLOT;
+  h->part_off = h->xs_bytes;
   h->tab_off = h->part_off + static_cast<int>(en_align256(sizeof(float) * EN_NSW * maxf * per * 16));
   h->ybuf_off = h->tab_off + 256;
   h->lds_bytes = h->ybuf_off + static_cast<int>(en_align256(sizeof(uint16_t) * static_cast<size_t>(max_rows) * per));
+  if (h->lds_bytes > EN_LDS_MAX) { set_error("hqq_hip_decode_plan_init: %d bytes of LDS needed (K too long / chunks too tall for one workgroup)", h->lds_bytes); return HQQ_ERR_UNSUPPORTED; }
   h->stages_off = sizeof(EnPlanHeader);
   h->sync_off = sizeof(EnPlanHeader) + sizeof(EnStage) * static_cast<size_t>(n_stages);
   h->total = en_plan_bytes(n_stages);
@@ -578,7 +566,7 @@ extern "C" int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t 
   a.stages = reinterpret_cast<const EnStage*>(base + h.stages_off);
   a.sync = reinterpret_cast<uint32_t*>(base + h.sync_off);
   a.n_stages = h.n_stages;
-  a.ring_off = h.ring_off; a.part_off = h.part_off; a.tab_off = h.tab_off; a.ybuf_off = h.ybuf_off; a.maxf = h.maxf;
+  a.part_off = h.part_off; a.tab_off = h.tab_off; a.ybuf_off = h.ybuf_off; a.maxf = h.maxf;
 #ifdef EN_LAB_TS
   a.ts = g_en_lab_ts;
 #endif

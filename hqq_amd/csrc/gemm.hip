@@ -447,7 +447,7 @@ using namespace hqq;
 extern "C" {
 
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream) {
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* stream) {
   clear_stale_error();
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemm: bad M/N/K/group_size"); return HQQ_ERR_SHAPE; }
   if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || N * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemm: size overflow"); return HQQ_ERR_SHAPE; }
@@ -461,9 +461,9 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
   if (dtype != HQQ_F16) { set_error("hqq_hip_gemm: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
   hipStream_t st = as_stream(stream);
   const int m = static_cast<int>(M), n = static_cast<int>(N), k = static_cast<int>(K), gs = static_cast<int>(group_size);
-  // opt-in (HQQ_HIP_GEMM_RT=1): register-tile kernel (weights never touch LDS).  Round-1 status: correct, 0.62-0.81 PFLOP/s — level
+  // opt-in (HQQ_OPT_GEMM_REGTILE): register-tile kernel (weights never touch LDS).  Round-1 status: correct, 0.62-0.81 PFLOP/s — level
   // with the LDS-staged kernels below (0.65-0.83), not ahead; PMC: waves stall on issue 33 % and wait 45 % of their cycles.
-  if (getenv("HQQ_HIP_GEMM_RT") && static_cast<int64_t>((M + 255) / 256) * ((N / per + 127) / 128) >= 256)
+  if ((opts & HQQ_OPT_GEMM_REGTILE) && static_cast<int64_t>((M + 255) / 256) * ((N / per + 127) / 128) >= 256)
     return nbits == 4 ? launch_gemm_rt_f16<4, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_rt_f16<2, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
   // 256-token tiles halve the dequantisation work per flop; keep 128 when M is too small to fill the chip with them
   const bool big = static_cast<int64_t>((M + 255) / 256) * ((N + GB_N - 1) / GB_N) >= 1536;   // >= 3 full waves of 256-token tiles
@@ -472,13 +472,14 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
 }
 
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                    void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream) {
-  if (M >= 1 && M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
+                    void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  if (M >= 1 && M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
   // a batch of 17..64 rows is still weight-streaming work: the skinny-GEMM kernel where it applies (same conditions as skinny_covers)
   if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
       N % (8 / nbits) == 0)
-    return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
-  return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, stream);
+    return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
+  return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, stream);
 }
 
 }  // extern "C"

@@ -601,11 +601,37 @@ namespace hqq {
 int gemv_mfma_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                   const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
 bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
+size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts);
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, hipStream_t st);
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
+               hipStream_t st);
+size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts);
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st);
-static int g_gemv_mode = HQQ_GEMV_EXACT;
+              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts,
+              void* ws, size_t ws_bytes, hipStream_t st);
+
+// hqq_hip_meta_check: groups whose (zero, scale) cannot take the three-op weight rebuild (decode_common.h, SlabExact<.., SUB>):
+// z 2^-J must be exact in fp16, s 2^J finite, |z| <= 2^15 (then q - z cannot overflow either), J = 9 - shift of the row's slab.
+template <int NBITS>
+__global__ __launch_bounds__(256) void meta_check_kernel(const half_t* __restrict__ scale, const half_t* __restrict__ zero, int64_t R, int G, int rows_per_slab,
+                                                         uint32_t* __restrict__ fails) {
+  constexpr int PER = 8 / NBITS;
+  uint32_t bad = 0;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < R; r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(r / G);
+    const int slab = n / rows_per_slab;
+    const int J = 9 - NBITS * (PER - 1 - slab);
+    const half_t dn = static_cast<half_t>(1.0f / static_cast<float>(1 << J)), up = static_cast<half_t>(static_cast<float>(1 << J));
+    const half_t z = zero[r], sc = scale[r];
+    const half_t zp = z * dn;          // one fp16 rounding, as the kernels do it
+    const half_t back = zp * up;       // exact when zp was (a power-of-two scaling up of a representable value)
+    const half_t sp = sc * up;
+    const float zf = static_cast<float>(z), spf = static_cast<float>(sp);
+    const bool ok = (back == z) && (zf <= 32768.0f) && (zf >= -32768.0f) && (spf - spf == 0.0f);   // NaN anywhere fails
+    bad += ok ? 0u : 1u;
+  }
+  if (bad) atomicAdd(fails, bad);   // rare
+}
 }  // namespace hqq
 
 using namespace hqq;
@@ -615,8 +641,10 @@ extern unsigned long long* g_lab_ts;
 
 extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
                                     const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
-                                    int64_t M, int64_t K, int64_t group_size, int dtype, void* stream) {
+                                    int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   clear_stale_error();
+  if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
   const bool skinny_ok = N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, N, n_layers);
@@ -629,7 +657,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
     if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers fp16 (got dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
     if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-    return gemv3_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
+    return gemv3_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, opts, workspace, workspace_bytes, as_stream(stream));
   }
   if (nbits != 4 && nbits != 2 && nbits != 8 && nbits != 1) { set_error("hqq_hip_gemv: nbits=%d not covered by the fused GEMV", nbits); return HQQ_ERR_UNSUPPORTED; }
   if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
@@ -641,7 +669,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   const int per = 8 / nbits;
   if (group_size % 16 || K % 16) { set_error("hqq_hip_gemv: needs group_size %% 16 == 0 (got gs=%lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (K > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
-  const bool exact = g_gemv_mode != HQQ_GEMV_FACTORED || dtype == HQQ_BF16;
+  const bool exact = !(opts & HQQ_OPT_FACTORED) || dtype == HQQ_BF16;
   if (n_layers > 1 && !skinny_ok && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (exact ? M > GV_EXACT_ROWWISE_MAX_M : M > 8)) {
     // a group in which only some layers meet the skinny kernel's conditions: launch the layers one by one, so that a layer is
     // served by the same kernel (same summation order, same bits) whether or not it was grouped
@@ -650,7 +678,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
     if (any) {
       for (int i = 0; i < n_layers; ++i) {
         const void* b1 = bias ? bias[i] : nullptr;
-        const int rc = hqq_hip_gemv_grouped(nbits, 1, x, Wq + i, scale + i, zero + i, bias ? &b1 : nullptr, y + i, N + i, M, K, group_size, dtype, stream);
+        const int rc = hqq_hip_gemv_grouped(nbits, 1, x, Wq + i, scale + i, zero + i, bias ? &b1 : nullptr, y + i, N + i, M, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
         if (rc) return rc;
       }
       return 0;
@@ -666,7 +694,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-    if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, as_stream(stream));
+    if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }
   int m_max = max_m_per_launch(K);
@@ -708,21 +736,54 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
     GvArgs b = a;
     b.x = static_cast<const half_t*>(x) + m0 * K;
     for (int i = 0; i < GV_MAXL; ++i) b.y[i] = a.y[i] + m0 * a.N[i];
-    const int rc = dtype == HQQ_BF16 ? dispatch_bf16(nbits, mm, b, st) : exact ? (g_gemv_mode == 2 ? dispatch<true, true>(nbits, mm, b, st) : dispatch<true>(nbits, mm, b, st)) : dispatch<false>(nbits, mm, b, st);
+    const int rc = dtype == HQQ_BF16 ? dispatch_bf16(nbits, mm, b, st) : exact ? ((opts & HQQ_OPT_META_SCALABLE) ? dispatch<true, true>(nbits, mm, b, st) : dispatch<true>(nbits, mm, b, st)) : dispatch<false>(nbits, mm, b, st);
     if (rc) return rc;
   }
   return 0;
 }
 
-extern "C" int hqq_hip_set_gemv_mode(int mode) {
-  if (mode != HQQ_GEMV_EXACT && mode != HQQ_GEMV_FACTORED && mode != 2) { set_error("hqq_hip_set_gemv_mode: unknown mode %d", mode); return HQQ_ERR_SHAPE; }
-  g_gemv_mode = mode;
+extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
+                            void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  const void* b1[1] = {bias};
+  return hqq_hip_gemv_grouped(nbits, 1, x, &Wq, &scale, &zero, bias ? b1 : nullptr, &y, &N, M, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  if (!N || n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || M < 1 || K <= 0 || group_size <= 0) return 0;
+  if (nbits == 3) return gemv3_workspace_bytes(n_layers, N, M, K, group_size, opts);
+  if ((dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, N, n_layers)) return skinny_workspace_bytes(nbits, n_layers, N, M, K, opts);
+  if (n_layers > 1 && M > GV_EXACT_ROWWISE_MAX_M) {   // a partly covered group is launched layer by layer (hqq_hip_gemv_grouped)
+    size_t most = 0;
+    for (int i = 0; i < n_layers; ++i)
+      if (skinny_covers(nbits, M, K, group_size, N + i, 1)) { const size_t b = skinny_workspace_bytes(nbits, 1, N + i, M, K, opts); most = b > most ? b : most; }
+    return most;
+  }
   return 0;
 }
-extern "C" int hqq_hip_get_gemv_mode(void) { return g_gemv_mode; }
 
-extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                            void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream) {
-  const void* b1[1] = {bias};
-  return hqq_hip_gemv_grouped(nbits, 1, x, &Wq, &scale, &zero, bias ? b1 : nullptr, &y, &N, M, K, group_size, dtype, stream);
+extern "C" int hqq_hip_meta_check(int nbits, const void* scale, const void* zero, int64_t N, int64_t K, int64_t group_size, int dtype,
+                                  uint32_t* fail_count, void* stream) {
+  clear_stale_error();
+  if (!scale || !zero || !fail_count) { set_error("hqq_hip_meta_check: null argument"); return HQQ_ERR_SHAPE; }
+  if (N <= 0 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_meta_check: bad N/K/group_size"); return HQQ_ERR_SHAPE; }
+  if (nbits != 8 && nbits != 4 && nbits != 2 && nbits != 1) { set_error("hqq_hip_meta_check: nbits=%d has no three-op rebuild", nbits); return HQQ_ERR_UNSUPPORTED; }
+  if (dtype != HQQ_F16) { set_error("hqq_hip_meta_check: the three-op rebuild is an fp16 sequence (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  const int per = 8 / nbits;
+  if (N % per) { set_error("hqq_hip_meta_check: N must divide by %d", per); return HQQ_ERR_SHAPE; }
+  const int64_t G = K / group_size, R = N * G;
+  if (R > INT32_MAX) { set_error("hqq_hip_meta_check: size overflow"); return HQQ_ERR_SHAPE; }
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) { set_error("hqq_hip_meta_check: hipMemsetAsync: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+  const int grid = static_cast<int>((R + 255) / 256 > 2048 ? 2048 : (R + 255) / 256);
+  const half_t* sp = static_cast<const half_t*>(scale);
+  const half_t* zp = static_cast<const half_t*>(zero);
+  switch (nbits) {
+    case 8: hipLaunchKernelGGL(meta_check_kernel<8>, dim3(grid), dim3(256), 0, st, sp, zp, R, static_cast<int>(G), static_cast<int>(N / per), fail_count); break;
+    case 4: hipLaunchKernelGGL(meta_check_kernel<4>, dim3(grid), dim3(256), 0, st, sp, zp, R, static_cast<int>(G), static_cast<int>(N / per), fail_count); break;
+    case 2: hipLaunchKernelGGL(meta_check_kernel<2>, dim3(grid), dim3(256), 0, st, sp, zp, R, static_cast<int>(G), static_cast<int>(N / per), fail_count); break;
+    case 1: hipLaunchKernelGGL(meta_check_kernel<1>, dim3(grid), dim3(256), 0, st, sp, zp, R, static_cast<int>(G), static_cast<int>(N / per), fail_count); break;
+  }
+  return check_launch("hqq_hip_meta_check");
 }

@@ -288,12 +288,27 @@ static int g3_launch(const G3Args& a, hipStream_t st) {
 }
 
 bool gemv3s_covers(int64_t M, int64_t K, int64_t group_size);   // gemv3s.hip: each packed word loaded once for all ten slabs
+size_t gemv3s_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K);
 int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st);
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, void* ws, size_t ws_bytes, hipStream_t st);
+
+// which of the two 3-bit kernels a launch takes: the slab-sharing one (gemv3s.hip) from 19 MB of packed weights on — 2.2 TB/s of
+// packed bytes at the margin against 1.2 here, but ~10 us of fixed cost (a task is a 4 us chain of instructions in one wave, plus
+// the finishing launch) against ~4 us; measured crossover on MI355X (tools/sweep_int3.py).  HQQ_OPT_GEMV3_ROWWISE / _SLABS force one.
+static bool gemv3_wants_slabs(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts) {
+  if (group_size != 64 || !gemv3s_covers(M, K, group_size)) return false;
+  int64_t packed = 0;
+  for (int i = 0; i < n_layers; ++i) packed += ((N[i] * (K / 64) + 9) / 10) * 256;
+  return (opts & HQQ_OPT_GEMV3_SLABS) || (packed >= (int64_t(19) << 20) && !(opts & HQQ_OPT_GEMV3_ROWWISE));
+}
+size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts) {
+  return gemv3_wants_slabs(n_layers, N, M, K, group_size, opts) ? gemv3s_workspace_bytes(n_layers, N, M, K) : 0;
+}
 
 // called by hqq_hip_gemv_grouped (gemv.hip) for nbits == 3 after the common argument checks
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, hipStream_t st) {
+              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts,
+              void* ws, size_t ws_bytes, hipStream_t st) {
   if (group_size != 64) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers group_size 64 (got %lld)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
   if (M > G3_MAX_M) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers M <= %d (got %lld)", G3_MAX_M, (long long)M); return HQQ_ERR_UNSUPPORTED; }
   G3Args a;
@@ -327,15 +342,7 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
     a.e_end[i] = static_cast<int>(ents);
     if (G > a.step[i]) { set_error("hqq_hip_gemv: 3-bit layer with fewer than 10 output rows per slab is not covered"); return HQQ_ERR_UNSUPPORTED; }
   }
-  // Large launches go to the slab-sharing kernel (gemv3s.hip): 2.2 TB/s of packed bytes at the margin against 1.2 here, but ~10 us
-  // of fixed cost (a task is a 4 us chain of instructions in one wave, plus the finishing launch) against ~4 us — measured
-  // crossover on MI355X around 19 MB per launch (tools/sweep_int3.py).  HQQ_HIP_GEMV3_V1 / _V2 force one or the other (tests).
-  {
-    int64_t packed = 0;
-    for (int i = 0; i < n_layers; ++i) packed += static_cast<int64_t>(a.step[i]) * 256;
-    const bool want = getenv("HQQ_HIP_GEMV3_V2") || (packed >= (int64_t(19) << 20) && !getenv("HQQ_HIP_GEMV3_V1"));
-    if (want && gemv3s_covers(M, K, group_size)) return gemv3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, st);
-  }
+  if (gemv3_wants_slabs(n_layers, N, M, K, group_size, opts)) return gemv3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, ws, ws_bytes, st);
   for (int i = n_layers; i < G3_MAXL; ++i) {
     a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
     a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.e_end[i] = a.e_end[n_layers - 1];

@@ -28,7 +28,6 @@
 
 namespace hqq {
 
-float* gemv_scratch(size_t bytes, hipStream_t st);   // skinny.hip: per-device scratch, grown outside stream capture only
 
 constexpr int S3_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int S3_WAVES = 4;
@@ -313,10 +312,12 @@ __global__ __launch_bounds__(256) void gemv3s_finish_kernel(const S3Args a) {
 }
 
 template <int M>
-static int s3_launch(S3Args& a, int max_n, hipStream_t st) {
+static int s3_launch(S3Args& a, int max_n, void* ws, size_t ws_bytes, hipStream_t st) {
   const size_t lds = static_cast<size_t>(M) * (a.K + S3_ROWS * 64) * 2;
-  a.part = gemv_scratch(static_cast<size_t>(a.total_tasks) * 10 * 2 * M * sizeof(float), st);
-  if (!a.part) return HQQ_ERR_UNSUPPORTED;
+  const size_t need = static_cast<size_t>(a.total_tasks) * 10 * 2 * M * sizeof(float);
+  if (!ws || ws_bytes < need) { set_error("hqq_hip_gemv(3-bit): the slab-sharing kernel parks %zu bytes of partial sums in the workspace (hqq_hip_gemv_workspace_bytes), got %zu", need, ws ? ws_bytes : size_t(0)); return HQQ_ERR_WORKSPACE; }
+  if (!aligned16(ws)) { set_error("hqq_hip_gemv: workspace must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  a.part = static_cast<float*>(ws);
   int n_cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0) n_cus = 256;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
@@ -347,8 +348,16 @@ bool gemv3s_covers(int64_t M, int64_t K, int64_t group_size) {
 }
 
 // called by gemv3_run (gemv3.hip) after the common argument checks; same contract
+// bytes of partial sums a launch of this shape parks in the caller's workspace
+size_t gemv3s_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K) {
+  const int64_t G = K / 64;
+  int64_t tasks = 0;
+  for (int i = 0; i < n_layers; ++i) tasks += ((N[i] * G + 9) / 10 + S3_ROWS - 1) / S3_ROWS;
+  return static_cast<size_t>(tasks) * 10 * 2 * static_cast<size_t>(M) * sizeof(float);
+}
+
 int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, hipStream_t st) {
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, void* ws, size_t ws_bytes, hipStream_t st) {
   S3Args a;
   const int64_t G = K / 64;
   int64_t tasks = 0, max_n = 0;
@@ -378,10 +387,10 @@ int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* c
   a.total_tasks = static_cast<int>(tasks);
   a.n_layers = n_layers;
   switch (M) {
-    case 1: return s3_launch<1>(a, static_cast<int>(max_n), st);
-    case 2: return s3_launch<2>(a, static_cast<int>(max_n), st);
-    case 3: return s3_launch<3>(a, static_cast<int>(max_n), st);
-    case 4: return s3_launch<4>(a, static_cast<int>(max_n), st);
+    case 1: return s3_launch<1>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 2: return s3_launch<2>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 3: return s3_launch<3>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 4: return s3_launch<4>(a, static_cast<int>(max_n), ws, ws_bytes, st);
   }
   return HQQ_ERR_SHAPE;
 }

@@ -526,62 +526,36 @@ static int sk_num_cus() {
   return n_cus;
 }
 
-// per-device scratch for the split-K partials, grown outside stream capture only (no allocation inside a captured call).
-// One buffer per device, not per stream: launches on different streams of a device must not overlap (documented in hqq_hip.h);
-// host-side state is not thread-safe (the reference drives the GPU from one Python thread).
-constexpr int SK_MAX_DEV = 16;
-constexpr size_t SK_CNT_BYTES = size_t(256) << 10;   // head of the scratch: one int per (panel, row group), 64 Ki counters
-static float* g_sk_part[SK_MAX_DEV] = {};
-static size_t g_sk_part_bytes[SK_MAX_DEV] = {};
+// Workspace of the split-K launches (caller-owned, hqq_hip_gemv_workspace_bytes): [arrival counters | fp32 partial tiles].
+// The counters must read zero when a call starts; every call leaves them zero again (the finishing split resets its counter),
+// so the caller clears the workspace once, when it allocates it.
+constexpr size_t SK_CNT_BYTES = size_t(256) << 10;   // head of the workspace: one int per (panel, row group), 64 Ki counters
 
-static float* sk_scratch(size_t bytes, hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SK_MAX_DEV) { set_error("hqq_hip_gemv: device index out of range"); return nullptr; }
-  if (g_sk_part_bytes[dev] >= bytes) return g_sk_part[dev];
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-  if (cs != hipStreamCaptureStatusNone) {
-    set_error("hqq_hip_gemv: the split-K scratch (%zu bytes) must be allocated by one call of this shape outside stream capture first", bytes);
-    return nullptr;
-  }
-  const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes;
-  float* pnew = nullptr;
-  if (hipMalloc(&pnew, want) != hipSuccess) { (void)hipGetLastError(); set_error("hqq_hip_gemv: cannot allocate %zu bytes of split-K scratch", want); return nullptr; }
-  // the arrival counters at the head of the buffer must read zero before their first launch (every launch leaves them zero again)
-  // (synchronised: the caller's stream may be a non-blocking one that does not order itself after the null stream's memset)
-  if (hipMemset(pnew, 0, SK_CNT_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pnew); set_error("hqq_hip_gemv: cannot clear the split-K counters"); return nullptr; }
-  if (g_sk_part[dev]) {
-    (void)hipDeviceSynchronize();   // earlier launches may still read the old buffer
-    (void)hipFree(g_sk_part[dev]);
-  }
-  g_sk_part[dev] = pnew;
-  g_sk_part_bytes[dev] = want;
-  return pnew;
+// K splits (shape-dependent only, never M: a row's result must not depend on the batch it is computed in).  Measured on 7B / 70B
+// shapes: about one workgroup per CU and >= 8 chunks per workgroup wins — every split pays the prologue (first data ~5 us after
+// launch) and writes a partial tile; only layers with few panels are worth cutting finer.  forced: HQQ_OPT_SKINNY_KS (tuning).
+static void sk_choose(int total_panels, int nchunks, int forced, int& ks, int& cps) {
+  const int cus = sk_num_cus();
+  ks = (total_panels * 16 >= cus * 9 && nchunks <= SK_MAX_CPS) ? 1   // >= 0.56 workgroups per CU: one pass, no partials
+                                                               : (cus + total_panels - 1) / total_panels;
+  if (total_panels >= 48) { const int lim = nchunks / 8 > 1 ? nchunks / 8 : 1; ks = ks > lim ? lim : ks; }
+  ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
+  ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
+  if (forced >= 1 && forced <= nchunks) ks = forced;
+  cps = (nchunks + ks - 1) / ks;
+  cps = cps > SK_MAX_CPS ? SK_MAX_CPS : cps;  // (long K: more splits than the occupancy rule asks for)
+  ks = (nchunks + cps - 1) / cps;             // drop empty splits
 }
-
-// the same scratch for other kernels' partial sums (gemv3s.hip): behind the counters, which must stay zero
-float* gemv_scratch(size_t bytes, hipStream_t st) {
-  float* buf = sk_scratch(SK_CNT_BYTES + bytes, st);
-  return buf ? buf + SK_CNT_BYTES / sizeof(float) : nullptr;
+static size_t sk_part_bytes(int nbits, int ks, int total_panels, int mt) {
+  return ks > 1 ? static_cast<size_t>(ks) * total_panels * SK_ROWS * (8 / nbits) * 16 * mt * sizeof(float) : 0;
 }
 
 template <int NBITS, bool BF16>
-static int sk_launch(SkArgs& a, hipStream_t st) {
+static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
   const int nchunks = a.K / SK_KC;
-  // K splits (shape-dependent only, never M: a row's result must not depend on the batch it is computed in).  Measured on 7B / 70B
-  // shapes: about one workgroup per CU and >= 8 chunks per workgroup wins — every split pays the prologue (first data ~5 us after
-  // launch) and writes a partial tile; only layers with few panels are worth cutting finer.
-  const int cus = sk_num_cus();
-  int ks = (a.total_panels * 16 >= cus * 9 && nchunks <= SK_MAX_CPS) ? 1   // >= 0.56 workgroups per CU: one pass, no partials, no second launch
-                                                                     : (cus + a.total_panels - 1) / a.total_panels;
-  if (a.total_panels >= 48) { const int lim = nchunks / 8 > 1 ? nchunks / 8 : 1; ks = ks > lim ? lim : ks; }
-  ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
-  ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
-  if (const char* e = getenv("HQQ_HIP_SKINNY_KS")) { const int v = atoi(e); if (v >= 1 && v <= nchunks) ks = v; }   // tuning knob (tools/sweep_ks.py)
-  int cps = (nchunks + ks - 1) / ks;
-  cps = cps > SK_MAX_CPS ? SK_MAX_CPS : cps;  // (long K: more splits than the occupancy rule asks for)
-  ks = (nchunks + cps - 1) / cps;             // drop empty splits
+  int ks, cps;
+  sk_choose(a.total_panels, nchunks, static_cast<int>(opts >> 24), ks, cps);
   a.KS = ks;
   a.cps = cps;
 #ifdef SK_LAB_TS
@@ -590,11 +564,11 @@ static int sk_launch(SkArgs& a, hipStream_t st) {
   a.part = nullptr;
   if (ks > 1) {
     if (static_cast<size_t>(a.total_panels) * SK_RG * sizeof(int) > SK_CNT_BYTES) { set_error("hqq_hip_gemv: too many row panels for the split-K counters"); return HQQ_ERR_UNSUPPORTED; }
-    const size_t bytes = SK_CNT_BYTES + static_cast<size_t>(ks) * a.total_panels * SK_ROWS * (8 / NBITS) * 16 * mt * sizeof(float);
-    float* buf = sk_scratch(bytes, st);
-    if (!buf) return HQQ_ERR_UNSUPPORTED;
-    a.cnt = reinterpret_cast<int*>(buf);
-    a.part = buf + SK_CNT_BYTES / sizeof(float);
+    const size_t need = SK_CNT_BYTES + sk_part_bytes(NBITS, ks, a.total_panels, mt);
+    if (!ws || ws_bytes < need) { set_error("hqq_hip_gemv: this launch splits K and needs %zu bytes of workspace (hqq_hip_gemv_workspace_bytes), got %zu", need, ws ? ws_bytes : size_t(0)); return HQQ_ERR_WORKSPACE; }
+    if (!aligned16(ws)) { set_error("hqq_hip_gemv: workspace must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    a.cnt = static_cast<int*>(ws);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(ws) + SK_CNT_BYTES);
   }
   const size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
@@ -629,8 +603,19 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
   return true;
 }
 
+// bytes of workspace a skinny launch of this shape needs (0: it does not split K)
+size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts) {
+  const int per = 8 / nbits;
+  int64_t panels = 0;
+  for (int i = 0; i < n_layers; ++i) panels += (N[i] / per + SK_ROWS - 1) / SK_ROWS;
+  int ks, cps;
+  sk_choose(static_cast<int>(panels), static_cast<int>(K / SK_KC), static_cast<int>(opts >> 24), ks, cps);
+  return ks > 1 ? SK_CNT_BYTES + sk_part_bytes(nbits, ks, static_cast<int>(panels), static_cast<int>((M + 15) / 16)) : 0;
+}
+
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, hipStream_t st) {
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
+               hipStream_t st) {
   const int per = 8 / nbits;
   SkArgs a;
   int64_t panels = 0, ntot = 0;
@@ -657,8 +642,8 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
   a.n_total = static_cast<int>(ntot);
   a.M = static_cast<int>(M);
   a.x = static_cast<const half_t*>(x);
-  if (dtype == HQQ_BF16) return nbits == 4 ? sk_launch<4, true>(a, st) : nbits == 2 ? sk_launch<2, true>(a, st) : sk_launch<8, true>(a, st);
-  return nbits == 4 ? sk_launch<4, false>(a, st) : nbits == 2 ? sk_launch<2, false>(a, st) : sk_launch<8, false>(a, st);
+  if (dtype == HQQ_BF16) return nbits == 4 ? sk_launch<4, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, true>(a, opts, ws, ws_bytes, st);
+  return nbits == 4 ? sk_launch<4, false>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false>(a, opts, ws, ws_bytes, st) : sk_launch<8, false>(a, opts, ws, ws_bytes, st);
 }
 
 }  // namespace hqq

@@ -21,6 +21,17 @@ GEMV_MAX_M = 16
 SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512
 GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
+# per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
+OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE = 1, 2, 4, 8, 16
+
+
+def OPT_SKINNY_KS(n: int) -> int:
+    return int(n) << 24
+
+
+# Default arithmetic of the decode wrappers below when a call passes no `opts` — a convenience of THIS module (tools, tests,
+# bench); the library itself holds no mode.
+_default_opts = 0
 
 
 def is_available() -> bool:
@@ -55,11 +66,68 @@ def _p(t):
 
 def set_gemv_mode(mode: int) -> None:
     """GEMV_EXACT (default): reference-identical weights on the MFMA path; GEMV_FACTORED: fp32-factored dot2 path."""
-    _C.check(_C.lib().hqq_hip_set_gemv_mode(int(mode)), "hqq_hip_set_gemv_mode")
+    global _default_opts
+    if mode not in (GEMV_EXACT, GEMV_FACTORED):
+        raise ValueError(f"hqq_amd: unknown gemv mode {mode}")
+    _default_opts = OPT_FACTORED if mode == GEMV_FACTORED else 0
 
 
 def get_gemv_mode() -> int:
-    return int(_C.lib().hqq_hip_get_gemv_mode())
+    return GEMV_FACTORED if (_default_opts & OPT_FACTORED) else GEMV_EXACT
+
+
+def _opts(opts) -> int:
+    return _default_opts if opts is None else int(opts)
+
+
+# ---- caller-owned workspace of the split-K / slab-sharing decode launches (include/hqq_hip.h "Workspace") --------------------
+# One zero-initialised buffer per device, sized for the largest launch seen so far.  Growing allocates a NEW buffer and keeps
+# the old ones alive: a hipGraph captured earlier has the old address baked in and must stay valid (never free what a graph
+# may reference).  Growth cannot happen inside stream capture (the new buffer would belong to the graph's private pool).
+_ws_cur: dict = {}
+_ws_retired: list = []
+_WS_MIN = 8 << 20
+
+
+def reserve_workspace(device, nbytes: int) -> Tensor:
+    """make sure the device's decode workspace holds `nbytes`; call it before capturing a graph whose launches need one"""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    cur = _ws_cur.get(key)
+    if cur is not None and cur.numel() >= nbytes:
+        return cur
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"hqq_amd: this launch needs {nbytes} bytes of decode workspace, more than was reserved before stream capture; "
+                           "run the step once eagerly (or call hqq_amd.ops.reserve_workspace) before capturing")
+    new = torch.zeros(max(int(nbytes), _WS_MIN), dtype=torch.uint8, device=torch.device("cuda", key))
+    if cur is not None:
+        _ws_retired.append(cur)
+    _ws_cur[key] = new
+    return new
+
+
+def _workspace(x: Tensor, nbits, Ns, M, K, group_size, opts):
+    import ctypes
+    n = len(Ns)
+    need = int(_C.lib().hqq_hip_gemv_workspace_bytes(int(nbits), n, (ctypes.c_int64 * n)(*[int(v) for v in Ns]), int(M), int(K), int(group_size),
+                                                     _dt(x.dtype), int(opts)))
+    if not need:
+        return None, 0
+    ws = reserve_workspace(x.device, need)
+    return ws.data_ptr(), ws.numel()
+
+
+def meta_scalable(scale: Tensor, zero: Tensor, N: int, K: int, group_size: int, nbits: int) -> bool:
+    """True when every (zero, scale) pair of the layer can take the three-op exact weight rebuild (hqq_hip_meta_check == 0 failing
+    groups): pass OPT_META_SCALABLE for it then.  Synchronises (one 4-byte read-back): call it when a layer is prepared, not per forward."""
+    _dev(scale, zero)
+    if scale.dtype != torch.float16 or zero.dtype != torch.float16 or nbits not in (8, 4, 2, 1) or N % PER[nbits]:
+        return False
+    cnt = torch.empty(1, dtype=torch.int32, device=scale.device)
+    with torch.cuda.device(scale.device):
+        rc = _C.lib().hqq_hip_meta_check(int(nbits), _p(scale.contiguous()), _p(zero.contiguous()), int(N), int(K), int(group_size), F16, _p(cnt), _stream())
+    _C.check(rc, "hqq_hip_meta_check")
+    return int(cnt.item()) == 0
 
 
 def packed_rows(nbits: int, rows: int) -> int:
@@ -110,7 +178,7 @@ def dequantize(W_q: Tensor, scale: Tensor, zero: Tensor, N: int, K: int, group_s
 
 
 def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias, N: int, K: int, group_size: int, nbits: int,
-         out: Tensor | None = None) -> Tensor:
+         out: Tensor | None = None, opts=None) -> Tensor:
     _dev(x, W_q, scale, zero, bias)
     if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
         raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
@@ -123,19 +191,24 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     if M > 0:
+        o = _opts(opts)
         with torch.cuda.device(x.device):
-            rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
-                                            _dt(x.dtype), _stream())
+            if fn_name == "hqq_hip_gemm":
+                rc = _C.lib().hqq_hip_gemm(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size, _dt(x.dtype), o, _stream())
+            else:
+                ws, ws_bytes = _workspace(x, nbits, [N], M, K, group_size, o) if M <= SKINNY_MAX_M else (None, 0)
+                rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
+                                                _dt(x.dtype), o, ws, ws_bytes, _stream())
         _C.check(rc, fn_name)
     return out.reshape(*x.shape[:-1], N)
 
 
-def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
+def gemv(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None) -> Tensor:
     """fused unpack->dequant->GEMV for decode-sized batches: 1 <= M <= 16 (3-bit, and bf16 outside the skinny-GEMM kernel: <= 4; FACTORED mode: <= 8); up to SKINNY_MAX_M where skinny_covers()."""
-    return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+    return _fwd("hqq_hip_gemv", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
 
 
-def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=None):
+def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=None, opts=None):
     """Horizontal fusion: one launch for up to GEMV_MAX_GROUP layers that consume the same x (q/k/v, gate/up, ...).
     layers: sequence of (W_q, scale, zero, bias_or_None, N).  Returns the list of outputs [*, N_i]."""
     import ctypes
@@ -157,16 +230,15 @@ def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=No
     if M > 0:
         VP = ctypes.c_void_p * n
         has_bias = any(L[3] is not None for L in layers)
+        o = _opts(opts)
         with torch.cuda.device(x.device):
+            ws, ws_bytes = _workspace(x, nbits, [L[4] for L in layers], M, K, group_size, o)
             rc = _C.lib().hqq_hip_gemv_grouped(
                 nbits, n, _p(x2), VP(*[_p(L[0]) for L in layers]), VP(*[_p(L[1]) for L in layers]), VP(*[_p(L[2]) for L in layers]),
-                VP(*[_p(L[3]) for L in layers]) if has_bias else None, VP(*[_p(o) for o in outs]),
-                (ctypes.c_int64 * n)(*[int(L[4]) for L in layers]), M, K, group_size, _dt(x.dtype), _stream())
+                VP(*[_p(L[3]) for L in layers]) if has_bias else None, VP(*[_p(o_) for o_ in outs]),
+                (ctypes.c_int64 * n)(*[int(L[4]) for L in layers]), M, K, group_size, _dt(x.dtype), o, ws, ws_bytes, _stream())
         _C.check(rc, "hqq_hip_gemv_grouped")
     return [o.reshape(*x.shape[:-1], L[4]) for o, L in zip(outs, layers)]
-
-
-OPT_META_SCALABLE = 2
 
 
 class _StageDesc(__import__("ctypes").Structure):
@@ -233,9 +305,9 @@ class DecodePlan:
         return int(self._dev[self._status_off:self._status_off + 4].view(torch.int32).item())
 
 
-def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None) -> Tensor:
+def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None) -> Tensor:
     """fused unpack->dequant->MFMA GEMM (prefill)."""
-    return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+    return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
 
 
 # From this many activation rows on, `forward` composes the HIP dequantise kernel with a plain library GEMM (hipBLASLt through
@@ -267,7 +339,7 @@ def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:
     return dtype == torch.float16 and (M <= 4 or K % 64 == 0)
 
 
-def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None) -> Tensor:
+def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None, opts=None) -> Tensor:
     """y = x @ dequantize(W_q)^T (+ bias).  M <= 16 (<= 64 where the skinny-GEMM kernel applies): weight-streaming decode kernels;
     larger M: fused MFMA dequant-GEMM, or — from LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.
     Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit beyond 4 rows,
@@ -279,7 +351,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
         fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
             (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M))
     if fused:
-        return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out)
+        return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
     W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)
     y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
     if bias is not None:

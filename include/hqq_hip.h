@@ -4,7 +4,9 @@
  * Boundary rules:
  *   - plain pointers and sizes only; no torch / ATen types cross this ABI.
  *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates or
- *     frees device memory and keeps no pointer after a call returns.
+ *     frees device memory, keeps no pointer after a call returns and holds no per-process mode:
+ *     whatever selects a kernel variant is a per-call `opts` bit (HQQ_OPT_*); no environment
+ *     variable is read.
  *   - every function enqueues on the given hipStream_t (passed as void*; NULL = legacy default
  *     stream) and returns immediately; there is no host synchronisation inside.
  *   - return value: 0 on success; >0 a hipError_t from the launch; <0 an argument error
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 1
+#define HQQ_HIP_ABI_VERSION 2
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -81,18 +83,39 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * Covered by hqq_hip_gemv: nbits in {8,4,2,1} with N % (8/nbits) == 0, group_size % 16 == 0, K % group_size == 0, fp16,
  * M <= 16 (bf16: nbits 4/2, M <= 4; up to HQQ_GEMV_MAX_M_SKINNY = 64 rows for fp16 and bf16, nbits 8/4/2, group_size 64,
  * K % 256 == 0, K >= 512: the weight-streaming skinny-GEMM kernel); nbits 3 with group_size 64, fp16, M <= 4.
- * Scratch: launches of 5..64 rows that split K, and 3-bit launches of >= 19 MB of packed weights, park fp32 partial sums in ONE
- * buffer per device (partial tiles + arrival counters).  It is allocated / grown by the first call that needs more — which must
- * therefore happen outside stream capture (a captured call that would have to grow it fails with HQQ_ERR_UNSUPPORTED) — and is
- * shared by all streams: such launches on DIFFERENT streams of one device must not overlap.
+ * Workspace: launches of 5..64 rows that split K, and 3-bit launches of >= 19 MB of packed weights, park fp32 partial sums (and
+ * arrival counters) in a caller-owned workspace of hqq_hip_gemv_workspace_bytes(...) bytes (0 = this call needs none; then
+ * workspace may be NULL).  Contract: 16-byte aligned device memory, ZERO when first used — the caller clears it once when
+ * allocating it; every call leaves the counter area zero again — and not shared by calls that may run concurrently.  A larger
+ * workspace than asked for is fine: one buffer sized for the largest launch serves a whole model.
  * hqq_hip_gemm: nbits in {4,2}, fp16, K % 64 == 0.
  * Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
 #define HQQ_GEMV_MAX_M_SKINNY 64   /* fp16 / bf16, 8-/4-/2-bit, group_size 64, K % 256 == 0, K >= 512: the skinny-GEMM kernel */
 #define HQQ_GEMV_MAX_GROUP 4
+/* per-call options */
+#define HQQ_OPT_FACTORED       1u   /* decode arithmetic: the group affine map is factored out of the dot product and applied in fp32
+                                       (no per-weight fp16 rounding: NOT the reference's weights; results differ from it by less than its
+                                       own weight-rounding noise).  M <= 8.  Default (bit clear): every weight is rebuilt as
+                                       round16(round16(q - z) * s), bit-identical to hqq_hip_dequantize / Quantizer.dequantize. */
+#define HQQ_OPT_META_SCALABLE  2u   /* the caller asserts hqq_hip_meta_check() returned 0 failing groups for EVERY layer of the call: the
+                                       exact rebuild may then use its three-op form (same bits, ~25 % less VALU work).  fp16. */
+#define HQQ_OPT_GEMV3_ROWWISE  4u   /* 3-bit decode: force the row-per-wave kernel (tests / tuning) */
+#define HQQ_OPT_GEMV3_SLABS    8u   /* 3-bit decode: force the slab-sharing kernel (needs workspace) */
+#define HQQ_OPT_GEMM_REGTILE  16u   /* prefill: the register-tile variant of the fused GEMM */
+#define HQQ_OPT_SKINNY_KS(n) ((uint32_t)(n) << 24)   /* 5..64 rows: force n K-splits (tuning; 0 = built-in rule) */
+#define HQQ_OPT_ALL (31u | (255u << 24))
+/* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
+ * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
+ * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.
+ * scale / zero as in hqq_hip_dequantize, axis = 1, fp16.  (No reference counterpart: the reference always does two torch ops.) */
+int hqq_hip_meta_check(int nbits, const void* scale, const void* zero, int64_t N, int64_t K, int64_t group_size, int dtype,
+                       uint32_t* fail_count, void* stream);
+size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts);
 int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                 void* stream);
 /* Horizontal fusion of up to HQQ_GEMV_MAX_GROUP layers that consume the SAME activation rows x[M,K] (q/k/v, gate/up,
  * experts of one token ...): one launch streams all their packed rows; layer i writes y[i][M, N[i]].  Every per-layer
  * argument is a host array of n_layers device pointers / sizes (read during the call, not kept); bias may be NULL or
@@ -100,15 +123,8 @@ int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, co
  * (The reference has no counterpart: HQQLinear.forward is per layer, quantize.py:880-898.) */
 int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
                          const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
-                         int64_t M, int64_t K, int64_t group_size, int dtype, void* stream);
-/* Arithmetic of the decode path (process-wide, not thread-safe; set it before launching work):
- *   HQQ_GEMV_EXACT    (default) every weight is rebuilt as round16(round16(q - z) * s) — bit-identical to
- *                     hqq_hip_dequantize / Quantizer.dequantize — and contracted on the matrix cores with fp32 accumulation.
- *   HQQ_GEMV_FACTORED the group affine map is factored out of the dot product and applied in fp32 (no per-weight fp16
- *                     rounding; results differ from the reference by less than its own weight-rounding noise). M <= 8. */
-enum { HQQ_GEMV_EXACT = 0, HQQ_GEMV_FACTORED = 1 };
-int hqq_hip_set_gemv_mode(int mode);
-int hqq_hip_get_gemv_mode(void);
+                         int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* ---------------------------------------------------------------------------------------------
  * The persistent decode engine: one launch walks a whole list of DEPENDENT stages, one activation row (bs = 1).
  * A stage is what one hqq_hip_gemv_grouped call computes — up to HQQ_GEMV_MAX_GROUP layers reading the same x[1,K] — and stage
@@ -124,7 +140,6 @@ int hqq_hip_get_gemv_mode(void);
  * hqq_hip_decode_plan_status_offset() of the device buffer is 0 after a run in which every hand-off completed (else 1 + the
  * stage whose wait gave up: the outputs are then undefined).  One run of a given device plan at a time.
  * ------------------------------------------------------------------------------------------- */
-#define HQQ_OPT_META_SCALABLE 2u   /* every layer passed hqq_hip_meta_check: the three-op exact weight rebuild may be used */
 typedef struct hqq_hip_decode_stage {
   const void* x;            /* [1, K] activations of this stage (may be an output buffer of an earlier stage) */
   int64_t K;
@@ -145,9 +160,11 @@ int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t plan_bytes,
 size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
 
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* stream);
+/* hqq_hip_gemv for M it covers, hqq_hip_gemm otherwise; workspace as hqq_hip_gemv (hqq_hip_gemv_workspace_bytes with the same M) */
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                    void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, void* stream);
+                    void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Quantizer.quantize + optimize_weights_proximal_legacy + BitPack.pack_* in one call

@@ -35,8 +35,28 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_quantize_workspace_bytes(1024, 64, 20) > 0
     assert L.hqq_hip_quantize_workspace_bytes(1000, 64, 20) == 0
     # nbits=5 has no container of its own (the reference stores it in 8 bits): reported, never silently computed elsewhere
-    rc = L.hqq_hip_gemv(5, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, None)
+    rc = L.hqq_hip_gemv(5, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, 0, None, 0, None)
     assert rc == -4 and b"not covered" in L.hqq_hip_last_error()
+    # unknown option bits are an argument error, not ignored
+    assert L.hqq_hip_gemv(4, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, 1 << 10, None, 0, None) == -2
+    # workspace sizes are pure host arithmetic: a bs=1 launch needs none; a small layer at 32 rows splits K and does
+    import ctypes
+    N1 = (ctypes.c_int64 * 1)(4096)
+    assert L.hqq_hip_gemv_workspace_bytes(4, 1, N1, 1, 4096, 64, 1, 0) == 0
+    assert L.hqq_hip_gemv_workspace_bytes(4, 1, N1, 32, 4096, 64, 1, 0) > 256 * 1024
+    # the decode plan: sizes and argument checks on the host
+    assert L.hqq_hip_decode_plan_bytes(0) == 0 and L.hqq_hip_decode_plan_bytes(128) == 256 + 128 * 256 + 1280
+
+
+def test_the_library_owns_no_device_memory_and_reads_no_environment():
+    """boundary rule of include/hqq_hip.h: the caller owns every buffer, nothing is configured through the environment"""
+    import subprocess
+    from hqq_amd import _C
+    if not os.path.exists(_C.LIB_PATH):
+        _C.build()
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _C.LIB_PATH], capture_output=True, text=True).stdout
+    for banned in (r"hipMalloc", r"hipFree", r"hipDeviceSynchronize", r"hipStreamSynchronize", r"getenv", r"hipMemset@", r"hipMemcpy"):
+        assert not re.search(r"\b" + banned, syms), banned   # (hipMemsetAsync — stream-ordered — is what the engine's sync words use)
 
 
 def test_ops_refuse_cpu_tensors():

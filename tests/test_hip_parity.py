@@ -459,7 +459,7 @@ def test_gemv_3bit_vs_oracle(ops, oracle, M, NK):
 
 @pytest.mark.parametrize("M", [1, 3, 4])
 @pytest.mark.parametrize("NK", [(512, 1024), (1001, 4096), (64, 11008), (4096, 4096), (173, 2048)])
-def test_gemv_3bit_slab_sharing_kernel(ops, oracle, M, NK, monkeypatch):
+def test_gemv_3bit_slab_sharing_kernel(ops, oracle, M, NK):
     """the kernel large 3-bit launches take (gemv3s.hip: each packed word loaded once for all ten slabs, per-task partial sums
     added in a fixed order by a second launch), forced here on small layers: exact weights (one-hot probes bit-identical to the
     dequant kernel), outputs within tolerance of the oracle / of the row-per-wave kernel, grouped == single, reproducible bits"""
@@ -470,28 +470,26 @@ def test_gemv_3bit_slab_sharing_kernel(ops, oracle, M, NK, monkeypatch):
     x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half().cuda()
     bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half().cuda() if M % 2 else None
     Pd, sd, zd = dev(P), s.cuda(), z.cuda()
-    monkeypatch.setenv("HQQ_HIP_GEMV3_V1", "1")
-    y1 = ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits).clone()
-    monkeypatch.delenv("HQQ_HIP_GEMV3_V1")
-    monkeypatch.setenv("HQQ_HIP_GEMV3_V2", "1")
-    y2 = ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits).clone()
+    y1 = ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits, opts=ops.OPT_GEMV3_ROWWISE).clone()
+    SLABS = ops.OPT_GEMV3_SLABS
+    y2 = ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits, opts=SLABS).clone()
     torch.testing.assert_close(y2.float(), y1.float(), rtol=1e-3, atol=1e-3)
     Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, gs, nbits)
     want = x.float() @ Wdev.float().t() + (0 if bias is None else bias.float())
     torch.testing.assert_close(y2.float(), want, rtol=1e-3, atol=1e-3)
     for k in ((3 * K) // 7, 0, 1, 2, 3, 63, 64, K - 1):
         e = torch.zeros(M, K, dtype=torch.float16, device="cuda"); e[M - 1, k] = 1.0
-        ye = ops.gemv(e, Pd, sd, zd, None, N, K, gs, nbits)
+        ye = ops.gemv(e, Pd, sd, zd, None, N, K, gs, nbits, opts=SLABS)
         assert torch.equal(ye[M - 1], Wdev[:, k])
         if M > 1: assert torch.count_nonzero(ye[0]) == 0
-    # grouped launch (layers of different N share the task space and the scratch) == single launches; same bits every time
+    # grouped launch (layers of different N share the task space and the workspace) == single launches; same bits every time
     U2, s2, z2 = _random_layer(N + 37, K, gs, nbits, seed=N + K + 6)
     P2 = dev(oracle.pack(nbits, U2.numpy()))
     layers = [(Pd, sd, zd, bias, N), (P2, s2.cuda(), z2.cuda(), None, N + 37)]
-    ys = [t.clone() for t in ops.gemv_grouped(x, layers, K, gs, nbits)]
+    ys = [t.clone() for t in ops.gemv_grouped(x, layers, K, gs, nbits, opts=SLABS)]
     assert torch.equal(ys[0], y2)
-    assert torch.equal(ys[1], ops.gemv(x, P2, s2.cuda(), z2.cuda(), None, N + 37, K, gs, nbits))
-    for _ in range(5): assert torch.equal(ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits), y2)
+    assert torch.equal(ys[1], ops.gemv(x, P2, s2.cuda(), z2.cuda(), None, N + 37, K, gs, nbits, opts=SLABS))
+    for _ in range(5): assert torch.equal(ops.gemv(x, Pd, sd, zd, bias, N, K, gs, nbits, opts=SLABS), y2)
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
@@ -566,8 +564,8 @@ def test_gemm_vs_oracle(ops, oracle, nbits, M, N, K):
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
-def test_gemm_register_tile_variant(ops, nbits, monkeypatch):
-    """opt-in register-tile kernel (HQQ_HIP_GEMM_RT=1: weights dequantised straight into MFMA operands, only x through LDS) vs the
+def test_gemm_register_tile_variant(ops, nbits):
+    """opt-in register-tile kernel (HQQ_OPT_GEMM_REGTILE: weights dequantised straight into MFMA operands, only x through LDS) vs the
     default LDS-staged kernel: same exact weights, different fp32 summation order; ragged N and M exercise the masked edges"""
     for (M, N, K) in ((16384, 4096, 512), (8200, 4112, 256)):
         U, s, z = _random_layer(N, K, 64, nbits, seed=3)
@@ -575,14 +573,10 @@ def test_gemm_register_tile_variant(ops, nbits, monkeypatch):
         x = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).half().cuda()
         bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).half().cuda()
         base = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
-        monkeypatch.setenv("HQQ_HIP_GEMM_RT", "1")
-        rt = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits)
-        monkeypatch.delenv("HQQ_HIP_GEMM_RT")
+        rt = ops.gemm(x, P, s.cuda(), z.cuda(), bias, N, K, 64, nbits, opts=ops.OPT_GEMM_REGTILE)
         torch.testing.assert_close(rt.float(), base.float(), rtol=1e-3, atol=2e-3)
         e = torch.zeros_like(x); e[torch.arange(M, device="cuda"), torch.arange(M, device="cuda") * 5 % K] = 1.0   # one-hot rows: exact columns
-        monkeypatch.setenv("HQQ_HIP_GEMM_RT", "1")
-        rt1 = ops.gemm(e, P, s.cuda(), z.cuda(), None, N, K, 64, nbits)
-        monkeypatch.delenv("HQQ_HIP_GEMM_RT")
+        rt1 = ops.gemm(e, P, s.cuda(), z.cuda(), None, N, K, 64, nbits, opts=ops.OPT_GEMM_REGTILE)
         assert torch.equal(rt1, ops.gemm(e, P, s.cuda(), z.cuda(), None, N, K, 64, nbits))
 
 

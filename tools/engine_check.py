@@ -39,12 +39,11 @@ def chain_case(nbits, dims, grid, sub, bias=False):
     torch.cuda.synchronize()
     st = plan.status()
     # reference: the per-launch kernels, stage after stage
-    ops.set_gemv_mode(0)
     xr = x0
     worst = 0.0
     for si, (K, Ns) in enumerate(dims):
         Ls = layers[si]
-        outs = ops.gemv_grouped(xr, [(L[0], L[1], L[2], L[3], L[4]) for L in Ls], K, 64, nbits)
+        outs = ops.gemv_grouped(xr, [(L[0], L[1], L[2], L[3], L[4]) for L in Ls], K, 64, nbits, opts=0)
         for L, o in zip(Ls, outs):
             got = L[5].float()
             ref = o.float()
@@ -78,13 +77,15 @@ def stack_case(nbits, blocks, sub):
     plan = ops.DecodePlan(stages, nbits, opts=ops.OPT_META_SCALABLE if sub else 0)
     print(f"stack nbits={nbits} blocks={blocks}: setup {time.time()-t0:.1f}s, plan {plan.nbytes} B", flush=True)
 
+    lopts = 0
+
     def launches():
         for blk in Ls:
             for g in GROUPS:
                 K = blk[g[0]][1]
-                ops.gemv_grouped(xs[K], [(blk[n][2], blk[n][3], blk[n][4], None, blk[n][0]) for n in g], K, 64, nbits, outs=out_l[g])
+                ops.gemv_grouped(xs[K], [(blk[n][2], blk[n][3], blk[n][4], None, blk[n][0]) for n in g], K, 64, nbits, outs=out_l[g], opts=lopts)
 
-    ops.set_gemv_mode(2 if sub else 0)
+    lopts = ops.OPT_META_SCALABLE if sub else 0
     plan.run(); launches(); torch.cuda.synchronize()
     st = plan.status()
     worst = 0.0

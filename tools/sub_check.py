@@ -15,11 +15,11 @@ for nbits in (4, 2, 8, 1):
         s, z = s.half(), z.half()
         for M in (1, 2, 4):
             x = torch.randn(M, K, device="cuda").half()
-            ops.set_gemv_mode(0); y0 = ops.gemv(x, Wq, s, z, None, N, K, gs, nbits)
-            ops.set_gemv_mode(2); y2 = ops.gemv(x, Wq, s, z, None, N, K, gs, nbits)
+            y0 = ops.gemv(x, Wq, s, z, None, N, K, gs, nbits, opts=0)
+            y2 = ops.gemv(x, Wq, s, z, None, N, K, gs, nbits, opts=ops.OPT_META_SCALABLE)
             torch.cuda.synchronize()
             neq = int((y0.view(torch.int16) != y2.view(torch.int16)).sum())
-            print(f"nbits={nbits} N={N} K={K} gs={gs} M={M}: outputs differing {neq} of {y0.numel()}  zmin={float(z.abs().min()):.4g}", flush=True)
+            print(f"nbits={nbits} N={N} K={K} gs={gs} M={M}: outputs differing {neq} of {y0.numel()}  zmin={float(z.abs().min()):.4g}  meta_check says scalable={ops.meta_scalable(s, z, N, K, gs, nbits)}", flush=True)
 # one-hot probes: every weight of a small layer, both modes, vs the dequantise kernel
 for nbits in (4, 2, 8):
     N, K = 64, 1024
@@ -28,11 +28,9 @@ for nbits in (4, 2, 8):
     s, z = s.half(), z.half()
     Wd = ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, 64, nbits)
     bad = 0
-    ops.set_gemv_mode(2)
     for k0 in range(0, K, 4):
         e = torch.zeros(4, K, dtype=torch.float16, device="cuda")
         for i in range(4): e[i, k0 + i] = 1.0
-        y = ops.gemv(e, Wq, s, z, None, N, K, 64, nbits)
+        y = ops.gemv(e, Wq, s, z, None, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE)
         bad += int((y.view(torch.int16) != Wd[:, k0:k0 + 4].t().contiguous().view(torch.int16)).sum())
     print(f"one-hot nbits={nbits}: {bad} of {N*K} weights differ from hqq_hip_dequantize", flush=True)
-ops.set_gemv_mode(0)

@@ -1,5 +1,5 @@
 """3-bit decode launches of a Llama-2-7B block: device us per launch for the slab-sharing kernel (gemv3s.hip) and the
-row-per-wave kernel (gemv3.hip, HQQ_HIP_GEMV3_V1=1); graph replay over a pool of distinct layers.  Usage: python tools/sweep_int3.py [M ...]"""
+row-per-wave kernel (gemv3.hip, opts=OPT_GEMV3_ROWWISE); graph replay over a pool of distinct layers.  Usage: python tools/sweep_int3.py [M ...]"""
 import os
 import sys
 
@@ -44,16 +44,12 @@ def main():
             x = torch.randn(M, K, device="cuda", dtype=torch.float16)
             outs = [torch.empty(M, N, device="cuda", dtype=torch.float16) for N, _ in shapes]
 
-            def sweep():
+            def sweep(opts):
                 for Ls in pool:
-                    ops.gemv_grouped(x, [(W, s, z, None, N) for (W, s, z), (N, _) in zip(Ls, shapes)], K, 64, 3, outs=outs)
-            os.environ.pop("HQQ_HIP_GEMV3_V1", None)
-            os.environ["HQQ_HIP_GEMV3_V2"] = "1"     # force each kernel in turn (the library picks by launch size otherwise)
-            t2 = timed(sweep, pool_n)
-            os.environ.pop("HQQ_HIP_GEMV3_V2", None)
-            os.environ["HQQ_HIP_GEMV3_V1"] = "1"
-            t1 = timed(sweep, pool_n)
-            os.environ.pop("HQQ_HIP_GEMV3_V1", None)
+                    ops.gemv_grouped(x, [(W, s, z, None, N) for (W, s, z), (N, _) in zip(Ls, shapes)], K, 64, 3, outs=outs, opts=opts)
+            # force each kernel in turn (the library picks by launch size otherwise)
+            t2 = timed(lambda: sweep(ops.OPT_GEMV3_SLABS), pool_n)
+            t1 = timed(lambda: sweep(ops.OPT_GEMV3_ROWWISE), pool_n)
             print(f"{name:8s} M={M}  {nbytes / 1e6:6.1f} MB   slab-sharing {t2:6.2f} us ({nbytes / t2 / 1e6:5.2f} TB/s)   row-per-wave {t1:6.2f} us ({nbytes / t1 / 1e6:5.2f} TB/s)", flush=True)
         del pool
 

@@ -1,4 +1,4 @@
-"""K-split sweep for the skinny GEMM (HQQ_HIP_SKINNY_KS overrides the built-in rule): device us per launch, graph replay over a
+"""K-split sweep for the skinny GEMM (opts=OPT_SKINNY_KS(n) overrides the built-in rule): device us per launch, graph replay over a
 pool of distinct layers (> 256 MiB), int4 gs=64 fp16.  Usage: python tools/sweep_ks.py [M ...]"""
 import os
 import sys
@@ -43,16 +43,13 @@ def main():
             x = torch.randn(M, K, device="cuda", dtype=torch.float16)
             outs = [torch.empty(M, N, device="cuda", dtype=torch.float16) for N, _ in shapes]
 
-            def sweep():
+            def sweep(ks):
                 for Ls in pool:
-                    ops.gemv_grouped(x, [(W, s, z, None, N) for (W, s, z), (N, _) in zip(Ls, shapes)], K, 64, 4, outs=outs)
+                    ops.gemv_grouped(x, [(W, s, z, None, N) for (W, s, z), (N, _) in zip(Ls, shapes)], K, 64, 4, outs=outs, opts=ops.OPT_SKINNY_KS(ks))
             row = []
             for ks in (0, 1, 2, 3, 4, 6, 8, 11, 16):
-                if ks: os.environ["HQQ_HIP_SKINNY_KS"] = str(ks)
-                else: os.environ.pop("HQQ_HIP_SKINNY_KS", None)
                 if ks > K // 256: continue
-                row.append(f"{'rule' if not ks else ks}:{timed(sweep, pool_n):6.2f}")
-            os.environ.pop("HQQ_HIP_SKINNY_KS", None)
+                row.append(f"{'rule' if not ks else ks}:{timed(lambda: sweep(ks), pool_n):6.2f}")
             print(f"{name:8s} M={M:3d}  " + "  ".join(row), flush=True)
         del pool
 
