@@ -194,7 +194,8 @@ class HQQLinear(nn.Module):
         shell = nn.Linear(1, 1, bias=False)
         shell.in_features, shell.out_features = weight.shape[1], weight.shape[0]
         shell.weight.data = weight
-        shell.bias = bias
+        # nn.Module refuses a plain Tensor in a registered parameter slot (the reference assigns it and raises, quantize.py:478)
+        shell.bias = None if bias is None else nn.Parameter(bias, requires_grad=False)
         return cls(shell, quant_config=quant_config, compute_dtype=compute_dtype, device=device, del_orig=del_orig)
 
     def extra_repr(self) -> str:

@@ -61,7 +61,7 @@ struct alignas(256) EnStage {
   int prow_end[EN_MAXL];   // end (exclusive) of layer i's packed rows in the stage's concatenated row space; unused entries repeat the last
   int K, G, spr /* steps per packed row */, total_prow;
   int rows_q, rows_rem;    // total_prow = nwg * rows_q + rows_rem: workgroup c owns rows_q + (c < rows_rem) rows
-  uint32_t spr_inv;        // ceil(2^32 / spr): t / spr = umulhi(t, spr_inv) for the step counts that occur
+  uint32_t spr_inv;        // ceil(2^32 / spr) (spr > 1): t / spr = umulhi(t, spr_inv) for the step counts that occur (en_div)
   int pad_;
 };
 static_assert(sizeof(EnStage) == 256, "one descriptor per 256-byte record");
@@ -113,6 +113,10 @@ __device__ __forceinline__ EnGeo en_geo(en_stage_p st, int c) {
   g.nrows = rows_q + (c < rows_rem ? 1 : 0);
   g.S = g.nrows * st->spr;
   return g;
+}
+// t / spr for the step counts that occur (spr_inv = ceil(2^32 / spr) does not fit 32 bits for spr = 1)
+__device__ __forceinline__ int en_div(int t, int spr, uint32_t spr_inv) {
+  return spr == 1 ? t : static_cast<int>(__umulhi(static_cast<uint32_t>(t), spr_inv));
 }
 __device__ __forceinline__ void en_range(int S, int w, int& a, int& b) {
   const int qs = S / EN_NSW, rs = S - qs * EN_NSW;
@@ -204,8 +208,22 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       EN_TS(s, 0)
       lds_barrier();   // B1: partials of stage s are in LDS
       EN_TS(s, 1)
+#ifdef EN_LAB_DUMP
+      if (a.ts && c == 0 && s == 0) {   // lab: LDS behind the x buffer, before the reduction
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(smem + a.part_off);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(a.ts);
+        for (int i = lane; i < 4096; i += 64) dst[i] = src[i];
+      }
+#endif
       reduce_stage(g);
       lds_barrier();   // B1': ybuf complete
+#ifdef EN_LAB_DUMP
+      if (a.ts && c == 0 && s == 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(smem + a.tab_off);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(a.ts) + 4096;
+        for (int i = lane; i < 256; i += 64) dst[i] = src[i];
+      }
+#endif
       // ---- publish this chunk of y (write-through), then arrive ----
       const int nout = g.nrows * PER;
       const int pe0 = st->prow_end[0], pe1 = st->prow_end[1], pe2 = st->prow_end[2];
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
       en_range(g.S, wave, ra, rb);
       if (rb > ra) {
         iK = ist->K; iG = ist->G; ispr = ist->spr;
-        const int rl = static_cast<int>(__umulhi(static_cast<uint32_t>(ra), ist->spr_inv));
+        const int rl = en_div(ra, ispr, ist->spr_inv);
         it = ra; it_end = rb;
         ikstep = ra - rl * ispr;
         irow = g.r0 + rl;
@@ -354,12 +372,12 @@ __global__ __launch_bounds__(EN_WAVES * 64) void decode_engine_kernel(const EnAr
     const uint32_t inv = st->spr_inv;
     ct = ra; ct_end = rb;
     cany = rb > ra;
-    crow = static_cast<int>(__umulhi(static_cast<uint32_t>(ra), inv));
+    crow = en_div(ra, cspr, inv);
     ckstep = ra - crow * cspr;
     frow = crow;
     if (lane == 0) {
       tab[wave] = rb > ra ? frow : 1;
-      tab[16 + wave] = rb > ra ? static_cast<int>(__umulhi(static_cast<uint32_t>(rb - 1), inv)) : 0;
+      tab[16 + wave] = rb > ra ? en_div(rb - 1, cspr, inv) : 0;
     }
   };
   auto flush = [&]() {   // the row's partial sums of this wave: the tile diagonals, 16 floats per slab

@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256) void gemv3s_finish_kernel(const S3Args a) {
 template <int M>
 static int s3_launch(S3Args& a, int max_n, void* ws, size_t ws_bytes, hipStream_t st) {
   const size_t lds = static_cast<size_t>(M) * (a.K + S3_ROWS * 64) * 2;
-  const size_t need = static_cast<size_t>(a.total_tasks) * 10 * 2 * M * sizeof(float);
+  const size_t need = WS_COUNTER_BYTES + static_cast<size_t>(a.total_tasks) * 10 * 2 * M * sizeof(float);   // (the head belongs to the split-K counters)
   if (!ws || ws_bytes < need) { set_error("hqq_hip_gemv(3-bit): the slab-sharing kernel parks %zu bytes of partial sums in the workspace (hqq_hip_gemv_workspace_bytes), got %zu", need, ws ? ws_bytes : size_t(0)); return HQQ_ERR_WORKSPACE; }
   if (!aligned16(ws)) { set_error("hqq_hip_gemv: workspace must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-  a.part = static_cast<float*>(ws);
+  a.part = reinterpret_cast<float*>(static_cast<char*>(ws) + WS_COUNTER_BYTES);
   int n_cus = 256, dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0) n_cus = 256;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
@@ -353,7 +353,7 @@ size_t gemv3s_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t
   const int64_t G = K / 64;
   int64_t tasks = 0;
   for (int i = 0; i < n_layers; ++i) tasks += ((N[i] * G + 9) / 10 + S3_ROWS - 1) / S3_ROWS;
-  return static_cast<size_t>(tasks) * 10 * 2 * static_cast<size_t>(M) * sizeof(float);
+  return WS_COUNTER_BYTES + static_cast<size_t>(tasks) * 10 * 2 * static_cast<size_t>(M) * sizeof(float);
 }
 
 int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,

@@ -73,6 +73,11 @@ template <> struct CD<bf16_t> {
   static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v.v); }
 };
 
+// Layout of the caller-owned decode workspace (hqq_hip_gemv_workspace_bytes): [arrival counters | fp32 partial sums].  The head holds
+// one int per (panel, row group) of a split-K launch (skinny.hip) and must be zero whenever a call starts — every kernel that uses
+// counters leaves them zero — so kernels that only park partial sums (gemv3s.hip) keep out of it.
+constexpr size_t WS_COUNTER_BYTES = size_t(256) << 10;
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace hqq

@@ -529,7 +529,7 @@ static int sk_num_cus() {
 // Workspace of the split-K launches (caller-owned, hqq_hip_gemv_workspace_bytes): [arrival counters | fp32 partial tiles].
 // The counters must read zero when a call starts; every call leaves them zero again (the finishing split resets its counter),
 // so the caller clears the workspace once, when it allocates it.
-constexpr size_t SK_CNT_BYTES = size_t(256) << 10;   // head of the workspace: one int per (panel, row group), 64 Ki counters
+constexpr size_t SK_CNT_BYTES = WS_COUNTER_BYTES;   // head of the workspace: one int per (panel, row group), 64 Ki counters
 
 // K splits (shape-dependent only, never M: a row's result must not depend on the batch it is computed in).  Measured on 7B / 70B
 // shapes: about one workgroup per CU and >= 8 chunks per workgroup wins — every split pays the prologue (first data ~5 us after

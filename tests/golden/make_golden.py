@@ -18,6 +18,10 @@ Fixture families
                              HQQLinear(...).dequantize() and .forward(x) for fp16 / bf16 / fp32
   cfg1_1024_<nbits>b.npz     BASELINE.json configs[0]: nn.Linear(1024,1024) seed 0, gs=64 axis=1;
                              W itself is regenerated from the seed by the tests (sha256 stored)
+  cfg2_4096_<nbits>b.npz     BASELINE.json configs[1] at full size: 4096x4096, W ~ N(0, 0.02^2) fp16-valued, seed 0:
+                             sha256 of the reference's packed W_q / zero / scale (+ heads), forward(x) for fp16
+  refsd_cfg1_4b.npz          the reference's own HQQLinear.state_dict() (encoded, quantize.py:617-680) of the configs[0]
+                             layer at 4 bits, fp16 — the wire format hqq_amd.HQQLinear.load_state_dict must accept
 """
 import hashlib
 import json
@@ -179,6 +183,47 @@ def main():
                 arrs[f"y_{cdn}"] = raw(layer.forward(x32.to(cd)))
             arrs[f"Wdeq_sha256_{cdn}"] = np.frombuffer(sha(raw(layer.dequantize())).encode(), np.uint8)
         save(f"cfg1_1024_{nbits}b", **arrs)
+
+    # ---------------- BASELINE.json configs[1] at full size: hashes of what the reference produces ----------------
+    torch.manual_seed(0)
+    W2 = (torch.randn(4096, 4096) * 0.02).half().float()
+    torch.manual_seed(1)
+    x2 = torch.randn(1, 4096)
+    for nbits in (4, 3, 2):
+        Wq, meta = Quantizer.quantize(W2.clone(), nbits=nbits, group_size=64, axis=1, round_zero=(nbits == 4),
+                                      optimize=True, device="cpu", compute_dtype=torch.float16)
+        arrs = {"W_sha256": np.frombuffer(sha(W2.numpy()).encode(), np.uint8), "W_head": W2.numpy()[:2, :8].copy(),
+                "Wq_sha256": np.frombuffer(sha(Wq.numpy()).encode(), np.uint8), "Wq_head": Wq.numpy()[:4, :16].copy(),
+                "scale_sha256": np.frombuffer(sha(meta["scale"].float().numpy()).encode(), np.uint8),
+                "zero_sha256": np.frombuffer(sha(meta["zero"].float().numpy()).encode(), np.uint8),
+                "scale_head": meta["scale"].float().numpy().reshape(-1)[:16].copy(), "zero_head": meta["zero"].float().numpy().reshape(-1)[:16].copy(),
+                "x_f32": x2.numpy()}
+        lin = torch.nn.Linear(4096, 4096, bias=False)
+        lin.weight.data = W2.clone()
+        layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=torch.float16, device="cpu")
+        assert np.array_equal(layer.W_q.data.numpy(), Wq.numpy())
+        with torch.no_grad():
+            arrs["y_f16"] = raw(layer.forward(x2.half()))
+        arrs["Wdeq_sha256_f16"] = np.frombuffer(sha(raw(layer.dequantize())).encode(), np.uint8)
+        save(f"cfg2_4096_{nbits}b", **arrs)
+
+    # ---------------- the reference's state_dict (wire format) of the configs[0] layer ----------------
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(1024, 1024, bias=True)
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cpu")
+    sd = layer.state_dict()
+    arrs = {}
+    for k, v in sd.items():
+        assert isinstance(v, torch.Tensor), (k, type(v))
+        arrs["sd__" + k] = raw(v)
+        arrs["dt__" + k] = np.frombuffer(str(v.dtype).encode(), np.uint8)
+    torch.manual_seed(1)
+    x32 = torch.randn(3, 1024)
+    arrs["x_f32"] = x32.numpy()
+    with torch.no_grad():
+        arrs["y_f16"] = raw(layer.forward(x32.half()))
+    arrs["Wdeq_sha256_f16"] = np.frombuffer(sha(raw(layer.dequantize())).encode(), np.uint8)
+    save("refsd_cfg1_4b", **arrs)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -103,8 +103,7 @@ def test_pack_unpack_roundtrip_and_oracle(ops, oracle, nbits, shape):
     U = torch.randint(0, 2 ** nbits, shape, generator=g, dtype=torch.uint8)
     P = ops.pack(nbits, U.cuda())
     assert torch.equal(ops.unpack(nbits, P)[: shape[0]].cpu(), U)
-    if U.numel() <= 1 << 22:
-        assert np.array_equal(P.cpu().numpy(), oracle.pack(nbits, U.numpy()))
+    assert np.array_equal(P.cpu().numpy(), oracle.pack(nbits, U.numpy()))   # every size: the oracle packs 16 M levels in a fraction of a second
 
 
 def test_pack_empty(ops):
@@ -443,12 +442,10 @@ def test_gemv_3bit_vs_oracle(ops, oracle, M, NK):
     Pd, sd, zd = dev(P), s.cuda(), z.cuda()
     y = ops.gemv(x.cuda(), Pd, sd, zd, None if bias is None else bias.cuda(), N, K, gs, nbits)
     Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, gs, nbits)
-    if N * K <= 1 << 22:
-        Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
-        yo, _ = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
-        want = torch.from_numpy(yo.astype(np.float32))
-    else:
-        want = (x.cuda().float() @ Wdev.float().t() + (0 if bias is None else bias.cuda().float())).cpu()
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)   # the oracle at every size (a 4096 x 4096 forward takes ~50 ms)
+    assert np.array_equal(Wdev.cpu().numpy().view(np.uint16), Wd.view(np.uint16))
+    yo, _ = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
+    want = torch.from_numpy(yo.astype(np.float32))
     torch.testing.assert_close(y.float().cpu(), want, rtol=1e-3, atol=1e-3)
     for k in ((3 * K) // 7, 0, K - 1):
         e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, k] = 1.0
@@ -672,20 +669,20 @@ def test_forward_unsupported_is_loud(ops):
 # ------------------------------------------------------------------------------------------------
 # Quantizer.quantize (solver + pack)
 # ------------------------------------------------------------------------------------------------
-def _check_quant(ops, W, nbits, gs, want_packed, want_scale, want_zero, max_frac=2e-5):
+def _check_quant(ops, W, nbits, gs, want_packed, want_scale, want_zero):
+    """the HIP solver against what the reference's CPU (float32) path produced: every level, every zero-point bit, every scale bit"""
     Wq, s, z, info = ops.quantize(dev(W), nbits=nbits, group_size=gs, round_zero=(nbits == 4), return_info=True)
     torch.cuda.synchronize()
-    want_u = None
     # compare levels, not bytes, so a single differing level counts once
     got_u = ops.unpack(ops.PACK_BITS[nbits], Wq).cpu().numpy()[: W.size // gs]
     want_u = ops.unpack(ops.PACK_BITS[nbits], dev(want_packed)).cpu().numpy()[: W.size // gs]
-    diff = got_u.astype(np.int32) - want_u.astype(np.int32)
-    nbad = int((diff != 0).sum())
-    assert np.abs(diff).max() <= 1
-    # documented residual: |e|^(p-1) rounding (ATen Sleef powf <= 1 ulp vs correctly rounded here)
-    assert nbad <= max(2, int(max_frac * W.size)), f"{nbad} of {W.size} levels differ"
-    np.testing.assert_allclose(s.cpu().numpy().reshape(-1), want_scale.reshape(-1), rtol=0, atol=0)   # scale is never touched by the solver
-    np.testing.assert_allclose(z.cpu().numpy().reshape(-1), want_zero.reshape(-1), rtol=2e-6, atol=2e-6)
+    nbad = int((got_u != want_u).sum())
+    zb, zw = z.cpu().numpy().reshape(-1).view(np.uint32), np.ascontiguousarray(want_zero, dtype=np.float32).reshape(-1).view(np.uint32)
+    sb, sw = s.cpu().numpy().reshape(-1).view(np.uint32), np.ascontiguousarray(want_scale, dtype=np.float32).reshape(-1).view(np.uint32)
+    nz, ns = int((zb != zw).sum()), int((sb != sw).sum())
+    print(f"solver vs reference: {nbad} of {W.size} levels, {nz} of {zb.size} zero-points, {ns} scales differ; iterations {info.cpu().numpy().tolist()}")
+    assert nbad == 0 and nz == 0 and ns == 0, f"{nbad} levels / {nz} zero-points / {ns} scales differ from the reference"
+    assert np.array_equal(Wq.cpu().numpy(), want_packed)
     return nbad, info.cpu().numpy()
 
 
@@ -730,7 +727,7 @@ def test_quantize_other_supported_bits(ops, oracle, nbits):
     o = oracle.quantize(W.numpy(), nbits=nbits, group_size=64)
     assert int(o["Wq"].max()) <= round(2 ** nbits - 1)
     container = ops.PACK_BITS[nbits]
-    _check_quant(ops, W.numpy(), nbits, 64, oracle.pack(container, o["Wq"]), o["scale"], o["zero"], max_frac=1e-4)
+    _check_quant(ops, W.numpy(), nbits, 64, oracle.pack(container, o["Wq"]), o["scale"], o["zero"])
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -749,7 +746,7 @@ def test_quantize_random_shapes_vs_oracle(ops, oracle, seed):
         W[rnd.randrange(N), rnd.randrange(K)] = 1e3          # an outlier
     W = W.to(rnd.choice([torch.float32, torch.float16]))
     o = oracle.quantize(W.float().numpy(), nbits=nbits, group_size=gs)
-    _check_quant(ops, W.numpy(), nbits, gs, oracle.pack(ops.PACK_BITS[nbits], o["Wq"]), o["scale"], o["zero"], max_frac=1e-4)
+    _check_quant(ops, W.numpy(), nbits, gs, oracle.pack(ops.PACK_BITS[nbits], o["Wq"]), o["scale"], o["zero"])
 
 
 def test_quantize_full_size_properties(ops):

@@ -47,7 +47,7 @@ def chain_case(nbits, dims, grid, sub, bias=False):
         for L, o in zip(Ls, outs):
             got = L[5].float()
             ref = o.float()
-            err = float(((got - ref).abs() / (1e-3 + 1e-3 * ref.abs())).max())
+            err = float(torch.nan_to_num((got - ref).abs() / (1e-3 + 1e-3 * ref.abs()), nan=1e9).max())
             worst = max(worst, err)
         xr = outs[-1]
     print(f"chain nbits={nbits} grid={grid} sub={int(sub)} bias={int(bias)} dims={dims}: status={st} worst_err/tol={worst:.3f}", flush=True)
@@ -91,7 +91,7 @@ def stack_case(nbits, blocks, sub):
     worst = 0.0
     for g in GROUPS:   # the buffers hold the LAST block's outputs
         for a, b in zip(out_e[g], out_l[g]):
-            worst = max(worst, float(((a.float() - b.float()).abs() / (1e-3 + 1e-3 * b.float().abs())).max()))
+            worst = max(worst, float(torch.nan_to_num((a.float() - b.float()).abs() / (1e-3 + 1e-3 * b.float().abs()), nan=1e9).max()))
     first = {g: [t.clone() for t in out_e[g]] for g in GROUPS}
     same = True
     for _ in range(5):
