@@ -185,7 +185,6 @@ def cpu_baseline(nbits):
     out = {"unit": "GB/s", "cores": cores, "kind": "port"}
     # ---- (1) torch eager ----
     if nbits in (8, 4, 2):
-        torch.set_num_threads(cores)
         g = torch.Generator().manual_seed(0)
         per = 8 // nbits
         R = N * K // 64
@@ -203,21 +202,29 @@ def cpu_baseline(nbits):
             W = ((tmp - zero) * scale).reshape(N, K)
             return torch.matmul(x, W.t())
 
+        # torch's fp16 CPU kernels do not scale to every core of a big host: try a few thread counts (2 s each) and keep the best
+        best = None
         with torch.no_grad():
-            fwd()
-            t0 = time.perf_counter()
-            reps = 0
-            while True:
+            for th in sorted({min(cores, 8), min(cores, 32), min(cores, 64), cores}):
+                torch.set_num_threads(th)
                 fwd()
-                reps += 1
-                el = time.perf_counter() - t0
-                if el > 10.0 or reps >= 500:
-                    break
-        t = el / reps
+                t0 = time.perf_counter()
+                reps = 0
+                while True:
+                    fwd()
+                    reps += 1
+                    el = time.perf_counter() - t0
+                    if el > 2.5 or reps >= 200:
+                        break
+                if best is None or el / reps < best[0]:
+                    best = (el / reps, th, reps, el)
+        t, th, reps, el = best
+        out["cores"] = th
         out.update({"value": round(nb / t / 1e9, 4), "ms_per_layer_call": round(t * 1e3, 3),
                     "tok_s_7b_stack_equiv": round(1.0 / (t * stack_calls), 4),
-                    "sample": f"torch {torch.__version__} CPU eager restatement of HQQBackend.PYTORCH's forward (unpack -> (W_r - zero) * scale -> matmul, fp16, "
-                              f"torch.set_num_threads({cores})) on one 4096x4096 int{nbits} gs=64 layer, bs=1: {reps} calls in {el:.1f} s"})
+                    "sample": f"torch {torch.__version__} CPU eager restatement of HQQBackend.PYTORCH's forward (unpack -> (W_r - zero) * scale -> matmul, fp16) on one "
+                              f"4096x4096 int{nbits} gs=64 layer, bs=1: {reps} calls in {el:.1f} s with torch.set_num_threads({th}) — the fastest of 8/32/64/{cores} "
+                              f"threads on this {cores}-core host"})
     # ---- (2) C oracle ----
     try:
         from oracle import hqq_oracle as orc
@@ -338,15 +345,16 @@ def main():
 
     def exchange(grp):
         """all-gather the group's shard outputs, then restore the reference's column order: rank r's packed-row block holds,
-        per slab s, output columns s * N/per + [r * n', (r + 1) * n'), n' = N / (per * P)  (hqq_amd/shard.py)"""
+        per slab s, output columns s * N/per + [r * n', (r + 1) * n'), n' = N / (per * P)  (hqq_amd.shard.unpermute,
+        the function tests/test_shard.py checks against whole layers, writing into a preallocated buffer here)"""
+        from hqq_amd import shard
         dist.all_gather_into_tensor(out_gath[grp], out_flat[grp])
         tot = sum(dimN[n] for n in grp)
         g = out_gath[grp].view(world, M * tot)
         off = 0
         for j, n in enumerate(grp):
             nl = dimN[n]
-            src = g[:, off:off + M * nl].view(world, M, per_slab, nl // per_slab)          # [P, M, per, n']
-            out_full[grp][j].view(M, per_slab, world, nl // per_slab).copy_(src.permute(1, 2, 0, 3))
+            out_full[grp][j].copy_(shard.unpermute(g[:, off:off + M * nl].reshape(world, M, nl), world * nl, nbits, world))
             off += M * nl
 
     # --streams S > 1 (study mode, not the headline): the step's launches are dealt over S parallel graph branches, i.e. the

@@ -6,7 +6,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --random-codes --no-graph > $OUT/$C.json 2> $OUT/$C.err
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-graph > $OUT/$C.json 2> $OUT/$C.err
 done
 cd $GRAFT_REPO_ROOT
 python - <<PY
