@@ -37,6 +37,8 @@ SYMBOLS = {
     "hqq_hip_quantize_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "hqq_hip_quantize": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hqq_hip_quantize_axis0": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
+                                      _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 ABI_VERSION = 2

@@ -52,16 +52,22 @@ class Quantizer:
         if group_size is not None:
             assert is_divisible(tensor.numel(), group_size), (
                 "group_size should be divisble by the total tensor dimensions. shape: " + str(tensor.shape) + ", group_size: " + str(group_size))
-        if axis != 1 or not channel_wise or not bitpack:
-            # the HIP solver covers the north-star configuration (axis=1, channel-wise groups, packed output)
-            raise NotImplementedError("hqq_amd: Quantizer.quantize on the GPU covers axis=1, channel_wise=True, bitpack=True "
-                                      f"(got axis={axis}, channel_wise={channel_wise}, bitpack={bitpack})")
+        if not channel_wise:
+            # one scale for the whole tensor (quantize.py:106-108) is only reached through the deprecated meta quantisation
+            raise NotImplementedError("hqq_amd: Quantizer.quantize covers channel_wise=True (per-group statistics), both axes")
         shape = tensor.shape
-        gs = tensor.shape[-1] if group_size is None else group_size   # one group per row (quantize.py:434-439 resolves None the same way)
+        # group_size None: one group per row (axis 1) / per column (axis 0) — HQQLinear.initialize resolves it the same way (quantize.py:434-439)
+        gs = (tensor.shape[-1] if axis == 1 else tensor.shape[0]) if group_size is None else group_size
         W = tensor.to(device)
-        W_q, scale, zero = ops.quantize(W, nbits=nbits, group_size=gs, round_zero=round_zero, optimize=optimize)
+        W_q, scale, zero = ops.quantize(W, nbits=nbits, group_size=gs, round_zero=round_zero, optimize=optimize, axis=axis)
         meta = {"nbits": nbits, "group_size": group_size, "shape": shape, "scale": scale, "zero": zero, "axis": axis,
                 "packing": Quantizer.bit_to_packing[nbits]}
+        if not bitpack:   # the levels themselves, in the input dtype (quantize.py:169): unpack what the fused solver packed
+            rows = (W.numel() // gs) if axis == 1 else gs
+            W_q = ops.unpack(Quantizer._packing_bits[meta["packing"]], W_q, dtype=tensor.dtype if tensor.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32)[:rows]
+            meta["packing"] = None
+            meta["unpack_view_dtype"], meta["view_as_float"] = None, False
+            return W_q, meta
         meta["unpack_view_dtype"] = Quantizer.unpack_view_dtype[meta["packing"]]
         meta["view_as_float"] = view_as_float
         if view_as_float:   # store the packed bytes reinterpreted as the compute dtype (quantize.py:170-173)
@@ -71,8 +77,9 @@ class Quantizer:
     @classmethod
     def dequantize(cls, W_q: Tensor, meta: dict) -> Tensor:
         """bit-unpack -> (W_q - zero) * scale -> reshape, two roundings in the compute dtype (quantize.py:183-199)"""
-        if not meta["packing"]:
-            raise NotImplementedError("hqq_amd: unpacked W_q (bitpack=False) is not covered")
+        if not meta["packing"]:   # bitpack=False: W_q holds the levels themselves (quantize.py:196) — two GPU elementwise ops, as the reference does it
+            cd = meta["compute_dtype"] if ("compute_dtype" in meta) else float16
+            return ((W_q.to(cd) - meta["zero"]) * meta["scale"]).reshape(meta["shape"])
         if meta["view_as_float"]:
             W_q = W_q.view(meta["unpack_view_dtype"])
         N, K = meta["shape"]

@@ -220,6 +220,163 @@ __global__ __launch_bounds__(256) void finalize_pack_kernel(const WT* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// axis = 0 (quantize.py:104-116 with axis=0): W viewed as [gs, C], C = numel / gs; group j is COLUMN j, statistics and the
+// solver's mean run down the rows.  One thread per group, the group's weights re-read (coalesced across the threads of a
+// wave) in every iteration; the mean restates ATen's float sum over the OUTER dimension (SumKernel.cpp vectorized_outer_sum):
+// columns below 32 * floor(C / 32) a cascade over the rows (16 rows into level 0, level 0 into level 1, ...), the remaining
+// columns the row_sum order (four interleaved cascades over rows i % 4, leftover rows, partials added in order) — see
+// oracle/hqq_oracle.c aten_col_sum_f32, which is pinned to the reference.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Cascade {   // multi_row_sum's accumulation for one output, fed one row at a time (level_step 16: row counts below 2^16)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  __device__ __forceinline__ void add(float x) {
+    a0 += x;
+    ++i;
+    if ((i & 15) == 0) {
+      a1 += a0; a0 = 0.f;
+      if ((i & 0xF0) == 0) {
+        a2 += a1; a1 = 0.f;
+        if ((i & 0xF00) == 0) { a3 += a2; a2 = 0.f; }
+      }
+    }
+  }
+  __device__ __forceinline__ float total() const { float t = a0; t += a1; t += a2; t += a3; return t; }
+};
+
+template <typename WT>
+__global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, SolveParams p, int64_t C,
+                                                     float* __restrict__ s_ws, float* __restrict__ zero_hist, double* __restrict__ err_part) {
+  extern __shared__ __attribute__((aligned(16))) double err_lds0[];   // [iters][256]
+  const int tid = threadIdx.x;
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + tid;
+  const bool live = j < C;
+  const int gs = p.gs;
+  const bool casc_col = j < (C / 32) * 32;
+  float mn = 0.f, mx = 0.f;
+  if (live) {
+    mn = mx = load_f32<WT>(W, j);
+    for (int i = 1; i < gs; ++i) { const float w = load_f32<WT>(W, static_cast<int64_t>(i) * C + j); mn = fminf(mn, w); mx = fmaxf(mx, w); }
+  }
+  const float denom = mx - mn;
+  float sc = (1.0f / denom) * p.maxv;
+  if (fabsf(denom) <= 1e-4f) sc = 1.0f;
+  sc = fminf(sc, 2e4f);
+  float ze = (-mn) * sc;
+  if (p.round_zero) ze = rintf(ze);
+  if (live) { s_ws[j] = sc; zero_hist[j] = ze; }
+  const int size4 = (gs / 4) * 4;
+  for (int it = 0; it < p.iters; ++it) {
+    double eabs = 0.0;
+    Cascade c0, c1, c2, c3;
+    float tail = 0.f;   // row_sum: rows past 4 * floor(gs / 4), added to partial 0 after its cascade
+    if (live) {
+      for (int i = 0; i < gs; ++i) {
+        const float wf = load_f32<WT>(W, static_cast<int64_t>(i) * C + j);
+        float q = wf * sc;
+        q = q + ze;
+        q = rintf(q);
+        q = fminf(fmaxf(q, 0.f), p.maxv);
+        const float wr = (q - ze) / sc;
+        const float e = wf - wr;
+        const float aa = fabsf(e);
+        eabs += static_cast<double>(aa);
+        float t;
+        if (p.lp_is_one) {
+          t = aa - p.inv_beta;
+        } else {
+          const float pw = static_cast<float>(pow(static_cast<double>(aa), p.pexp));
+          t = p.inv_beta * pw;
+          t = aa - t;
+        }
+        t = (t < 0.f) ? 0.f : t;
+        const float we = t * sgnf(e);
+        float u = wf - we;
+        u = u * sc;
+        const float t3 = q - u;
+        if (casc_col) {
+          c0.add(t3);
+        } else if (i < size4) {
+          const int k = i & 3;
+          if (k == 0) c0.add(t3); else if (k == 1) c1.add(t3); else if (k == 2) c2.add(t3); else c3.add(t3);
+        } else {
+          tail += t3;   // (at most three rows, added to partial 0 in order below: 0 + x is exact, so summing them first is the same)
+        }
+      }
+      float sum;
+      if (casc_col) {
+        sum = c0.total();
+      } else {
+        float p0 = c0.total();
+        // leftover rows go to partial 0 one by one (row_sum); `tail` holds them already added in order only when there is one —
+        // keep the reference's association: re-read is avoided by never having more than 3 and adding them individually
+        sum = p0;
+        for (int i = size4; i < gs; ++i) {
+          const float wf = load_f32<WT>(W, static_cast<int64_t>(i) * C + j);
+          float q = wf * sc; q = q + ze; q = rintf(q); q = fminf(fmaxf(q, 0.f), p.maxv);
+          const float wr = (q - ze) / sc;
+          const float e = wf - wr;
+          const float aa = fabsf(e);
+          float t;
+          if (p.lp_is_one) t = aa - p.inv_beta;
+          else { const float pw = static_cast<float>(pow(static_cast<double>(aa), p.pexp)); t = p.inv_beta * pw; t = aa - t; }
+          t = (t < 0.f) ? 0.f : t;
+          const float we = t * sgnf(e);
+          float u = wf - we; u = u * sc;
+          sum += q - u;
+        }
+        sum += c1.total();
+        sum += c2.total();
+        sum += c3.total();
+        (void)tail;
+      }
+      ze = sum / static_cast<float>(gs);
+      zero_hist[static_cast<int64_t>(it + 1) * C + j] = ze;
+    }
+    err_lds0[it * 256 + tid] = live ? eabs : 0.0;
+  }
+  __syncthreads();
+  if (tid < p.iters) {
+    double sacc = 0.0;
+    for (int t = 0; t < 256; ++t) sacc += err_lds0[tid * 256 + ((t + tid) & 255)];
+    err_part[static_cast<int64_t>(blockIdx.x) * p.iters + tid] = sacc;
+  }
+}
+
+// W_q[i, j] = clamp(rint(W*scale_j + zero_j)) packed row slab by row slab: packed row pr holds rows s * step + pr of the [gs, C] view
+template <typename WT, int NBITS>
+__global__ __launch_bounds__(256) void finalize_pack0_kernel(const WT* __restrict__ W, const float* __restrict__ s_ws, const float* __restrict__ zero_hist,
+                                                             const double* __restrict__ err_mean, void* __restrict__ Wq_out, float* __restrict__ scale_out,
+                                                             float* __restrict__ zero_out, int32_t* __restrict__ info_out, int64_t C, int gs, int step,
+                                                             float maxv, int iters) {
+  constexpr int PER = (NBITS == 3) ? 10 : 8 / NBITS;
+  int ran;
+  const int slot = pick_slot(err_mean, iters, &ran);
+  const float* zsel = zero_hist + static_cast<int64_t>(slot) * C;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // packed element (pr, j)
+  if (idx == 0 && info_out) { info_out[0] = ran; info_out[1] = slot - 1; }
+  if (idx >= static_cast<int64_t>(step) * C) return;
+  const int pr = static_cast<int>(idx / C);
+  const int64_t j = idx - static_cast<int64_t>(pr) * C;
+  const float sc = s_ws[j], ze = zsel[j];
+  if (pr == 0) { scale_out[j] = 1.0f / sc; zero_out[j] = ze; }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int s = 0; s < PER; ++s) {
+    const int i = s * step + pr;
+    if (i >= gs) continue;   // 3-bit zero padding rows
+    float q = load_f32<WT>(W, static_cast<int64_t>(i) * C + j) * sc;
+    q = q + ze;
+    q = rintf(q);
+    q = fminf(fmaxf(q, 0.f), maxv);
+    const int sh = (NBITS == 3) ? (27 - 3 * s) : NBITS * (PER - 1 - s);
+    acc |= static_cast<uint32_t>(q) << sh;
+  }
+  if constexpr (NBITS == 3) static_cast<int32_t*>(Wq_out)[idx] = static_cast<int32_t>(acc);
+  else static_cast<uint8_t*>(Wq_out)[idx] = static_cast<uint8_t>(acc);
+}
+
 static inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 struct WsLayout {
@@ -320,11 +477,86 @@ static int run_quantize(const void* W, int64_t numel, int64_t gs, int max_v, int
                                static_cast<int>(gs), static_cast<float>(max_v), iters, st);
 }
 
+template <typename WT>
+static int run_quantize_axis0(const void* W, int64_t numel, int64_t gs, int max_v, int pack_bits, int round_zero, int iters,
+                              float beta, float lp_norm, void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
+                              void* ws, hipStream_t st) {
+  const WsLayout L = ws_layout(numel, gs, iters);
+  char* base = static_cast<char*>(ws);
+  float* s_ws = reinterpret_cast<float*>(base + L.s_off);
+  float* zh = reinterpret_cast<float*>(base + L.zh_off);
+  double* ep = reinterpret_cast<double*>(base + L.ep_off);
+  double* em = reinterpret_cast<double*>(base + L.em_off);
+  const int64_t C = numel / gs;
+  SolveParams p;
+  p.R = C; p.gs = static_cast<int>(gs); p.maxv = static_cast<float>(max_v); p.round_zero = round_zero; p.iters = iters;
+  p.inv_beta = static_cast<float>(1.0 / static_cast<double>(beta));
+  p.pexp = static_cast<double>(static_cast<float>(static_cast<double>(lp_norm) - 1.0));
+  p.lp_is_one = (lp_norm == 1.0f);
+  const int64_t nblocks = (C + 255) / 256;   // (<= the axis-1 block count the workspace was sized for)
+  hipLaunchKernelGGL((solve0_kernel<WT>), dim3(static_cast<unsigned>(nblocks)), dim3(256), sizeof(double) * 256 * (iters > 0 ? iters : 1), st,
+                     static_cast<const WT*>(W), p, C, s_ws, zh, ep);
+  int rc = check_launch("hqq_hip_quantize(axis 0 solve)");
+  if (rc) return rc;
+  if (iters > 0) {
+    hipLaunchKernelGGL(reduce_err_kernel, dim3(iters), dim3(256), 0, st, ep, em, nblocks, iters, 1.0 / static_cast<double>(numel));
+    rc = check_launch("hqq_hip_quantize(reduce_err)");
+    if (rc) return rc;
+  }
+  const int per = per_of(pack_bits);
+  const int step = static_cast<int>((gs + per - 1) / per);
+  const int64_t n = static_cast<int64_t>(step) * C;
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256)), blk(256);
+#define HQQ_FIN0(NB) hipLaunchKernelGGL((finalize_pack0_kernel<WT, NB>), grid, blk, 0, st, static_cast<const WT*>(W), s_ws, zh, em, Wq_out, scale_out, zero_out, info_out, C, static_cast<int>(gs), step, static_cast<float>(max_v), iters)
+  switch (pack_bits) {
+    case 8: HQQ_FIN0(8); break;
+    case 4: HQQ_FIN0(4); break;
+    case 3: HQQ_FIN0(3); break;
+    case 2: HQQ_FIN0(2); break;
+    case 1: HQQ_FIN0(1); break;
+    default: return HQQ_ERR_NBITS;
+  }
+#undef HQQ_FIN0
+  return check_launch("hqq_hip_quantize(axis 0 finalize)");
+}
+
 }  // namespace hqq
 
 using namespace hqq;
 
 extern "C" {
+
+int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t group_size, int max_v, int pack_bits,
+                           int round_zero, int optimize, int iters, float beta, float lp_norm,
+                           void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  clear_stale_error();
+  if (numel <= 0 || group_size <= 0 || numel % group_size) {
+    set_error("hqq_hip_quantize_axis0: group_size should divide the tensor size (numel=%lld, group_size=%lld)", (long long)numel, (long long)group_size);
+    return HQQ_ERR_SHAPE;
+  }
+  if (!per_of(pack_bits)) { set_error("hqq_hip_quantize_axis0: pack_bits=%d not in {8,4,3,2,1}", pack_bits); return HQQ_ERR_NBITS; }
+  if (max_v < 1 || max_v > 255) { set_error("hqq_hip_quantize_axis0: max_v=%d out of range", max_v); return HQQ_ERR_SHAPE; }
+  if (group_size >= 65536) { set_error("hqq_hip_quantize_axis0: group_size %lld (the row cascade is restated for < 2^16 rows)", (long long)group_size); return HQQ_ERR_UNSUPPORTED; }
+  if (numel / group_size < 8) { set_error("hqq_hip_quantize_axis0: fewer than 8 groups (ATen's scalar outer-sum order is not restated)"); return HQQ_ERR_UNSUPPORTED; }
+  if (pack_bits != 3 && group_size % per_of(pack_bits)) {
+    set_error("hqq_hip_quantize_axis0: group_size %lld rows cannot be packed at %d bits (must divide by %d)", (long long)group_size, pack_bits, per_of(pack_bits));
+    return HQQ_ERR_SHAPE;
+  }
+  if (!optimize) iters = 0;
+  if (iters < 0 || iters > MAX_ITERS) { set_error("hqq_hip_quantize_axis0: iters=%d outside [0,%d]", iters, MAX_ITERS); return HQQ_ERR_SHAPE; }
+  const size_t need = ws_layout(numel, group_size, iters).total;
+  if (!workspace || workspace_bytes < need) { set_error("hqq_hip_quantize_axis0: workspace %zu < %zu bytes", workspace_bytes, need); return HQQ_ERR_WORKSPACE; }
+  if (!aligned16(W) || !aligned16(Wq_out) || !aligned16(workspace)) { set_error("hqq_hip_quantize_axis0: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  hipStream_t st = as_stream(stream);
+  switch (w_dtype) {
+    case HQQ_F32: return run_quantize_axis0<float>(W, numel, group_size, max_v, pack_bits, round_zero, iters, beta, lp_norm, Wq_out, scale_out, zero_out, info_out, workspace, st);
+    case HQQ_F16: return run_quantize_axis0<half_t>(W, numel, group_size, max_v, pack_bits, round_zero, iters, beta, lp_norm, Wq_out, scale_out, zero_out, info_out, workspace, st);
+    case HQQ_BF16: return run_quantize_axis0<bf16_t>(W, numel, group_size, max_v, pack_bits, round_zero, iters, beta, lp_norm, Wq_out, scale_out, zero_out, info_out, workspace, st);
+  }
+  set_error("hqq_hip_quantize_axis0: bad w_dtype %d", w_dtype);
+  return HQQ_ERR_DTYPE;
+}
 
 size_t hqq_hip_quantize_workspace_bytes(int64_t numel, int64_t group_size, int iters) {
   if (numel <= 0 || group_size <= 0 || numel % group_size || iters < 0 || iters > MAX_ITERS) return 0;

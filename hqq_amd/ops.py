@@ -360,10 +360,14 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
 
 
 def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False, optimize: bool = True,
-             iters: int = 20, beta: float = 10.0, lp_norm: float = 0.7, return_info: bool = False):
-    """Quantizer.quantize(axis=1, channel_wise=True, bitpack=True) with optimize_weights_proximal_legacy, fused with
-    packing.  Returns (W_q packed, scale [R,1] f32 (already inverted), zero [R,1] f32[, info int32[2] on device])."""
+             iters: int = 20, beta: float = 10.0, lp_norm: float = 0.7, return_info: bool = False, axis: int = 1):
+    """Quantizer.quantize(channel_wise=True, bitpack=True) with optimize_weights_proximal_legacy, fused with packing.
+    axis=1: groups are runs of `group_size` consecutive elements — returns (W_q packed [packed_rows(R), gs], scale [R,1] f32 (already
+    inverted), zero [R,1] f32), R = numel / gs.  axis=0: W is viewed as [gs, C], C = numel / gs, every column a group — returns
+    (W_q packed [packed_rows(gs), C], scale [1,C], zero [1,C]).  [+ info int32[2] on device with return_info]"""
     _dev(W)
+    if axis not in (0, 1):
+        raise ValueError("axis should be either 0 or 1")
     if W.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         W = W.float()
     W = W.contiguous()
@@ -374,11 +378,17 @@ def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False,
     pack_bits = PACK_BITS[nbits]
     max_v = int(round(2 ** nbits - 1))
     R = numel // group_size
-    prow = packed_rows(pack_bits, R)
     dev = W.device
-    W_q = torch.empty((prow, group_size), dtype=torch.int32 if pack_bits == 3 else torch.uint8, device=dev)
-    scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
-    zero = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    if axis == 1:
+        prow = packed_rows(pack_bits, R)
+        W_q = torch.empty((prow, group_size), dtype=torch.int32 if pack_bits == 3 else torch.uint8, device=dev)
+        scale = torch.empty((R, 1), dtype=torch.float32, device=dev)
+        zero = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    else:
+        prow = packed_rows(pack_bits, group_size)
+        W_q = torch.empty((prow, R), dtype=torch.int32 if pack_bits == 3 else torch.uint8, device=dev)
+        scale = torch.empty((1, R), dtype=torch.float32, device=dev)
+        zero = torch.empty((1, R), dtype=torch.float32, device=dev)
     info = torch.zeros((2,), dtype=torch.int32, device=dev)
     L = _C.lib()
     it = iters if optimize else 0
@@ -386,10 +396,11 @@ def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False,
     if ws_bytes == 0:
         raise ValueError(f"hqq_amd: bad quantize arguments (numel={numel}, group_size={group_size}, iters={it})")
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    fn = L.hqq_hip_quantize if axis == 1 else L.hqq_hip_quantize_axis0
     with torch.cuda.device(dev):
-        rc = L.hqq_hip_quantize(_p(W), _dt(W.dtype), numel, group_size, max_v, pack_bits, int(bool(round_zero)), int(bool(optimize)),
-                                it, float(beta), float(lp_norm), _p(W_q), _p(scale), _p(zero), _p(info), _p(ws), ws_bytes, _stream())
-    _C.check(rc, "hqq_hip_quantize")
+        rc = fn(_p(W), _dt(W.dtype), numel, group_size, max_v, pack_bits, int(bool(round_zero)), int(bool(optimize)),
+                it, float(beta), float(lp_norm), _p(W_q), _p(scale), _p(zero), _p(info), _p(ws), ws_bytes, _stream())
+    _C.check(rc, "hqq_hip_quantize" if axis == 1 else "hqq_hip_quantize_axis0")
     if return_info:
         return W_q, scale, zero, info
     return W_q, scale, zero

@@ -183,6 +183,15 @@ int hqq_hip_quantize(const void* W, int w_dtype, int64_t numel, int64_t group_si
                      void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with axis=0 (quantize.py:104-116): W is viewed as [group_size, numel/group_size] and every COLUMN is a group (min/max,
+ * scale, zero and the solver's mean run down the rows).  Wq_out: the packed [packed_rows(group_size), numel/group_size] tensor
+ * (row slabs of the [group_size, C] level matrix share a byte / word, as BitPack.pack_* packs it); scale_out / zero_out
+ * [numel/group_size] float32.  Same workspace size as hqq_hip_quantize. */
+int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t group_size, int max_v, int pack_bits,
+                           int round_zero, int optimize, int iters, float beta, float lp_norm,
+                           void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

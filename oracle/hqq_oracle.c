@@ -12,6 +12,8 @@
  *   hqq_oracle_quantize                   hqq/core/quantize.py:75-180  (Quantizer.quantize, axis=1)
  *                                         hqq/core/optimize.py:96-108  (shrink_lp_op)
  *                                         hqq/core/optimize.py:201-255 (optimize_weights_proximal_legacy)
+ *   hqq_oracle_quantize_axis0             the same with axis=0 (groups run down the rows of the [gs, numel/gs] view; the group mean
+ *                                         is ATen's OUTER-dimension float sum: SumKernel.cpp vectorized_outer_sum)
  *   hqq_oracle_dequantize                 hqq/core/quantize.py:183-199 (Quantizer.dequantize)
  *   hqq_oracle_matmul / _forward          hqq/core/quantize.py:880-898 (HQQLinear.matmul / forward_pytorch)
  *
@@ -356,6 +358,129 @@ int hqq_oracle_quantize(const float* W, int64_t numel, int gs, int max_v, int ro
     zero_out[r] = z[r];
   }
   free(s); free(z);
+  return ran;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ATen float sum over the OUTER dimension of a contiguous [n, C] tensor (torch.mean(dim=0)):     */
+/* SumKernel.cpp vectorized_outer_sum.  Columns are taken 32 at a time (four 8-float vectors)     */
+/* through multi_row_sum — a cascade over the rows: 16 rows into level 0, level 0 into level 1    */
+/* ... —, a remaining run of 8 columns and the last C % 8 columns through row_sum (four           */
+/* interleaved partial sums over rows i % 4, each a cascade; leftover rows; partials 1..3 added   */
+/* to partial 0 in order).  Verified bit-exact against torch 2.10 in this image for n = 8..256,   */
+/* C = 7..65536.  x(i) = base[i * stride].                                                        */
+/* ------------------------------------------------------------------------------------------ */
+static float cascade_sum_strided(const float* base, int64_t stride, int64_t n) {
+  enum { LEVELS = 4 };
+  float acc[LEVELS] = {0.f, 0.f, 0.f, 0.f};
+  int level_power = ceil_log2_i64(n) / LEVELS; if (level_power < 4) level_power = 4;
+  const int64_t level_step = (int64_t)1 << level_power, level_mask = level_step - 1;
+  int64_t i = 0;
+  for (; i + level_step <= n;) {
+    for (int64_t j = 0; j < level_step; ++j, ++i) acc[0] += base[i * stride];
+    for (int j = 1; j < LEVELS; ++j) {
+      acc[j] += acc[j - 1]; acc[j - 1] = 0.f;
+      if ((i & (level_mask << (j * level_power))) != 0) break;
+    }
+  }
+  for (; i < n; ++i) acc[0] += base[i * stride];
+  for (int j = 1; j < LEVELS; ++j) acc[0] += acc[j];
+  return acc[0];
+}
+static float aten_col_sum_f32(const float* col, int64_t stride, int64_t n, int64_t j, int64_t C) {
+  if (j < (C / 32) * 32) return cascade_sum_strided(col, stride, n);
+  /* row_sum: the column read as a (-1, 4) array -> four partial sums, each a cascade over every fourth row */
+  const int64_t size_ilp = n / 4;
+  float part[4];
+  for (int k = 0; k < 4; ++k) part[k] = cascade_sum_strided(col + k * stride, 4 * stride, size_ilp);
+  for (int64_t i = size_ilp * 4; i < n; ++i) part[0] += col[i * stride];
+  for (int k = 1; k < 4; ++k) part[0] += part[k];
+  return part[0];
+}
+float hqq_oracle_col_sum_f32(const float* col, int64_t stride, int64_t n, int64_t j, int64_t C) { return aten_col_sum_f32(col, stride, n, j, C); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Quantizer.quantize, axis=0, channel_wise=True (quantize.py:75-180): W viewed as [gs, C],      */
+/* C = numel / gs; group j is column j.  Same solver (optimize.py:201-255), statistics and mean   */
+/* along axis 0.  Wq_out [gs*C] uint8 in the [gs, C] layout (what BitPack.pack_* then packs row   */
+/* slab by row slab), scale_out [C] = 1/scale, zero_out [C].                                      */
+/* ------------------------------------------------------------------------------------------ */
+int hqq_oracle_quantize_axis0(const float* W, int64_t numel, int gs, int max_v, int round_zero, int optimize,
+                              int iters, float beta, float lp_norm,
+                              uint8_t* Wq_out, float* scale_out, float* zero_out, double* err_hist) {
+  if (gs <= 0 || numel % gs) return -1;
+  const int64_t C = numel / gs;
+  if (C < 8) return -2;                   /* ATen sums fewer than 8 columns on its scalar outer path: another order, not restated */
+  float* s = (float*)malloc(sizeof(float) * (size_t)C);
+  float* z = (float*)malloc(sizeof(float) * (size_t)C);
+  float* t3 = (float*)malloc(sizeof(float) * (size_t)numel);
+  if (!s || !z || !t3) { free(s); free(z); free(t3); return -3; }
+  const float maxv = (float)max_v;
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < C; ++j) {
+    float mn = W[j], mx = W[j];
+    for (int i = 1; i < gs; ++i) { const float w = W[(int64_t)i * C + j]; if (w < mn) mn = w; if (w > mx) mx = w; }
+    float denom = mx - mn;
+    float sc = (1.0f / denom) * maxv;
+    if (fabsf(denom) <= 1e-4f) sc = 1.0f;
+    if (sc > 2e4f) sc = 2e4f;
+    float ze = (-mn) * sc;
+    if (round_zero) ze = rintf(ze);
+    s[j] = sc; z[j] = ze;
+  }
+  int ran = 0;
+  if (optimize) {
+    const float inv_beta = (float)(1.0 / (double)beta);
+    const double pexp = (double)(float)((double)lp_norm - 1.0);
+    float best = INFINITY;
+    for (int it = 0; it < iters; ++it) {
+      double err_sum = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : err_sum)
+      for (int64_t j = 0; j < C; ++j) {
+        const float sc = s[j], ze = z[j];
+        double e_acc = 0.0;
+        for (int i = 0; i < gs; ++i) {
+          const int64_t idx = (int64_t)i * C + j;
+          const float wf = W[idx];
+          float q = wf * sc; q = q + ze; q = rintf(q); q = fminf(fmaxf(q, 0.f), maxv);
+          float wr = (q - ze) / sc;
+          float e = wf - wr;
+          float a = fabsf(e);
+          e_acc += (double)a;
+          float we;
+          if (lp_norm == 1.0f) {
+            float t = a - inv_beta; t = (t < 0.f) ? 0.f : t;
+            we = t * (float)((e > 0.f) - (e < 0.f));
+          } else {
+            float pw = (float)pow((double)a, pexp);
+            float t = inv_beta * pw; t = a - t;
+            t = (t < 0.f || t != t) ? ((t != t) ? t : 0.f) : t;
+            we = t * (float)((e > 0.f) - (e < 0.f));
+          }
+          float u = wf - we; u = u * sc;
+          t3[idx] = q - u;
+        }
+        err_sum += e_acc;
+      }
+#pragma omp parallel for schedule(static)
+      for (int64_t j = 0; j < C; ++j) z[j] = aten_col_sum_f32(t3 + j, C, gs, j, C) / (float)gs;
+      float cur = (float)(err_sum / (double)numel);
+      if (err_hist) err_hist[it] = err_sum / (double)numel;
+      ran = it + 1;
+      if (cur < best) best = cur; else break;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < C; ++j) {
+    for (int i = 0; i < gs; ++i) {
+      const int64_t idx = (int64_t)i * C + j;
+      float q = W[idx] * s[j]; q = q + z[j]; q = rintf(q); q = fminf(fmaxf(q, 0.f), maxv);
+      Wq_out[idx] = (uint8_t)q;
+    }
+    scale_out[j] = 1.0f / s[j];
+    zero_out[j] = z[j];
+  }
+  free(s); free(z); free(t3);
   return ran;
 }
 

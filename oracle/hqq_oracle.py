@@ -46,6 +46,7 @@ def lib() -> ctypes.CDLL:
         L.hqq_oracle_row_sum_f32.restype = f32
         L.hqq_oracle_row_sum_f32.argtypes = [vp, i64]
         L.hqq_oracle_quantize.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]
+        L.hqq_oracle_quantize_axis0.argtypes = [vp, i64, i32, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp]
         L.hqq_oracle_dequantize.argtypes = [i32, vp, vp, vp, vp, i64, i64, i32, i32]
         L.hqq_oracle_matmul.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32]
         L.hqq_oracle_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32]
@@ -177,6 +178,24 @@ def quantize(W: np.ndarray, nbits=4, group_size: int = 64, round_zero=None, opti
                                    iters, beta, lp_norm, _p(Wq), _p(sc), _p(ze), _p(err))
     if rc < 0:
         raise ValueError(f"hqq_oracle_quantize rc={rc}")
+    return {"Wq": Wq, "scale": sc, "zero": ze, "iters_run": rc, "err_hist": err}
+
+
+def quantize_axis0(W: np.ndarray, nbits=4, group_size: int = 64, round_zero=None, optimize: bool = True,
+                   iters: int = 20, beta: float = 10.0, lp_norm: float = 0.7):
+    """Quantizer.quantize(axis=0): returns dict(Wq [gs, C] uint8, scale [1, C] f32 (= 1/scale), zero [1, C] f32, iters_run, err_hist), C = numel / gs."""
+    W = _c(W, np.float32)
+    if round_zero is None:
+        round_zero = nbits == 4
+    C = W.size // group_size
+    Wq = np.empty((group_size, C), np.uint8)
+    sc = np.empty((1, C), np.float32)
+    ze = np.empty((1, C), np.float32)
+    err = np.full((iters,), np.nan, np.float64)
+    rc = lib().hqq_oracle_quantize_axis0(_p(W), W.size, group_size, max_v_of(nbits), int(bool(round_zero)), int(bool(optimize)),
+                                         iters, beta, lp_norm, _p(Wq), _p(sc), _p(ze), _p(err))
+    if rc < 0:
+        raise ValueError(f"hqq_oracle_quantize_axis0 rc={rc}")
     return {"Wq": Wq, "scale": sc, "zero": ze, "iters_run": rc, "err_hist": err}
 
 

@@ -20,6 +20,8 @@ Fixture families
                              W itself is regenerated from the seed by the tests (sha256 stored)
   cfg2_4096_<nbits>b.npz     BASELINE.json configs[1] at full size: 4096x4096, W ~ N(0, 0.02^2) fp16-valued, seed 0:
                              sha256 of the reference's packed W_q / zero / scale (+ heads), forward(x) for fp16
+  quant_axis0_<tag>.npz      Quantizer.quantize(axis=0) (groups down the rows of the [gs, numel/gs] view) + HQQLinear(axis=0)
+                             dequantize / forward for fp16
   refsd_cfg1_4b.npz          the reference's own HQQLinear.state_dict() (encoded, quantize.py:617-680) of the configs[0]
                              layer at 4 bits, fp16 — the wire format hqq_amd.HQQLinear.load_state_dict must accept
 """
@@ -206,6 +208,41 @@ def main():
             arrs["y_f16"] = raw(layer.forward(x2.half()))
         arrs["Wdeq_sha256_f16"] = np.frombuffer(sha(raw(layer.dequantize())).encode(), np.uint8)
         save(f"cfg2_4096_{nbits}b", **arrs)
+
+    # ---------------- axis = 0 (the reference's better-quality layout, Readme.md:28-31; quantize.py:104-116) ----------------
+    def axis0_case(tag, W, nbits, gs, M):
+        N, K = W.shape
+        arrs = {"W": W.numpy().astype(np.float32), "nbits": np.array(nbits), "gs": np.array(gs)}
+        Wq, meta = Quantizer.quantize(W.clone(), nbits=nbits, group_size=gs, axis=0, round_zero=(nbits == 4),
+                                      optimize=True, device="cpu", compute_dtype=torch.float16)
+        arrs["Wq_packed"] = Wq.numpy()
+        arrs["scale_f32"] = meta["scale"].numpy()
+        arrs["zero_f32"] = meta["zero"].numpy()
+        Wq_raw, _ = Quantizer.quantize(W.clone(), nbits=nbits, group_size=gs, axis=0, round_zero=(nbits == 4),
+                                       optimize=True, device="cpu", bitpack=False)
+        arrs["Wq_unpacked"] = Wq_raw.numpy().astype(np.uint8)
+        torch.manual_seed(1)
+        x32 = torch.randn(M, K)
+        arrs["x_f32"] = x32.numpy()
+        lin = torch.nn.Linear(K, N, bias=False)
+        lin.weight.data = W.clone()
+        layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=gs, axis=0), compute_dtype=torch.float16, device="cpu")
+        assert np.array_equal(layer.W_q.data.numpy(), arrs["Wq_packed"])
+        arrs["scale_f16"] = raw(layer.meta["scale"])
+        arrs["zero_f16"] = raw(layer.meta["zero"])
+        arrs["Wdeq_f16"] = raw(layer.dequantize())
+        with torch.no_grad():
+            arrs["y_f16"] = raw(layer.forward(x32.half()))
+        save(tag, **arrs)
+
+    torch.manual_seed(11)
+    Wa = torch.randn(128, 256) * 0.05
+    for nbits in (4, 3, 2, 8):
+        axis0_case(f"quant_axis0_{nbits}b_128x256", Wa, nbits, 64, 2)
+    torch.manual_seed(12)
+    axis0_case("quant_axis0_4b_32x80", torch.randn(32, 80) * 0.05, 4, 64, 1)        # 40 groups: the 8-column and scalar tails of ATen's outer sum
+    axis0_case("quant_axis0_4b_96x72_gs8", torch.randn(96, 72) * 0.05, 4, 8, 1)      # 864 groups of 8
+    axis0_case("quant_axis0_4b_256x256_gs128", torch.randn(256, 256) * 0.05, 4, 128, 1)
 
     # ---------------- the reference's state_dict (wire format) of the configs[0] layer ----------------
     torch.manual_seed(0)

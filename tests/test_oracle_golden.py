@@ -116,3 +116,41 @@ def test_half_conversions(oracle):
     torch = pytest.importorskip("torch")
     wb = torch.from_numpy(x).to(torch.bfloat16).view(torch.uint16).numpy()
     assert np.array_equal(oracle.to_cd(x, 2), wb)
+
+
+AXIS0_FILES = [f"quant_axis0_{b}b_128x256" for b in (4, 3, 2, 8)] + ["quant_axis0_4b_32x80", "quant_axis0_4b_96x72_gs8", "quant_axis0_4b_256x256_gs128"]
+
+
+@pytest.mark.parametrize("name", AXIS0_FILES)
+def test_quantize_axis0_matches_reference(oracle, name):
+    """Quantizer.quantize(axis=0): groups down the rows of the [gs, numel/gs] view; the solver's mean is ATen's OUTER-dimension
+    float sum (32-column cascade blocks, 8-column and scalar tails) — levels, zero, scale and packed bytes bit-exact"""
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    o = oracle.quantize_axis0(g["W"], nbits=nbits, group_size=gs)
+    assert np.array_equal(o["Wq"], g["Wq_unpacked"])
+    assert np.array_equal(o["zero"].view(np.uint32), g["zero_f32"].reshape(1, -1).view(np.uint32))
+    assert np.array_equal(o["scale"].view(np.uint32), g["scale_f32"].reshape(1, -1).view(np.uint32))
+    assert np.array_equal(oracle.pack(nbits, o["Wq"]), g["Wq_packed"])
+    # (W_r - zero) * scale on the [gs, C] view, reshaped to [N, K]  (quantize.py:183-199)
+    N, K = g["W"].shape
+    z16, s16 = oracle.to_cd(o["zero"], 1), oracle.to_cd(o["scale"], 1)
+    with np.errstate(over="ignore"):
+        Wd = ((o["Wq"].astype(np.float16) - z16).astype(np.float16) * s16).astype(np.float16).reshape(N, K)
+    assert np.array_equal(Wd.view(np.uint16), g["Wdeq_f16"].view(np.uint16))
+
+
+def test_aten_outer_sum_order(oracle):
+    """the restated order of torch.sum(dim=0) on a contiguous [n, C] float tensor (the mean of the axis-0 solver)"""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    L = oracle.lib()
+    L.hqq_oracle_col_sum_f32.restype = ctypes.c_float
+    L.hqq_oracle_col_sum_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    # (fewer than 8 columns take ATen's scalar outer-sum path, another order: the oracle and the HIP solver refuse C < 8)
+    for (n, C) in ((64, 256), (64, 40), (128, 40), (32, 9), (8, 24), (256, 64), (64, 33), (100, 19), (64, 4096)):
+        x = (torch.randn(n, C, generator=torch.Generator().manual_seed(n * C)) * 3).float()
+        ref = x.sum(dim=0).numpy()
+        xn = np.ascontiguousarray(x.numpy())
+        got = np.array([L.hqq_oracle_col_sum_f32(xn[:, j:].ctypes.data_as(ctypes.c_void_p), C, n, j, C) for j in range(C)], np.float32)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (n, C)

@@ -347,3 +347,57 @@ def test_from_weights_with_a_bias(ops):
     assert layer.bias is not None and layer.bias.dtype == torch.float16 and tuple(layer.meta["shape"]) == (128, 256)
     x = torch.randn(2, 256, device="cuda").half()
     torch.testing.assert_close(layer(x).float(), x.float() @ layer.dequantize().float().t() + layer.bias.float(), rtol=1e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# axis = 0: the solver with groups down the rows, pinned to the reference's goldens
+# ------------------------------------------------------------------------------------------------
+AXIS0_FILES = [f"quant_axis0_{b}b_128x256" for b in (4, 3, 2, 8)] + ["quant_axis0_4b_32x80", "quant_axis0_4b_96x72_gs8", "quant_axis0_4b_256x256_gs128"]
+
+
+@pytest.mark.parametrize("name", AXIS0_FILES)
+def test_quantize_axis0_golden(ops, name):
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    Wq, s, z = ops.quantize(dev(g["W"]), nbits=nbits, group_size=gs, round_zero=(nbits == 4), axis=0)
+    assert np.array_equal(Wq.cpu().numpy(), g["Wq_packed"]), "packed levels differ from the reference"
+    assert np.array_equal(z.cpu().numpy().view(np.uint32), g["zero_f32"].reshape(1, -1).view(np.uint32))
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), g["scale_f32"].reshape(1, -1).view(np.uint32))
+    # fp16 input weights take the same path (`tensor.float()` first, quantize.py:102)
+    W16 = torch.from_numpy(g["W"]).half()
+    a = ops.quantize(W16.cuda(), nbits=nbits, group_size=gs, round_zero=(nbits == 4), axis=0)
+    b = ops.quantize(W16.float().cuda(), nbits=nbits, group_size=gs, round_zero=(nbits == 4), axis=0)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2, 8])
+def test_hqqlinear_axis0_end_to_end(ops, nbits):
+    """HQQLinear(axis=0): quantise on the GPU, dequantize() bit-identical to the reference's, forward within 1e-3 of its output;
+    Quantizer.quantize(bitpack=False) returns the reference's level matrix"""
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQLinear, Quantizer
+    g = load_golden(f"quant_axis0_{nbits}b_128x256")
+    W = torch.from_numpy(g["W"])
+    lin = torch.nn.Linear(256, 128, bias=False)
+    lin.weight.data = W.clone()
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=0), compute_dtype=torch.float16, device="cuda")
+    assert np.array_equal(layer.W_q.data.cpu().numpy(), g["Wq_packed"]) and layer.meta["axis"] == 0
+    assert tuple(layer.meta["scale"].shape) == (1, 512) and layer.meta["scale"].dtype == torch.float16
+    assert np.array_equal(layer.dequantize().cpu().numpy().view(np.uint16), g["Wdeq_f16"].view(np.uint16))
+    x = dev(g["x_f32"]).half()
+    torch.testing.assert_close(layer(x).float().cpu(), torch.from_numpy(g["y_f16"].astype(np.float32)), rtol=1e-3, atol=1e-3)
+    Wq_raw, meta = Quantizer.quantize(W.clone(), nbits=nbits, group_size=64, axis=0, round_zero=(nbits == 4), bitpack=False, device="cuda")
+    assert meta["packing"] is None and np.array_equal(Wq_raw.cpu().numpy().astype(np.uint8), g["Wq_unpacked"])
+    Wd = Quantizer.dequantize(Wq_raw, {**meta, "compute_dtype": torch.float32})
+    ref = ((torch.from_numpy(g["Wq_unpacked"].astype(np.float32)) - torch.from_numpy(g["zero_f32"])) * torch.from_numpy(g["scale_f32"])).reshape(128, 256)
+    assert torch.equal(Wd.cpu(), ref)
+
+
+def test_quantize_axis0_vs_oracle_large(ops, oracle):
+    """a 1024 x 1024 layer (16384 groups): the oracle (pinned to the reference on the fixtures above) agrees bit for bit"""
+    W = (torch.randn(1024, 1024, generator=torch.Generator().manual_seed(5)) * 0.02)
+    for nbits in (4, 2):
+        o = oracle.quantize_axis0(W.numpy(), nbits=nbits, group_size=64)
+        Wq, s, z = ops.quantize(W.cuda(), nbits=nbits, group_size=64, round_zero=(nbits == 4), axis=0)
+        assert np.array_equal(Wq.cpu().numpy(), oracle.pack(nbits, o["Wq"]))
+        assert np.array_equal(z.cpu().numpy().view(np.uint32), o["zero"].view(np.uint32))
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), o["scale"].view(np.uint32))
