@@ -139,6 +139,105 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WT* __restri
   }
 }
 
+// Any other group size (multiples of 8: 512, 1024, a whole row ...): the same 8 lanes per group, the group's weights re-read in
+// every iteration instead of held in registers, and ATen's full row-sum order — four interleaved accumulators over the 8-wide
+// vectors, each a cascade (16 vectors into level 0, level 0 into level 1, ...: it matters from 512 elements on), leftover vectors
+// to accumulator 0, accumulators 1..3 added to 0, the 8 lanes in order (oracle/hqq_oracle.c aten_row_sum_f32).
+struct CascadeF {   // one accumulator of multi_row_sum, fed one element at a time (level_step 16)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  __device__ __forceinline__ void add(float x) {
+    a0 += x;
+    ++i;
+    if ((i & 15) == 0) {
+      a1 += a0; a0 = 0.f;
+      if ((i & 0xF0) == 0) {
+        a2 += a1; a1 = 0.f;
+        if ((i & 0xF00) == 0) { a3 += a2; a2 = 0.f; }
+      }
+    }
+  }
+  __device__ __forceinline__ float total() const { float t = a0; t += a1; t += a2; t += a3; return t; }
+};
+
+template <typename WT>
+__global__ __launch_bounds__(SOLVE_THREADS) void solve_generic_kernel(const WT* __restrict__ W, SolveParams p,
+                                                                     float* __restrict__ s_ws, float* __restrict__ zero_hist,
+                                                                     double* __restrict__ err_part) {
+  extern __shared__ __attribute__((aligned(16))) float err_lds[];   // [iters][SOLVE_THREADS]
+  const int tid = threadIdx.x, lane = tid & 63, j = tid & 7;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * SOLVE_GROUPS_PER_BLOCK + (tid >> 3);
+  const bool live = r < p.R;
+  const int cl = lane & ~7;
+  const int gs = p.gs, nvec = gs / 8;        // gs % 8 == 0
+  const int size_ilp = nvec / 4;             // rows of the (-1, 4)-shaped vector view
+  const WT* wg = W + (live ? r : 0) * gs;
+  float mn = load_f32<WT>(wg, j), mx = mn;
+  for (int v = 1; v < nvec; ++v) { const float w = load_f32<WT>(wg, 8 * v + j); mn = fminf(mn, w); mx = fmaxf(mx, w); }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) { mn = fminf(mn, __shfl_xor(mn, off, 64)); mx = fmaxf(mx, __shfl_xor(mx, off, 64)); }
+  const float denom = mx - mn;
+  float sc = (1.0f / denom) * p.maxv;
+  if (fabsf(denom) <= 1e-4f) sc = 1.0f;
+  sc = fminf(sc, 2e4f);
+  float ze = (-mn) * sc;
+  if (p.round_zero) ze = rintf(ze);
+  if (live && j == 0) { s_ws[r] = sc; zero_hist[r] = ze; }
+  for (int it = 0; it < p.iters; ++it) {
+    double eabs = 0.0;   // (up to 2^16 elements per lane: keep the per-lane partial of the layer-global error exact enough)
+    CascadeF c0, c1, c2, c3;
+    float left = 0.f;   // leftover vectors (beyond 4 * size_ilp) are added to accumulator 0 AFTER its cascade is totalled
+    float a0 = 0.f;
+    bool totalled = false;
+    for (int v = 0; v < nvec; ++v) {
+      const float wf = load_f32<WT>(wg, 8 * v + j);
+      float q = wf * sc;
+      q = q + ze;
+      q = rintf(q);
+      q = fminf(fmaxf(q, 0.f), p.maxv);
+      const float wr = (q - ze) / sc;
+      const float e = wf - wr;
+      const float a = fabsf(e);
+      eabs += static_cast<double>(a);
+      float t;
+      if (p.lp_is_one) {
+        t = a - p.inv_beta;
+      } else {
+        const float pw = static_cast<float>(pow(static_cast<double>(a), p.pexp));
+        t = p.inv_beta * pw;
+        t = a - t;
+      }
+      t = (t < 0.f) ? 0.f : t;
+      const float we = t * sgnf(e);
+      float u = wf - we;
+      u = u * sc;
+      const float t3 = q - u;
+      if (v < size_ilp * 4) {
+        const int k = v & 3;
+        if (k == 0) c0.add(t3); else if (k == 1) c1.add(t3); else if (k == 2) c2.add(t3); else c3.add(t3);
+      } else {
+        if (!totalled) { a0 = c0.total(); totalled = true; }
+        a0 += t3;
+      }
+    }
+    if (!totalled) a0 = c0.total();
+    (void)left;
+    a0 += c1.total(); a0 += c2.total(); a0 += c3.total();
+    float fin = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin += __shfl(a0, cl | l, 64);
+    ze = fin / static_cast<float>(gs);
+    if (live && j == 0) zero_hist[static_cast<int64_t>(it + 1) * p.R + r] = ze;
+    err_lds[it * SOLVE_THREADS + tid] = live ? static_cast<float>(eabs) : 0.f;
+  }
+  __syncthreads();
+  if (tid < p.iters) {
+    double sacc = 0.0;
+    for (int t = 0; t < SOLVE_THREADS; ++t) sacc += static_cast<double>(err_lds[tid * SOLVE_THREADS + ((t + tid) & (SOLVE_THREADS - 1))]);
+    err_part[static_cast<int64_t>(blockIdx.x) * p.iters + tid] = sacc;
+  }
+}
+
 // err_mean[it] = sum_b err_part[b][it] / numel, deterministic tree; one workgroup per iteration
 __global__ __launch_bounds__(256) void reduce_err_kernel(const double* __restrict__ err_part, double* __restrict__ err_mean,
                                                          int64_t nblocks, int iters, double inv_numel) {
@@ -411,8 +510,13 @@ static int dispatch_solve(const void* W, const SolveParams& p, float* s_ws, floa
     case 128: launch_solve<WT, 16>(W, p, s_ws, zh, ep, nblocks, st); break;
     case 256: launch_solve<WT, 32>(W, p, s_ws, zh, ep, nblocks, st); break;
     default:
-      set_error("hqq_hip_quantize: group_size=%d not covered (8,16,32,64,128,256)", p.gs);
-      return HQQ_ERR_UNSUPPORTED;
+      if (p.gs % 8 || p.gs >= (1 << 19)) {   // (the reference's configuration asserts multiples of 8, quantize.py:1088-1091)
+        set_error("hqq_hip_quantize: group_size=%d not covered (multiples of 8 below 2^19)", p.gs);
+        return HQQ_ERR_UNSUPPORTED;
+      }
+      hipLaunchKernelGGL((solve_generic_kernel<WT>), dim3(static_cast<unsigned>(nblocks)), dim3(SOLVE_THREADS), sizeof(float) * SOLVE_THREADS * (p.iters > 0 ? p.iters : 1), st,
+                         static_cast<const WT*>(W), p, s_ws, zh, ep);
+      break;
   }
   return check_launch("hqq_hip_quantize(solve)");
 }

@@ -159,6 +159,13 @@ def main():
     for gs in (32, 128, 256):
         quant_case(f"quant_4b_32x256_gs{gs}", Wg, None, 4, gs, 1, cds=("f16",))
 
+    # large groups (ATen's row sum starts cascading at 512 elements) and one group per row (group_size = in_features)
+    torch.manual_seed(6)
+    Wl = torch.randn(16, 4096) * 0.05
+    for gs in (512, 1024, 4096):
+        quant_case(f"quant_4b_16x4096_gs{gs}", Wl, None, 4, gs, 1, cds=("f16",))
+    quant_case("quant_2b_16x4096_gs2048", Wl, None, 2, 2048, 1, cds=("f16",))
+
     # ---------------- BASELINE.json configs[0]: 1024x1024 on CPU ----------------
     for nbits in (4, 3, 2):
         torch.manual_seed(0)

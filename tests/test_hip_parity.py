@@ -114,7 +114,7 @@ def test_pack_empty(ops):
 # ------------------------------------------------------------------------------------------------
 # Quantizer.dequantize
 # ------------------------------------------------------------------------------------------------
-QUANT_FILES = ([f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
+QUANT_FILES = ([f"quant_4b_16x4096_gs{g}" for g in (512, 1024, 4096)] + ["quant_2b_16x4096_gs2048"] + [f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
                [f"quant_{b}b_16x128_edge" for b in (4, 3, 2)] + [f"quant_4b_32x256_gs{g}" for g in (32, 128, 256)])
 
 

@@ -46,7 +46,7 @@ def test_aten_row_sum_order(oracle):
     assert oracle.row_sum(x) == 1.0      # x[0]+x[32] cancel first (lane pairing 32 apart), then +1 survives
 
 
-QUANT_FILES = ([f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
+QUANT_FILES = ([f"quant_4b_16x4096_gs{g}" for g in (512, 1024, 4096)] + ["quant_2b_16x4096_gs2048"] + [f"quant_{b}b_192x256" for b in NB] + [f"quant_{b}b_64x2048_normal" for b in (4, 3, 2)] +
                [f"quant_{b}b_16x128_edge" for b in (4, 3, 2)] + [f"quant_4b_32x256_gs{g}" for g in (32, 128, 256)])
 
 
