@@ -52,10 +52,22 @@ class Quantizer:
         if group_size is not None:
             assert is_divisible(tensor.numel(), group_size), (
                 "group_size should be divisble by the total tensor dimensions. shape: " + str(tensor.shape) + ", group_size: " + str(group_size))
-        if not channel_wise:
-            # one scale for the whole tensor (quantize.py:106-108) is only reached through the deprecated meta quantisation
-            raise NotImplementedError("hqq_amd: Quantizer.quantize covers channel_wise=True (per-group statistics), both axes")
         shape = tensor.shape
+        if not channel_wise:   # one scale / zero for the whole tensor, no solver, levels in the tensor's own shape (quantize.py:114-116)
+            W = tensor.to(device)
+            W_q, scale, zero = ops.quantize_tensorwise(W, nbits=nbits, round_zero=round_zero)
+            meta = {"nbits": nbits, "group_size": group_size, "shape": shape, "scale": scale, "zero": zero, "axis": axis,
+                    "packing": Quantizer.bit_to_packing[nbits]}
+            if not bitpack:
+                W_q = ops.unpack(Quantizer._packing_bits[meta["packing"]], W_q, dtype=tensor.dtype if tensor.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32)[:shape[0]]
+                meta["packing"] = None
+                meta["unpack_view_dtype"], meta["view_as_float"] = None, False
+                return W_q, meta
+            meta["unpack_view_dtype"] = Quantizer.unpack_view_dtype[meta["packing"]]
+            meta["view_as_float"] = view_as_float
+            if view_as_float:
+                W_q = W_q.view(torch.float32 if compute_dtype is None else compute_dtype)
+            return W_q, meta
         # group_size None: one group per row (axis 1) / per column (axis 0) — HQQLinear.initialize resolves it the same way (quantize.py:434-439)
         gs = (tensor.shape[-1] if axis == 1 else tensor.shape[0]) if group_size is None else group_size
         W = tensor.to(device)
@@ -83,6 +95,10 @@ class Quantizer:
         if meta["view_as_float"]:
             W_q = W_q.view(meta["unpack_view_dtype"])
         N, K = meta["shape"]
+        if meta["scale"].numel() == 1 and meta["zero"].numel() == 1 and (N if meta["axis"] == 1 else K) > 1 and not meta["group_size"]:
+            # channel_wise=False: one scale / zero for the tensor, packed in its own shape — every row is a group with the same constants
+            return ops.dequantize(W_q, meta["scale"].reshape(1).expand(N).contiguous(), meta["zero"].reshape(1).expand(N).contiguous(),
+                                  N, K, K, Quantizer._packing_bits[meta["packing"]], 1)
         gs = meta["group_size"] if meta["group_size"] else (K if meta["axis"] == 1 else N)
         return ops.dequantize(W_q, meta["scale"].reshape(-1), meta["zero"].reshape(-1), N, K, gs,
                               Quantizer._packing_bits[meta["packing"]], meta["axis"])

@@ -23,6 +23,8 @@
 // accumulators, sequential lane sum), which is why the lane<->element map is c = 8*v + lane.
 // |e|^(p-1) is evaluated in double and rounded once (ATen uses Sleef's <=1ulp powf).  The global error is
 // summed in double.  See oracle/hqq_oracle.c, which restates the same sequence on the CPU.
+#include <algorithm>
+
 #include "hqq_common.h"
 
 namespace hqq {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WT* __restri
   const float denom = mx - mn;
   float sc = (1.0f / denom) * p.maxv;          // Tensor.__rtruediv__: reciprocal() * max_v, two roundings
   if (fabsf(denom) <= 1e-4f) sc = 1.0f;
-  sc = fminf(sc, 2e4f);
+  sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
   if (live && j == 0) { s_ws[r] = sc; zero_hist[r] = ze; }
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_generic_kernel(const WT* 
   const float denom = mx - mn;
   float sc = (1.0f / denom) * p.maxv;
   if (fabsf(denom) <= 1e-4f) sc = 1.0f;
-  sc = fminf(sc, 2e4f);
+  sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
   if (live && j == 0) { s_ws[r] = sc; zero_hist[r] = ze; }
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
   const float denom = mx - mn;
   float sc = (1.0f / denom) * p.maxv;
   if (fabsf(denom) <= 1e-4f) sc = 1.0f;
-  sc = fminf(sc, 2e4f);
+  sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
   if (live) { s_ws[j] = sc; zero_hist[j] = ze; }
@@ -624,6 +626,85 @@ static int run_quantize_axis0(const void* W, int64_t numel, int64_t gs, int max_
   return check_launch("hqq_hip_quantize(axis 0 finalize)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// channel_wise = False (quantize.py:114-116): ONE scale / zero for the whole tensor from its min and max, no solver; the levels are
+// packed in the tensor's own [rows, cols] shape.  min / max are order-free, so a two-level reduction is exact.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TW_MAX_BLOCKS = 1024;
+
+template <typename WT>
+__global__ __launch_bounds__(256) void tensor_minmax_kernel(const WT* __restrict__ W, int64_t numel, float* __restrict__ part) {
+  __shared__ float lmn[4], lmx[4];
+  float mn = INFINITY, mx = -INFINITY;
+  bool nan = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < numel; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float v = load_f32<WT>(W, i);
+    nan |= (v != v);
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  if (nan) { mn = NAN; mx = NAN; }             // Tensor.min()/max() propagate NaN
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+    mn = (a != a || mn != mn) ? NAN : fminf(mn, a);
+    mx = (b != b || mx != mx) ? NAN : fmaxf(mx, b);
+  }
+  if ((threadIdx.x & 63) == 0) { lmn[threadIdx.x >> 6] = mn; lmx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      mn = (lmn[w] != lmn[w] || mn != mn) ? NAN : fminf(mn, lmn[w]);
+      mx = (lmx[w] != lmx[w] || mx != mx) ? NAN : fmaxf(mx, lmx[w]);
+    }
+    part[2 * blockIdx.x] = mn; part[2 * blockIdx.x + 1] = mx;
+  }
+}
+
+__global__ __launch_bounds__(64) void tensor_init_kernel(const float* __restrict__ part, int nparts, float maxv, int round_zero,
+                                                         float* __restrict__ s_ws, float* __restrict__ zero_hist) {
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nparts; i += 64) {
+    const float a = part[2 * i], b = part[2 * i + 1];
+    mn = (a != a || mn != mn) ? NAN : fminf(mn, a);
+    mx = (b != b || mx != mx) ? NAN : fmaxf(mx, b);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+    mn = (a != a || mn != mn) ? NAN : fminf(mn, a);
+    mx = (b != b || mx != mx) ? NAN : fmaxf(mx, b);
+  }
+  if (threadIdx.x == 0) {
+    const float denom = mx - mn;               // quantize.py:126-134 on 0-d tensors: the same op sequence as per group
+    float sc = (1.0f / denom) * maxv;
+    if (fabsf(denom) <= 1e-4f) sc = 1.0f;
+    sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
+    float ze = (-mn) * sc;
+    if (round_zero) ze = rintf(ze);
+    s_ws[0] = sc; zero_hist[0] = ze;
+  }
+}
+
+template <typename WT>
+static int run_quantize_tensor(const void* W, int64_t rows, int64_t cols, int max_v, int pack_bits, int round_zero,
+                               void* Wq_out, float* scale_out, float* zero_out, void* ws, hipStream_t st) {
+  const int64_t numel = rows * cols;
+  float* s_ws = static_cast<float*>(ws);       // [0] scale, [1] zero, [2] unused, [4..] per-block (min, max)
+  float* zh = s_ws + 1;
+  float* part = s_ws + 4;
+  const int nb = static_cast<int>(std::min<int64_t>(TW_MAX_BLOCKS, (numel + 2047) / 2048));
+  hipLaunchKernelGGL((tensor_minmax_kernel<WT>), dim3(nb), dim3(256), 0, st, static_cast<const WT*>(W), numel, part);
+  int rc = check_launch("hqq_hip_quantize_tensor(min/max)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(tensor_init_kernel, dim3(1), dim3(64), 0, st, part, nb, static_cast<float>(max_v), round_zero, s_ws, zh);
+  rc = check_launch("hqq_hip_quantize_tensor(init)");
+  if (rc) return rc;
+  // the packing kernel of the grouped path with the whole tensor as its one group: rows of the [rows, cols] level matrix share a container
+  const int64_t n = hqq_hip_packed_rows(pack_bits, rows) * cols;
+  return dispatch_finalize<WT>(pack_bits, W, s_ws, zh, nullptr, Wq_out, scale_out, zero_out, nullptr, n, numel, 1,
+                               static_cast<int>(numel), static_cast<float>(max_v), 0, st);
+}
+
 }  // namespace hqq
 
 using namespace hqq;
@@ -659,6 +740,29 @@ int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t gr
     case HQQ_BF16: return run_quantize_axis0<bf16_t>(W, numel, group_size, max_v, pack_bits, round_zero, iters, beta, lp_norm, Wq_out, scale_out, zero_out, info_out, workspace, st);
   }
   set_error("hqq_hip_quantize_axis0: bad w_dtype %d", w_dtype);
+  return HQQ_ERR_DTYPE;
+}
+
+int hqq_hip_quantize_tensor(const void* W, int w_dtype, int64_t rows, int64_t cols, int max_v, int pack_bits, int round_zero,
+                            void* Wq_out, float* scale_out, float* zero_out, void* workspace, size_t workspace_bytes, void* stream) {
+  clear_stale_error();
+  if (rows <= 0 || cols <= 0 || rows * cols >= (int64_t(1) << 31)) { set_error("hqq_hip_quantize_tensor: shape [%lld, %lld] (below 2^31 elements)", (long long)rows, (long long)cols); return HQQ_ERR_SHAPE; }
+  if (!per_of(pack_bits)) { set_error("hqq_hip_quantize_tensor: pack_bits=%d not in {8,4,3,2,1}", pack_bits); return HQQ_ERR_NBITS; }
+  if (max_v < 1 || max_v > 255) { set_error("hqq_hip_quantize_tensor: max_v=%d out of range", max_v); return HQQ_ERR_SHAPE; }
+  if (hqq_hip_packed_rows(pack_bits, rows) < 0) {
+    set_error("hqq_hip_quantize_tensor: %lld rows cannot be packed at %d bits (row count must divide by %d)", (long long)rows, pack_bits, per_of(pack_bits));
+    return HQQ_ERR_SHAPE;
+  }
+  if (cols % 8) { set_error("hqq_hip_quantize_tensor: cols=%lld must be a multiple of 8", (long long)cols); return HQQ_ERR_UNSUPPORTED; }
+  if (!workspace || workspace_bytes < HQQ_QUANTIZE_TENSOR_WS_BYTES) { set_error("hqq_hip_quantize_tensor: workspace %zu < %d bytes", workspace_bytes, HQQ_QUANTIZE_TENSOR_WS_BYTES); return HQQ_ERR_WORKSPACE; }
+  if (!aligned16(W) || !aligned16(Wq_out) || !aligned16(workspace)) { set_error("hqq_hip_quantize_tensor: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  hipStream_t st = as_stream(stream);
+  switch (w_dtype) {
+    case HQQ_F32: return run_quantize_tensor<float>(W, rows, cols, max_v, pack_bits, round_zero, Wq_out, scale_out, zero_out, workspace, st);
+    case HQQ_F16: return run_quantize_tensor<half_t>(W, rows, cols, max_v, pack_bits, round_zero, Wq_out, scale_out, zero_out, workspace, st);
+    case HQQ_BF16: return run_quantize_tensor<bf16_t>(W, rows, cols, max_v, pack_bits, round_zero, Wq_out, scale_out, zero_out, workspace, st);
+  }
+  set_error("hqq_hip_quantize_tensor: bad w_dtype %d", w_dtype);
   return HQQ_ERR_DTYPE;
 }
 

@@ -404,3 +404,25 @@ def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False,
     if return_info:
         return W_q, scale, zero, info
     return W_q, scale, zero
+
+
+def quantize_tensorwise(W: Tensor, nbits=4, round_zero: bool = False):
+    """Quantizer.quantize(channel_wise=False) (quantize.py:114-116): one scale / zero from the tensor's min and max, no solver; the
+    levels packed in the tensor's own 2-D shape.  Returns (W_q packed [packed_rows(rows), cols], scale 0-d f32 (inverted), zero 0-d f32)."""
+    _dev(W)
+    if W.dim() != 2:
+        raise ValueError("hqq_amd: quantize_tensorwise takes a 2-D tensor")
+    if W.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        W = W.float()
+    W = W.contiguous()
+    rows, cols = W.shape
+    pack_bits = PACK_BITS[nbits]
+    dev = W.device
+    W_q = torch.empty((packed_rows(pack_bits, rows), cols), dtype=torch.int32 if pack_bits == 3 else torch.uint8, device=dev)
+    meta = torch.empty((2,), dtype=torch.float32, device=dev)
+    ws = torch.empty((16384,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _C.lib().hqq_hip_quantize_tensor(_p(W), _dt(W.dtype), rows, cols, int(round(2 ** nbits - 1)), pack_bits, int(bool(round_zero)),
+                                              _p(W_q), _p(meta), meta.data_ptr() + 4, _p(ws), ws.numel(), _stream())
+    _C.check(rc, "hqq_hip_quantize_tensor")
+    return W_q, meta[0], meta[1]

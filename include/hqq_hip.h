@@ -192,6 +192,13 @@ int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t gr
                            void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* channel_wise=False (quantize.py:114-116, 146): one scale and one zero for the WHOLE [rows, cols] tensor from its min and max, no
+ * solver; the levels are packed in the tensor's own shape — Wq_out [packed_rows(rows), cols].  scale_out / zero_out: one float32 each
+ * (scale already inverted, quantize.py:154).  cols % 8 == 0, rows * cols < 2^31.  workspace: HQQ_QUANTIZE_TENSOR_WS_BYTES. */
+#define HQQ_QUANTIZE_TENSOR_WS_BYTES 16384
+int hqq_hip_quantize_tensor(const void* W, int w_dtype, int64_t rows, int64_t cols, int max_v, int pack_bits, int round_zero,
+                            void* Wq_out, float* scale_out, float* zero_out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,14 @@ def quantize_axis0(W: np.ndarray, nbits=4, group_size: int = 64, round_zero=None
     return {"Wq": Wq, "scale": sc, "zero": ze, "iters_run": rc, "err_hist": err}
 
 
+def quantize_tensorwise(W: np.ndarray, nbits=4, round_zero: bool = False):
+    """Quantizer.quantize(channel_wise=False) (quantize.py:114-116,146): the whole tensor is one group, no solver; the levels keep the
+    tensor's shape.  returns dict(Wq [rows, cols] uint8, scale 0-d f32 (= 1/scale), zero 0-d f32)."""
+    W = _c(W, np.float32)
+    r = quantize(W, nbits=nbits, group_size=W.size, round_zero=round_zero, optimize=False)
+    return {"Wq": r["Wq"].reshape(W.shape), "scale": r["scale"].reshape(()), "zero": r["zero"].reshape(())}
+
+
 def row_sum(x: np.ndarray) -> float:
     x = _c(x, np.float32)
     return float(lib().hqq_oracle_row_sum_f32(_p(x), x.size))

@@ -20,6 +20,7 @@ Fixture families
                              W itself is regenerated from the seed by the tests (sha256 stored)
   cfg2_4096_<nbits>b.npz     BASELINE.json configs[1] at full size: 4096x4096, W ~ N(0, 0.02^2) fp16-valued, seed 0:
                              sha256 of the reference's packed W_q / zero / scale (+ heads), forward(x) for fp16
+  quant_tensorwise_<tag>.npz Quantizer.quantize(channel_wise=False): one scale / zero for the whole tensor, packed in its own shape
   quant_axis0_<tag>.npz      Quantizer.quantize(axis=0) (groups down the rows of the [gs, numel/gs] view) + HQQLinear(axis=0)
                              dequantize / forward for fp16
   refsd_cfg1_4b.npz          the reference's own HQQLinear.state_dict() (encoded, quantize.py:617-680) of the configs[0]
@@ -250,6 +251,29 @@ def main():
     axis0_case("quant_axis0_4b_32x80", torch.randn(32, 80) * 0.05, 4, 64, 1)        # 40 groups: the 8-column and scalar tails of ATen's outer sum
     axis0_case("quant_axis0_4b_96x72_gs8", torch.randn(96, 72) * 0.05, 4, 8, 1)      # 864 groups of 8
     axis0_case("quant_axis0_4b_256x256_gs128", torch.randn(256, 256) * 0.05, 4, 128, 1)
+
+    # ---------------- channel_wise=False: one scale / zero for the tensor (quantize.py:114-116) ----------------
+    def tensorwise_case(tag, W, nbits, round_zero):
+        arrs = {"W": W.numpy().astype(np.float32), "nbits": np.array(nbits), "round_zero": np.array(int(round_zero))}
+        Wq, meta = Quantizer.quantize(W.clone(), nbits=nbits, channel_wise=False, group_size=None, optimize=False, round_zero=round_zero,
+                                      axis=1, device="cpu", compute_dtype=torch.float16)
+        arrs["Wq_packed"] = Wq.numpy()
+        arrs["scale_f32"] = meta["scale"].numpy()
+        arrs["zero_f32"] = meta["zero"].numpy()
+        Wq_raw, _ = Quantizer.quantize(W.clone(), nbits=nbits, channel_wise=False, group_size=None, optimize=False, round_zero=round_zero,
+                                       axis=1, device="cpu", bitpack=False)
+        arrs["Wq_unpacked"] = Wq_raw.numpy().astype(np.uint8)
+        meta16 = dict(meta)
+        meta16["scale"], meta16["zero"] = meta["scale"].half(), meta["zero"].half()
+        meta16["compute_dtype"] = torch.float16
+        if nbits != 3:   # (the reference's dequantize divides by group_size=None for 3-bit, quantize.py:190-195)
+            arrs["Wdeq_f16"] = raw(Quantizer.dequantize(Wq, meta16))
+        save(tag, **arrs)
+
+    torch.manual_seed(13)
+    Wt = torch.randn(160, 256) * 0.05
+    for nbits in (8, 4, 3, 2, 1):
+        tensorwise_case(f"quant_tensorwise_{nbits}b_160x256", Wt, nbits, nbits == 4)
 
     # ---------------- the reference's state_dict (wire format) of the configs[0] layer ----------------
     torch.manual_seed(0)

@@ -82,8 +82,10 @@ def test_quantizer_tables():
 
 def test_quantize_rejects_what_the_kernels_do_not_cover_loudly():
     W = torch.zeros(64, 64)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         Quantizer.quantize(W, nbits=4, axis=0, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Quantizer.quantize(W, nbits=8, channel_wise=False, group_size=None, device="cpu")
     with pytest.raises(AssertionError):
         Quantizer.quantize(W, nbits=4, group_size=48, axis=1)     # 4096 % 48 != 0 (quantize.py:94-100)
     with pytest.raises(RuntimeError, match="no CPU path"):

@@ -118,6 +118,21 @@ def test_half_conversions(oracle):
     assert np.array_equal(oracle.to_cd(x, 2), wb)
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 3, 2, 1])
+def test_quantize_tensorwise_matches_reference(oracle, nbits):
+    """Quantizer.quantize(channel_wise=False): one scale / zero from the tensor's min and max, levels packed in the tensor's shape"""
+    g = load_golden(f"quant_tensorwise_{nbits}b_160x256")
+    o = oracle.quantize_tensorwise(g["W"], nbits=nbits, round_zero=bool(g["round_zero"]))
+    assert np.array_equal(o["Wq"], g["Wq_unpacked"])
+    assert o["scale"].shape == g["scale_f32"].shape == () and np.array_equal(o["scale"].view(np.uint32), g["scale_f32"].view(np.uint32))
+    assert np.array_equal(o["zero"].view(np.uint32), g["zero_f32"].view(np.uint32))
+    assert np.array_equal(oracle.pack(nbits, o["Wq"]), g["Wq_packed"])
+    if nbits != 3:
+        z16, s16 = oracle.to_cd(o["zero"].reshape(1), 1), oracle.to_cd(o["scale"].reshape(1), 1)
+        Wd = ((o["Wq"].astype(np.float16) - z16).astype(np.float16) * s16).astype(np.float16)
+        assert np.array_equal(Wd.view(np.uint16), g["Wdeq_f16"].view(np.uint16))
+
+
 AXIS0_FILES = [f"quant_axis0_{b}b_128x256" for b in (4, 3, 2, 8)] + ["quant_axis0_4b_32x80", "quant_axis0_4b_96x72_gs8", "quant_axis0_4b_256x256_gs128"]
 
 

@@ -392,6 +392,41 @@ def test_hqqlinear_axis0_end_to_end(ops, nbits):
     assert torch.equal(Wd.cpu(), ref)
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 3, 2, 1])
+def test_quantize_tensorwise_golden(ops, nbits):
+    """Quantizer.quantize(channel_wise=False) (quantize.py:114-116): bytes, scale, zero and the dequantised tensor identical to the reference's"""
+    from hqq_amd.core.quantize import Quantizer
+    g = load_golden(f"quant_tensorwise_{nbits}b_160x256")
+    rz = bool(g["round_zero"])
+    for W in (torch.from_numpy(g["W"]), torch.from_numpy(g["W"]).half()):
+        Wq, meta = Quantizer.quantize(W.clone(), nbits=nbits, channel_wise=False, group_size=None, optimize=False, round_zero=rz, axis=1, device="cuda")
+        if W.dtype == torch.float32:
+            assert np.array_equal(Wq.cpu().numpy(), g["Wq_packed"])
+            assert meta["scale"].dim() == 0 and meta["zero"].dim() == 0
+            assert np.array_equal(meta["scale"].cpu().numpy().view(np.uint32), g["scale_f32"].view(np.uint32))
+            assert np.array_equal(meta["zero"].cpu().numpy().view(np.uint32), g["zero_f32"].view(np.uint32))
+            raw, m2 = Quantizer.quantize(W.clone(), nbits=nbits, channel_wise=False, group_size=None, optimize=False, round_zero=rz, axis=1, device="cuda", bitpack=False)
+            assert m2["packing"] is None and np.array_equal(raw.cpu().numpy().astype(np.uint8), g["Wq_unpacked"])
+            if nbits != 3:
+                m16 = {**meta, "scale": meta["scale"].half(), "zero": meta["zero"].half(), "compute_dtype": torch.float16}
+                assert np.array_equal(Quantizer.dequantize(Wq, m16).cpu().numpy().view(np.uint16), g["Wdeq_f16"].view(np.uint16))
+        else:   # a half input takes the same path after `tensor.float()` (quantize.py:102)
+            Wq32, meta32 = Quantizer.quantize(W.float(), nbits=nbits, channel_wise=False, group_size=None, optimize=False, round_zero=rz, axis=1, device="cuda")
+            assert torch.equal(Wq, Wq32) and torch.equal(meta["scale"], meta32["scale"]) and torch.equal(meta["zero"], meta32["zero"])
+
+
+def test_quantize_tensorwise_vs_oracle_large(ops, oracle):
+    """4096 x 4096 (more elements than one block sweep of the min/max kernel), and a NaN anywhere poisons scale and zero as Tensor.min() does"""
+    W = torch.randn(4096, 4096, generator=torch.Generator().manual_seed(9)) * 0.02
+    o = oracle.quantize_tensorwise(W.numpy(), nbits=4, round_zero=True)
+    Wq, s, z = ops.quantize_tensorwise(W.cuda(), nbits=4, round_zero=True)
+    assert np.array_equal(Wq.cpu().numpy(), oracle.pack(4, o["Wq"]))
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), o["scale"].view(np.uint32)) and np.array_equal(z.cpu().numpy().view(np.uint32), o["zero"].view(np.uint32))
+    W[17, 33] = float("nan")
+    _, s, z = ops.quantize_tensorwise(W.cuda(), nbits=4)
+    assert bool(torch.isnan(s)) and bool(torch.isnan(z))
+
+
 def test_quantize_axis0_vs_oracle_large(ops, oracle):
     """a 1024 x 1024 layer (16384 groups): the oracle (pinned to the reference on the fixtures above) agrees bit for bit"""
     W = (torch.randn(1024, 1024, generator=torch.Generator().manual_seed(5)) * 0.02)
