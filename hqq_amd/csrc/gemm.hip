@@ -440,18 +440,43 @@ static int launch_gemm_f16(const void* x, const void* Wq, const void* scale, con
   return check_launch("hqq_hip_gemm");
 }
 
+// gemm_pipe.hip: the pipelined split-K kernel for the rows between decode and long prefill
+struct GpPlan;
+size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts);
+bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype);
+int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
+                  int64_t M, int64_t N, int64_t K, int64_t gs, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// which fused GEMM serves M rows: the pipelined split-K kernel up to GEMM_PIPE_MAX_M rows (measured against the tile kernels and
+// against dequantise + library GEMM, tools/sweep_prefill.py), the round-1 tile kernels beyond
+constexpr int64_t GEMM_PIPE_MAX_M = 1024;
+static bool use_pipe(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts) {
+  if (opts & (HQQ_OPT_GEMM_REGTILE | HQQ_OPT_GEMM_CLASSIC)) return false;
+  return (M <= GEMM_PIPE_MAX_M || nbits == 8) && gemm_pipe_covers(nbits, M, N, K, gs, dtype);   // (8-bit: the only fused GEMM there is)
+}
+
 }  // namespace hqq
 
 using namespace hqq;
 
 extern "C" {
 
+size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
+  if (M <= HQQ_GEMV_MAX_M_SKINNY) return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
+  return use_pipe(nbits, M, N, K, group_size, dtype, opts) ? gemm_pipe_workspace_bytes(nbits, M, N, K, opts) : 0;
+}
+
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* stream) {
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                 void* stream) {
   clear_stale_error();
+  if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemm: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemm: bad M/N/K/group_size"); return HQQ_ERR_SHAPE; }
   if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || N * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemm: size overflow"); return HQQ_ERR_SHAPE; }
   if (!aligned16(x) || !aligned16(Wq) || !aligned16(y)) { set_error("hqq_hip_gemm: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  hipStream_t st = as_stream(stream);
+  if (use_pipe(nbits, M, N, K, group_size, dtype, opts)) return gemm_pipe_run(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, opts, workspace, workspace_bytes, st);
   if (nbits != 4 && nbits != 2) { set_error("hqq_hip_gemm: nbits=%d not covered by the fused GEMM", nbits); return HQQ_ERR_UNSUPPORTED; }
   const int per = 8 / nbits;
   if (N % per || (N / per) % 4 || group_size % 16 || K % GB_K) {
@@ -459,7 +484,6 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
     return HQQ_ERR_UNSUPPORTED;
   }
   if (dtype != HQQ_F16) { set_error("hqq_hip_gemm: dtype %d not covered (fp16 only for now)", dtype); return HQQ_ERR_UNSUPPORTED; }
-  hipStream_t st = as_stream(stream);
   const int m = static_cast<int>(M), n = static_cast<int>(N), k = static_cast<int>(K), gs = static_cast<int>(group_size);
   // opt-in (HQQ_OPT_GEMM_REGTILE): register-tile kernel (weights never touch LDS).  Round-1 status: correct, 0.62-0.81 PFLOP/s — level
   // with the LDS-staged kernels below (0.65-0.83), not ahead; PMC: waves stall on issue 33 % and wait 45 % of their cycles.
@@ -479,7 +503,7 @@ int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale,
   if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
       N % (8 / nbits) == 0)
     return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
-  return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, stream);
+  return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_siz
 GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 # per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
-OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE = 1, 2, 4, 8, 16
+OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC = 1, 2, 4, 8, 16, 32
 
 
 def OPT_SKINNY_KS(n: int) -> int:
@@ -193,12 +193,14 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
     if M > 0:
         o = _opts(opts)
         with torch.cuda.device(x.device):
-            if fn_name == "hqq_hip_gemm":
-                rc = _C.lib().hqq_hip_gemm(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size, _dt(x.dtype), o, _stream())
-            else:
-                ws, ws_bytes = _workspace(x, nbits, [N], M, K, group_size, o) if M <= SKINNY_MAX_M else (None, 0)
-                rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
-                                                _dt(x.dtype), o, ws, ws_bytes, _stream())
+            if fn_name == "hqq_hip_gemv":
+                ws, ws_bytes = _workspace(x, nbits, [N], M, K, group_size, o)
+            else:   # hqq_hip_gemm / hqq_hip_forward
+                need = int(_C.lib().hqq_hip_forward_workspace_bytes(int(nbits), M, N, K, group_size, _dt(x.dtype), o)) if fn_name == "hqq_hip_forward" or M > SKINNY_MAX_M else 0
+                ws = reserve_workspace(x.device, need) if need else None
+                ws, ws_bytes = (ws.data_ptr(), ws.numel()) if need else (None, 0)
+            rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
+                                            _dt(x.dtype), o, ws, ws_bytes, _stream())
         _C.check(rc, fn_name)
     return out.reshape(*x.shape[:-1], N)
 

@@ -88,7 +88,8 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * workspace may be NULL).  Contract: 16-byte aligned device memory, ZERO when first used — the caller clears it once when
  * allocating it; every call leaves the counter area zero again — and not shared by calls that may run concurrently.  A larger
  * workspace than asked for is fine: one buffer sized for the largest launch serves a whole model.
- * hqq_hip_gemm: nbits in {4,2}, fp16, K % 64 == 0.
+ * hqq_hip_gemm: nbits in {4,2}, fp16, K % 64 == 0.  Up to 1024 rows it splits K across workgroups until the chip is full and parks
+ * fp32 partial tiles in the workspace (hqq_hip_forward_workspace_bytes), summed in split order by the last split to arrive.
  * Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
@@ -104,8 +105,10 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_GEMV3_ROWWISE  4u   /* 3-bit decode: force the row-per-wave kernel (tests / tuning) */
 #define HQQ_OPT_GEMV3_SLABS    8u   /* 3-bit decode: force the slab-sharing kernel (needs workspace) */
 #define HQQ_OPT_GEMM_REGTILE  16u   /* prefill: the register-tile variant of the fused GEMM */
-#define HQQ_OPT_SKINNY_KS(n) ((uint32_t)(n) << 24)   /* 5..64 rows: force n K-splits (tuning; 0 = built-in rule) */
-#define HQQ_OPT_ALL (31u | (255u << 24))
+#define HQQ_OPT_GEMM_CLASSIC  32u   /* fused GEMM: the plain output-tile kernels for every M (tests / tuning; default: the pipelined split-K
+                                       kernel up to 1024 rows) */
+#define HQQ_OPT_SKINNY_KS(n) ((uint32_t)(n) << 24)   /* 5..64 rows, and the split-K fused GEMM: force n K-splits (tuning; 0 = built-in rule) */
+#define HQQ_OPT_ALL (63u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.
@@ -159,9 +162,13 @@ int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int nbits, int6
 int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t plan_bytes, void* stream);
 size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
 
+/* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
+ * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */
+size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
-                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* stream);
-/* hqq_hip_gemv for M it covers, hqq_hip_gemm otherwise; workspace as hqq_hip_gemv (hqq_hip_gemv_workspace_bytes with the same M) */
+                 void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                 void* stream);
+/* hqq_hip_gemv for M it covers, hqq_hip_gemm otherwise; workspace: hqq_hip_forward_workspace_bytes with the same M */
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                     void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                     void* stream);
