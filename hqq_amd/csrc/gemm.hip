@@ -444,6 +444,7 @@ static int launch_gemm_f16(const void* x, const void* Wq, const void* scale, con
 struct GpPlan;
 size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts);
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype);
+bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                   int64_t M, int64_t N, int64_t K, int64_t gs, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
 
@@ -461,10 +462,25 @@ using namespace hqq;
 
 extern "C" {
 
+size_t hqq_hip_gemm_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
+  return use_pipe(nbits, M, N, K, group_size, dtype, opts) ? gemm_pipe_workspace_bytes(nbits, M, N, K, opts) : 0;
+}
+
 size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
-  if (M <= HQQ_GEMV_MAX_M_SKINNY) return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
-  return use_pipe(nbits, M, N, K, group_size, dtype, opts) ? gemm_pipe_workspace_bytes(nbits, M, N, K, opts) : 0;
+  // (the same test as hqq_hip_forward's dispatch)
+  if (M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
+  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
+      N % (8 / nbits) == 0)
+    return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
+  return hqq_hip_gemm_workspace_bytes(nbits, M, N, K, group_size, dtype, opts);
+}
+
+int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {
+  if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
+  if (M <= HQQ_GEMV_MAX_M_SKINNY) return 1;   // decode-sized: always the weight-streaming kernels where they apply
+  return gemm_pipe_covers(nbits, M, N, K, group_size, dtype) && gemm_pipe_wins(nbits, M, N, K) ? 1 : 0;
 }
 
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,

@@ -196,7 +196,7 @@ def _fwd(fn_name: str, x: Tensor, W_q: Tensor, scale: Tensor, zero: Tensor, bias
             if fn_name == "hqq_hip_gemv":
                 ws, ws_bytes = _workspace(x, nbits, [N], M, K, group_size, o)
             else:   # hqq_hip_gemm / hqq_hip_forward
-                need = int(_C.lib().hqq_hip_forward_workspace_bytes(int(nbits), M, N, K, group_size, _dt(x.dtype), o)) if fn_name == "hqq_hip_forward" or M > SKINNY_MAX_M else 0
+                need = int(getattr(_C.lib(), fn_name + "_workspace_bytes")(int(nbits), M, N, K, group_size, _dt(x.dtype), o))
                 ws = reserve_workspace(x.device, need) if need else None
                 ws, ws_bytes = (ws.data_ptr(), ws.numel()) if need else (None, 0)
             rc = getattr(_C.lib(), fn_name)(nbits, _p(x2), _p(W_q), _p(scale), _p(zero), _p(bias), _p(out), M, N, K, group_size,
@@ -312,11 +312,14 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None
     return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
 
 
-# From this many activation rows on, `forward` composes the HIP dequantise kernel with a plain library GEMM (hipBLASLt through
-# torch.matmul).  Measured on MI355X (profiles/r01_sweep.md): the composition costs one extra write+read of the fp16 weights
-# (13.6 us for 4096x4096) and then runs the library's tuned MFMA pipeline — 26 us at M = 256 and 1.05-1.4 PFLOP/s at M = 8192,
-# against 81 us / 0.63-0.83 PFLOP/s for the fused 128-tile kernel, whose only remaining advantage is that it needs no N*K*2-byte
-# temporary.  `fused=True` (or LIBRARY_GEMM_MIN_M = 0) forces the fused kernel.  M <= 16 always takes the fused decode kernels.
+# Which path `forward` takes by the number of activation rows M (measured on MI355X, tools/sweep_prefill.py -> profiles/):
+#   M <= 16 (<= 64 where skinny_covers): the weight-streaming decode kernels;
+#   65 <= M <= 1024 where hqq_hip_forward_prefers_fused says so (<= 256 rows everywhere, <= 1024 while the tiles fit one round of
+#       workgroups): the pipelined split-K fused GEMM — 1.1-1.8x the composition below, whose dequantise pass (11-36 us per layer)
+#       is as long as its GEMM at these sizes;
+#   otherwise: the HIP dequantise kernel + a plain library GEMM (hipBLASLt through torch.matmul) — one extra write + read of the
+#       fp16 weights (11-36 us), then 1.05-1.45 PFLOP/s at M = 8192 against 0.6-0.85 for the fused output-tile kernels.
+# `fused=True` forces the fused kernels for every M.  LIBRARY_GEMM_MIN_M applies to the decode-sized cases the skinny kernel does not cover.
 LIBRARY_GEMM_MIN_M = 17
 
 
@@ -351,7 +354,9 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
         raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
     if fused is None:
         fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
-            (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M))
+            (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M)) or \
+            (M > SKINNY_MAX_M and x.is_cuda and nbits in (8, 4, 2) and x.dtype in _DT and
+             bool(_C.lib().hqq_hip_forward_prefers_fused(int(nbits), M, int(N), int(K), int(group_size or 0), _dt(x.dtype))))
     if fused:
         return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
     W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)

@@ -88,8 +88,9 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * workspace may be NULL).  Contract: 16-byte aligned device memory, ZERO when first used — the caller clears it once when
  * allocating it; every call leaves the counter area zero again — and not shared by calls that may run concurrently.  A larger
  * workspace than asked for is fine: one buffer sized for the largest launch serves a whole model.
- * hqq_hip_gemm: nbits in {4,2}, fp16, K % 64 == 0.  Up to 1024 rows it splits K across workgroups until the chip is full and parks
- * fp32 partial tiles in the workspace (hqq_hip_forward_workspace_bytes), summed in split order by the last split to arrive.
+ * hqq_hip_gemm: fp16; nbits in {8,4,2} with group_size 64, K % 128 == 0 (the pipelined kernel: all operands by LDS-DMA, K split
+ * across workgroups until the chip is full, fp32 partial tiles parked in the workspace and summed in split order by a second launch;
+ * used up to 1024 rows, 8-bit at any M); nbits in {4,2}, K % 64 == 0, group_size % 16 == 0 (the output-tile kernels, any M).
  * Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16
@@ -165,6 +166,10 @@ size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */
 size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);
+size_t hqq_hip_gemm_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);   /* hqq_hip_gemm called directly, any M */
+/* 1 when, for this shape, the fused kernels behind hqq_hip_forward are measured faster on MI355X than hqq_hip_dequantize + a library
+ * GEMM on the result (the caller's alternative for M > HQQ_GEMV_MAX_M_SKINNY), else 0: a speed hint, never a correctness matter. */
+int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype);
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                  void* stream);

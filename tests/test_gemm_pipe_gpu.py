@@ -1,0 +1,144 @@
+"""GPU parity tests of the pipelined split-K fused GEMM (csrc/gemm_pipe.hip: 65..1024 activation rows; all operands by LDS-DMA,
+weights rebuilt into MFMA fragments) against the oracle and against hqq_hip_dequantize."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from hqq_amd import ops as o
+    assert o.is_available(), "libhqq_hip.so must load on the GPU box (no fallback)"
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _layer(N, K, nbits, seed, round_zero):
+    g = torch.Generator().manual_seed(seed)
+    R = N * K // 64
+    U = torch.randint(0, 2 ** nbits, (R, 64), generator=g, dtype=torch.uint8)
+    s = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).half()
+    z = torch.rand(R, 1, generator=g) * (2 ** nbits - 1)
+    z = (z.round() if round_zero else z).half()
+    return U, s, z
+
+
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+@pytest.mark.parametrize("M,N,K", [(65, 256, 128), (128, 200, 256), (129, 1024, 512), (300, 264, 1024), (512, 128, 2048), (96, 72, 1280)])
+@pytest.mark.parametrize("round_zero", [True, False])
+def test_pipelined_gemm_vs_oracle(ops, oracle, nbits, M, N, K, round_zero):
+    """y against the C oracle's dequantise + fp32-accumulate matmul (tolerance: fp32 summation order + one fp16 rounding, 1e-3 of the
+    output scale), and the weights themselves bit for bit: one-hot activation rows pick single columns of W exactly.  round_zero=True
+    layers pass hqq_hip_meta_check and take the three-op rebuild, the others the four-op one.  Shapes: ragged N (rows per slab not a
+    multiple of the 64-row tile), M not a multiple of 128, K of two steps up to twenty."""
+    per = 8 // nbits
+    if N % per or (N // per) % 4:
+        pytest.skip("N not packable at this width")
+    U, s, z = _layer(N, K, nbits, M + N + K, round_zero)
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half()
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, 64, 1)
+    yo, _ = oracle.matmul(x.numpy(), Wd, bias.numpy(), 1)
+    sd, zd, Pd = s.cuda(), z.cuda(), dev(P)
+    scalable = ops.meta_scalable(sd, zd, N, K, 64, nbits)
+    assert scalable == round_zero or not round_zero   # integer zero-points always qualify
+    opts = ops.OPT_META_SCALABLE if scalable else 0
+    y = ops.gemm(x.cuda(), Pd, sd, zd, bias.cuda(), N, K, 64, nbits, opts=opts)
+    torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=2e-3)
+    e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+    ks = torch.arange(M, device="cuda") * 7 % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    Y = ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=opts)
+    Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, 64, nbits)
+    assert np.array_equal(Wdev.cpu().numpy().view(np.uint16), Wd.view(np.uint16))
+    assert torch.equal(Y, Wdev[:, ks].t().contiguous())
+    if scalable:   # the three-op and the four-op rebuild give the same bits
+        assert torch.equal(Y, ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=0))
+
+
+@pytest.mark.parametrize("nbits", [4, 2, 8])
+def test_split_k_is_reproducible_and_order_is_fixed(ops, nbits):
+    """K = 11008 (172 steps: uneven splits, every forced split count), bias, one-hot exactness for every split count; two runs of the
+    same call give the same bits (fixed summation order, no atomics); different split counts agree to fp32 rounding"""
+    M, N, K = 160, 512, 11008
+    U, s, z = _layer(N, K, nbits, 7, True)
+    P = ops.pack(nbits, U.cuda())
+    s, z = s.cuda(), z.cuda()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(3)).half().cuda()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(4)).half().cuda()
+    Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, nbits)
+    ref = (x.float() @ Wd.float().t() + bias.float())
+    e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+    cols = torch.arange(M, device="cuda") * 67 % K
+    e[torch.arange(M, device="cuda"), cols] = 1.0
+    base = None
+    for ks in (0, 1, 2, 3, 5, 8, 10, 16):
+        o = ops.OPT_META_SCALABLE | (ks << 24)
+        y = ops.gemm(x, P, s, z, bias, N, K, 64, nbits, opts=o)
+        assert torch.equal(y, ops.gemm(x, P, s, z, bias, N, K, 64, nbits, opts=o))
+        torch.testing.assert_close(y.float(), ref, rtol=1e-3, atol=2e-3 * float(ref.abs().max()) / 4)
+        if base is None:
+            base = y
+        torch.testing.assert_close(y.float(), base.float(), rtol=2e-3, atol=1e-2)
+        assert torch.equal(ops.gemm(e, P, s, z, None, N, K, 64, nbits, opts=o), Wd[:, cols].t().contiguous())
+
+
+def test_full_size_layers_one_hot_exact_and_linear(ops):
+    """Llama-2-7B shapes at 128 and 1000 rows: every weight the kernel multiplies is the dequantised weight (one-hot rows), and the
+    result is linear in x — size-independent properties, no oracle needed"""
+    for (N, K) in [(4096, 4096), (11008, 4096), (4096, 11008)]:
+        U, s, z = _layer(N, K, 4, N ^ K, True)
+        P = ops.pack(4, U.cuda())
+        s, z = s.cuda(), z.cuda()
+        Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, 4)
+        for M in (128, 1000):
+            e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+            cols = torch.arange(M, device="cuda") * 131 % K
+            e[torch.arange(M, device="cuda"), cols] = 1.0
+            assert torch.equal(ops.forward(e, P, s, z, None, N, K, 64, 4, fused=True, opts=ops.OPT_META_SCALABLE), Wd[:, cols].t().contiguous())
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().cuda()
+            y = ops.forward(x, P, s, z, None, N, K, 64, 4, fused=True, opts=ops.OPT_META_SCALABLE).float()
+            torch.testing.assert_close(y, x.float() @ Wd.float().t(), rtol=1e-3, atol=2e-3)
+
+
+def test_routing_workspace_and_variants(ops):
+    """forward() takes the fused kernel where the ABI's hint says it wins and the composition elsewhere — same weights either way;
+    the output-tile kernels stay reachable (OPT_GEMM_CLASSIC); a split-K call without its workspace is refused, not computed wrong"""
+    from hqq_amd import _C
+    L = _C.lib()
+    assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 512, 12288, 4096, 64, 1) == 0     # 384 tiles: more than one round of workgroups
+    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 2048, 4096, 4096, 64, 1) == 0
+    assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 128, 1) == 0     # group_size 128: not this kernel
+    assert L.hqq_hip_forward_prefers_fused(3, 128, 4096, 4096, 64, 1) == 0
+    assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 1024, 4096, 4096, 64, 1, 0) == 0
+    N, K, M = 1024, 2048, 128
+    U, s, z = _layer(N, K, 4, 11, True)
+    P = ops.pack(4, U.cuda())
+    s, z = s.cuda(), z.cuda()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).half().cuda()
+    y = ops.forward(x, P, s, z, None, N, K, 64, 4)
+    assert torch.equal(y, ops.gemm(x, P, s, z, None, N, K, 64, 4))
+    comp = ops.forward(x, P, s, z, None, N, K, 64, 4, fused=False)
+    classic = ops.gemm(x, P, s, z, None, N, K, 64, 4, opts=ops.OPT_GEMM_CLASSIC)
+    torch.testing.assert_close(y.float(), comp.float(), rtol=2e-3, atol=1e-2)
+    torch.testing.assert_close(y.float(), classic.float(), rtol=2e-3, atol=1e-2)
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    rc = L.hqq_hip_gemm(4, x.data_ptr(), P.data_ptr(), s.data_ptr(), z.data_ptr(), None, out.data_ptr(), M, N, K, 64, 1, 0, None, 0, None)
+    assert rc == -5 and b"workspace" in L.hqq_hip_last_error()
+    # captured in a hipGraph (workspace reserved beforehand), replayed: same bits
+    g = torch.cuda.CUDAGraph()
+    yg = torch.empty_like(y)
+    with torch.cuda.graph(g):
+        ops.gemm(x, P, s, z, None, N, K, 64, 4, out=yg)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y)

@@ -28,6 +28,6 @@ for M, KS in ((128, 1), (128, 8), (1024, 1)):
     print(f"  M={M} KS={KS}: {e0.elapsed_time(e1) * 1e3 / 60:.1f} us", end="")
 print()
 PY
-for v in "" gp_NOPUT gp_NOLOAD gp_NOVALU gp_NOMFMA $EXTRA_VARIANTS; do
+for v in "" gp_NODMA gp_NOXDMA gp_NOVALU gp_NOMFMA gp_NOBAR $EXTRA_VARIANTS; do
   if [ -z "$v" ]; then echo -n "shipped:"; python /tmp/t.py $R; else echo -n "$v:"; HQQ_AMD_LIB=$R/tools/libhqq_hip_$v.so python /tmp/t.py $R; fi
 done

@@ -35,6 +35,9 @@ def timeit(fn, reps):
 
 def main():
     nbits = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    if len(sys.argv) > 2:
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(sys.argv[2])), exist_ok=True)
     out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
     gs = 64
     g = torch.Generator().manual_seed(0)
