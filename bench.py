@@ -510,6 +510,25 @@ def main():
                 legs[-1]["status"] = p2.status()
             except Exception as e:
                 legs.append({"name": "persistent decode engine", "error": repr(e)})
+        # 128 rows through every layer of the stack (batched decode / speculative verification / short prompts): the pipelined split-K
+        # fused GEMM (csrc/gemm_pipe.hip) against the alternative a caller has — dequantise kernel + library GEMM on the result
+        if nbits in (8, 4, 2):
+            try:
+                xs128 = {K: torch.randn(128, K, device=dev, generator=gx).to(cd) for K in xs}
+                y128 = {N_: torch.empty(128, N_, device=dev, dtype=cd) for N_ in sorted({L.N for L in blocks[0].values()})}
+                flops128 = 2.0 * 128 * nblocks * sum(N * K for _, N, K in BLOCK)
+
+                def stack128(fused):
+                    for blk in blocks:
+                        for L in blk.values():
+                            ops.forward(xs128[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=y128[L.N], fused=fused, opts=group_opts([L]))
+                for nm, fused, kern in (("7b-stack bs=128, fused dequant-GEMM (one launch + split-K reduce per layer)", True, "hqq::gemm_pipe_f16_kernel"),
+                                        ("7b-stack bs=128, dequantise kernel + library GEMM (the composition)", False, "hqq::dequantize + hipBLASLt")):
+                    leg(nm, lambda f=fused: stack128(f), nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * len(BLOCK), kern)
+                    legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
+                    legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+            except Exception as e:
+                legs.append({"name": "7b-stack bs=128", "error": repr(e)})
         out["legs"] = legs
 
     if rank == 0:

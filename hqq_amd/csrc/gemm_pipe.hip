@@ -30,7 +30,7 @@
 
 namespace hqq {
 
-constexpr int GD_BM = 128, GD_K = 64, GD_WAVES = 4, GD_T = 64 * GD_WAVES, GD_PROWS = 16 * GD_WAVES;
+constexpr int GD_BM = 128, GD_K = 64;   // waves per workgroup NW (4 or 8) is a template parameter: 16 NW packed rows per tile
 constexpr int GD_DX = 4, GD_PX = 3;      // x ring: stages, steps ahead
 constexpr int GD_DW = 8, GD_PW = 5;      // packed-weight ring: slots, steps ahead
 constexpr int GD_DM = 4;                 // (zero, scale) ring: slots of two steps
@@ -115,12 +115,13 @@ template <int NBITS> struct GdMeta {   // (zero, scale) DMA: one dword = the two
   static constexpr int SLOT = NI * 256;                        // bytes per wave and pair of steps
 };
 
-template <int NBITS, bool SUB>
-__global__ __launch_bounds__(GD_T, 2) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
+template <int NBITS, bool SUB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
   constexpr int PER = 8 / NBITS;
+  constexpr int GD_WAVES = NW, GD_T = 64 * NW, GD_PROWS = 16 * NW, XP = 16 / NW;   // XP: x DMA pieces (1 KiB = 8 token rows) per wave and step
   using MD = GdMeta<NBITS>;
   constexpr int X_BYTES = GD_DX * GD_XSTAGE;                   // 64 KiB
-  constexpr int W_BYTES = GD_DW * GD_WAVES * 1024;             // 32 KiB
+  constexpr int W_BYTES = GD_DW * GD_WAVES * 1024;             // 32 / 64 KiB
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];   // [x ring | weight ring | (zero, scale) ring]
   uint8_t* const xring = lds;
   uint8_t* const wring = lds + X_BYTES;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(GD_T, 2) void gemm_pipe_f16_kernel(const GdArgs a) 
   const bool w_active = (p0 + r) < rows_per_slab;
   const int wrow = w_active ? p0 + r : rows_per_slab - 1;
   const uint8_t* wsrc = a.Wq + static_cast<int64_t>(wrow) * K + c * 16 + static_cast<int64_t>(kt0) * GD_K;
-  const half_t* xsrc[4];
+  const half_t* xsrc[XP];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {   // instruction q of this wave fills rows 32 w + 8 q .. + 7 of the stage: lane -> (row, position)
-    const int row = 32 * wave + 8 * q + (lane >> 3), pos = lane & 7;
+  for (int q = 0; q < XP; ++q) {   // piece XP w + q fills rows 8 (XP w + q) .. + 7 of the stage: lane -> (row, position)
+    const int row = 8 * (XP * wave + q) + (lane >> 3), pos = lane & 7;
     const int chunk = pos ^ gd_swz(row);
     xsrc[q] = a.x + static_cast<int64_t>(m0 + row < M ? m0 + row : 0) * K + chunk * 8 + static_cast<int64_t>(kt0) * GD_K;
   }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(GD_T, 2) void gemm_pipe_f16_kernel(const GdArgs a) 
   auto issue_x = [&](int step) {
     const int sc = step < nsteps ? step : nsteps - 1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gd_dma16(xsrc[q] + static_cast<int64_t>(sc) * GD_K, xring + (step % GD_DX) * GD_XSTAGE + (4 * wave + q) * 1024);
+    for (int q = 0; q < XP; ++q) gd_dma16(xsrc[q] + static_cast<int64_t>(sc) * GD_K, xring + (step % GD_DX) * GD_XSTAGE + (XP * wave + q) * 1024);
   };
 
   // ---- the lane's packed bytes and group constants of a step, out of the rings; rebuilt into A fragments ----
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(GD_T, 2) void gemm_pipe_f16_kernel(const GdArgs a) 
     __builtin_amdgcn_sched_barrier(0);   // reads first: left alone the scheduler sinks them below the MFMAs they were meant to hide under
     mma(0, ca0, ca1, bl0, bl1);
     // (lgkmcnt(0): this wave's fragment reads have left the LDS before another wave's DMA may overwrite the stage)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(5 + (((par + GD_PW) & 1) ? MD::NI : 0)) : "memory");   // N = what iteration i - 1 issued
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + XP + (((par + GD_PW) & 1) ? MD::NI : 0)) : "memory");   // N = what iteration i - 1 issued
     __builtin_amdgcn_s_barrier();
     issue_w(i + GD_PW);
     if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
@@ -310,9 +311,9 @@ __global__ __launch_bounds__(GD_T, 2) void gemm_pipe_f16_kernel(const GdArgs a) 
 // Second launch of a split-K call: output quad (tile, slab s, token tile j, thread) = the sum of the KS parked tiles in split order
 // (four tiles' loads of a thread in flight at once, every CU takes part), rounded once, + bias.  One finishing workgroup per tile
 // inside the first kernel (ticket scheme) read its KS x 64 KiB alone and cost 2-3 us per split.
-template <int NBITS>
-__global__ __launch_bounds__(GD_T) void gemm_pipe_reduce_kernel(const GdArgs a) {
-  constexpr int PER = 8 / NBITS;
+template <int NBITS, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs a) {
+  constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, c = lane >> 4;
   const int sj = blockIdx.x % (PER * GD_MT), tile = blockIdx.x / (PER * GD_MT);
@@ -352,46 +353,74 @@ __global__ __launch_bounds__(GD_T) void gemm_pipe_reduce_kernel(const GdArgs a) 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
-struct GpPlan { int n_tiles, m_tiles, KS, kps; };
+struct GpPlan { int NW, n_tiles, m_tiles, KS, kps; };
 
-// Shapes only (never the data): the split depends on (M, N, K), so a row of y can differ in the last bit between batch sizes that
-// choose different splits — as with any split-K GEMM — but is reproducible run to run.
-static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
-  const int per = 8 / nbits;
+static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int ks) {
   GpPlan p;
-  const int64_t rows_per_slab = N / per;
-  p.n_tiles = static_cast<int>((rows_per_slab + GD_PROWS - 1) / GD_PROWS);
-  p.m_tiles = static_cast<int>((M + GD_BM - 1) / GD_BM);
-  const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
+  const int64_t rows_per_slab = N / (8 / nbits);
   const int nk = static_cast<int>(K / GD_K);
-  int ks = 1;
-  const int forced = static_cast<int>(opts >> 24);
-  if (forced) {
-    ks = forced;
-  } else if (tiles < 256) {
-    ks = static_cast<int>(256 / tiles);                // one workgroup per CU is the target (100 KiB of LDS each): measured best at tiles x KS = 128..256
-  }
+  p.NW = nw;
+  p.m_tiles = static_cast<int>((M + GD_BM - 1) / GD_BM);
+  p.n_tiles = static_cast<int>((rows_per_slab + 16 * nw - 1) / (16 * nw));
   if (ks > GD_MAX_KS) ks = GD_MAX_KS;
-  if (ks > nk / 16) ks = nk / 16 > 0 ? nk / 16 : 1;    // at least sixteen steps (1024 k) per split: below that the prologue and the parked tile cost more than the split saves
+  if (ks < 1) ks = 1;
   p.kps = (nk + ks - 1) / ks;
   p.kps += p.kps & 1;                                   // even: the (zero, scale) DMA fetches two steps per dword
   p.KS = (nk + p.kps - 1) / p.kps;                      // no empty split
   return p;
 }
 
+// Estimated time of a plan in microseconds: a model of the measurements in profiles/r02_prefill_sweep.md (MI355X, one workgroup per CU):
+// rounds of workgroups x (steps x time per step + a fixed 5 us), the time per step growing with the number of CUs that pull the same x
+// tiles through L2 at once; a split adds the second launch and 0.4 us per MiB of parked fp32 tiles.  Picks the measured-best
+// (waves, splits) for 15 of the 16 Llama-2-7B cases swept and is within 12 % of the measured time everywhere.
+static double gp_cost(const GpPlan& p, int64_t M, int64_t N) {
+  const double wgs = static_cast<double>(p.n_tiles) * p.m_tiles * p.KS;
+  const double rounds = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
+  const double active = wgs < 256.0 ? wgs : 256.0;
+  const double tstep = (p.NW == 4 ? 0.50 : 0.85) * (1.0 + 0.45 * active / 256.0);
+  double t = rounds * (p.kps * tstep + 5.0);
+  if (p.KS > 1) t += 1.5 + 0.4 * p.KS * static_cast<double>(p.m_tiles) * GD_BM * static_cast<double>(N) * 4.0 / 1.0e6;
+  return t;
+}
+
+// Shapes only (never the data): the split depends on (M, N, K), so a row of y can differ in the last bit between batch sizes that
+// choose different splits — as with any split-K GEMM — but is reproducible run to run.
+static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
+  const int nk = static_cast<int>(K / GD_K);
+  const int forced_ks = static_cast<int>(opts >> 24);
+  const int forced_nw = (opts & HQQ_OPT_GEMM_WIDE) ? 8 : (opts & HQQ_OPT_GEMM_NARROW) ? 4 : 0;
+  static const int KSS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+  GpPlan best = gp_make(nbits, M, N, K, forced_nw ? forced_nw : 4, forced_ks ? forced_ks : 1);
+  double best_cost = gp_cost(best, M, N);
+  for (int nw = 4; nw <= 8; nw += 4) {
+    if (forced_nw && nw != forced_nw) continue;
+    for (int ks : KSS) {
+      if (forced_ks && ks != 1) continue;
+      const GpPlan p = gp_make(nbits, M, N, K, nw, forced_ks ? forced_ks : ks);
+      // at least sixteen steps (1024 k) per split: below that the prologue and the parked tile cost more than the split saves
+      if (!forced_ks && p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
+      const double c = gp_cost(p, M, N);
+      if (c < best_cost) { best = p; best_cost = c; }
+    }
+  }
+  return best;
+}
+
 size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   if (p.KS <= 1) return 0;
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
-  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * GD_BM * GD_PROWS * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
+  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * GD_BM * (16 * p.NW) * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
 }
 
-// Where this kernel beats "dequantise kernel + library GEMM" on MI355X (tools/sweep_prefill.py, Llama-2-7B shapes, int4): up to 256 rows
-// everywhere (1.1-1.8x), and up to 1024 rows as long as the tiles fit one round of workgroups (o / down: 1.0-1.4x); with more tiles than
-// CUs the second, partly filled round costs more than the library's tile scheduler loses.
+// Where this kernel beats "dequantise kernel + library GEMM" on MI355X (profiles/r02_prefill_sweep.md, Llama-2-7B shapes, int4): up to
+// 256 rows everywhere (1.15-2.65x), and up to 512 rows as long as the planned workgroups fit one round (o, down: 1.1-1.4x; q|k|v: level);
+// with more workgroups than CUs the second, partly filled round costs more than the library's tile scheduler loses, and from ~768 rows
+// on the library's 256 x 256 tiles are ahead (0.6-0.8 PFLOP/s here against 0.8-1.45).
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
   const GpPlan p = gp_plan(nbits, M, N, K, 0);
-  return M <= 256 || (M <= 1024 && static_cast<int64_t>(p.n_tiles) * p.m_tiles <= 256);
+  return M <= 256 || (M <= 512 && static_cast<int64_t>(p.n_tiles) * p.m_tiles * p.KS <= 256);
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {
@@ -401,23 +430,23 @@ bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, in
   return N % per == 0 && (N / per) % 4 == 0 && gs == 64 && K % 128 == 0 && M >= 1;
 }
 
-template <int NBITS, bool SUB>
+template <int NBITS, bool SUB, int NW>
 static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
-  constexpr int lds_bytes = GD_DX * GD_XSTAGE + GD_DW * GD_WAVES * 1024 + GD_DM * GD_WAVES * GdMeta<NBITS>::SLOT;
+  constexpr int lds_bytes = GD_DX * GD_XSTAGE + GD_DW * NW * 1024 + GD_DM * NW * GdMeta<NBITS>::SLOT;
   static bool attr_done = false;   // (idempotent; a race sets it twice)
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       set_error("hqq_hip_gemm: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
       return static_cast<int>(e);   // (positive: a HIP error, as check_launch reports them)
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB>), dim3(static_cast<unsigned>(blocks)), dim3(GD_T), lds_bytes, st, a);
+  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
   int rc = check_launch("hqq_hip_gemm(pipelined)");
   if (rc || a.KS <= 1) return rc;
   const int64_t rblocks = static_cast<int64_t>(a.n_tiles) * a.m_tiles * ((8 / NBITS) * GD_MT);
-  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS>), dim3(static_cast<unsigned>(rblocks)), dim3(GD_T), 0, st, a);
+  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
 
@@ -443,7 +472,8 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTER_BYTES);
   }
   const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0;
-#define GP_GO(NB) (sub ? gp_launch<NB, true>(a, blocks, st) : gp_launch<NB, false>(a, blocks, st))
+#define GP_GO(NB) (p.NW == 8 ? (sub ? gp_launch<NB, true, 8>(a, blocks, st) : gp_launch<NB, false, 8>(a, blocks, st)) \
+                             : (sub ? gp_launch<NB, true, 4>(a, blocks, st) : gp_launch<NB, false, 4>(a, blocks, st)))
   if (nbits == 8) return GP_GO(8);
   if (nbits == 4) return GP_GO(4);
   return GP_GO(2);

@@ -109,7 +109,9 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_GEMM_CLASSIC  32u   /* fused GEMM: the plain output-tile kernels for every M (tests / tuning; default: the pipelined split-K
                                        kernel up to 1024 rows) */
 #define HQQ_OPT_SKINNY_KS(n) ((uint32_t)(n) << 24)   /* 5..64 rows, and the split-K fused GEMM: force n K-splits (tuning; 0 = built-in rule) */
-#define HQQ_OPT_ALL (63u | (255u << 24))
+#define HQQ_OPT_GEMM_NARROW  64u   /* pipelined fused GEMM: force 4 waves per workgroup (64 packed rows per tile) — tuning */
+#define HQQ_OPT_GEMM_WIDE   128u   /* pipelined fused GEMM: force 8 waves per workgroup (128 packed rows per tile) — tuning */
+#define HQQ_OPT_ALL (255u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.

@@ -114,12 +114,13 @@ def test_routing_workspace_and_variants(ops):
     from hqq_amd import _C
     L = _C.lib()
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 512, 12288, 4096, 64, 1) == 0     # 384 tiles: more than one round of workgroups
-    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 512, 22016, 4096, 64, 1) == 0     # 344 tiles of 8 waves: more than one round of workgroups
+    assert L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 2048, 4096, 4096, 64, 1) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 128, 1) == 0     # group_size 128: not this kernel
     assert L.hqq_hip_forward_prefers_fused(3, 128, 4096, 4096, 64, 1) == 0
-    assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 1024, 4096, 4096, 64, 1, 0) == 0
+    assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 1024, 12288, 4096, 64, 1, 0) == 0
     N, K, M = 1024, 2048, 128
     U, s, z = _layer(N, K, 4, 11, True)
     P = ops.pack(4, U.cuda())

@@ -41,7 +41,8 @@ def main():
     out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
     gs = 64
     g = torch.Generator().manual_seed(0)
-    ksweep = len(sys.argv) > 3 and sys.argv[3] == "ks"
+    ksweep = len(sys.argv) > 3 and sys.argv[3].startswith("ks")
+    wide = {"ks": 0, "ks4": ops.OPT_GEMM_NARROW, "ks8": ops.OPT_GEMM_WIDE}.get(sys.argv[3] if len(sys.argv) > 3 else "ks", 0)
     print(f"## int{nbits} fp16, us per call (TFLOP/s): fused kernels vs dequantise + library GEMM\n", file=out)
     if ksweep:
         KSS = [1, 2, 4, 8, 16]
@@ -76,7 +77,7 @@ def main():
                 ref = x.float() @ Wd.float().t()
                 err = ((y.float() - ref).abs().max() / ref.abs().max()).item()
                 cols = [t(lambda: ops.gemm(x, P, s, z, None, N, K, gs, nbits, opts=base))]
-                cols += [t(lambda k=k: ops.gemm(x, P, s, z, None, N, K, gs, nbits, opts=base | (k << 24))) for k in KSS]
+                cols += [t(lambda k=k: ops.gemm(x, P, s, z, None, N, K, gs, nbits, opts=base | wide | (k << 24))) for k in KSS]
                 print(f"| {name} | {M} | " + " | ".join(cols) + f" | {err:.1e} |", file=out)
             else:
                 a = t(lambda: ops.gemm(x, P, s, z, None, N, K, gs, nbits, opts=base))
