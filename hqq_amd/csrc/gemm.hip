@@ -448,9 +448,13 @@ bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                   int64_t M, int64_t N, int64_t K, int64_t gs, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
 
-// which fused GEMM serves M rows: the pipelined split-K kernel up to GEMM_PIPE_MAX_M rows (measured against the tile kernels and
-// against dequantise + library GEMM, tools/sweep_prefill.py), the round-1 tile kernels beyond
-constexpr int64_t GEMM_PIPE_MAX_M = 1024;
+// which fused GEMM serves a call: the pipelined kernel (gemm_pipe.hip) wherever it applies — it is ahead of the output-tile kernels
+// below at every M (0.8-1.14 PFLOP/s against 0.5-0.84 from 2048 rows on, 2-4x below 512) —, the output-tile kernels for the group sizes
+// and K it does not cover
+#ifndef GEMM_PIPE_MAX_M_VALUE
+#define GEMM_PIPE_MAX_M_VALUE (int64_t(1) << 40)
+#endif
+constexpr int64_t GEMM_PIPE_MAX_M = GEMM_PIPE_MAX_M_VALUE;
 static bool use_pipe(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts) {
   if (opts & (HQQ_OPT_GEMM_REGTILE | HQQ_OPT_GEMM_CLASSIC)) return false;
   return (M <= GEMM_PIPE_MAX_M || nbits == 8) && gemm_pipe_covers(nbits, M, N, K, gs, dtype);   // (8-bit: the only fused GEMM there is)

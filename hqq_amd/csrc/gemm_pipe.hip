@@ -30,13 +30,17 @@
 
 namespace hqq {
 
-constexpr int GD_BM = 128, GD_K = 64;   // waves per workgroup NW (4 or 8) is a template parameter: 16 NW packed rows per tile
-constexpr int GD_DX = 4, GD_PX = 3;      // x ring: stages, steps ahead
-constexpr int GD_DW = 8, GD_PW = 5;      // packed-weight ring: slots, steps ahead
-constexpr int GD_DM = 4;                 // (zero, scale) ring: slots of two steps
-constexpr int GD_MT = GD_BM / 16;        // token tiles
-constexpr int GD_XSTAGE = GD_BM * GD_K * 2;
+constexpr int GD_K = 64;   // k per step.  Waves per workgroup NW (4 or 8: 16 NW packed rows per tile) and tokens per tile BM (128 or 256) are template parameters
 constexpr int GD_MAX_KS = 16;
+#ifndef GP_TSTEP_256
+#define GP_TSTEP_256 1.45   /* us per step of the 8-wave, 256-token tile at low load (cost model) */
+#endif
+template <int NW, int BM> struct GdCfg {   // LDS rings: x stages / steps ahead, packed-weight slots / steps ahead (odd), (zero, scale) slots of two steps
+  static constexpr int DX = BM == 128 ? 4 : 3, PX = DX - 1;
+  static constexpr int DW = BM == 128 ? 8 : 4, PW = BM == 128 ? 5 : 3;
+  static constexpr int DM = BM == 128 ? 4 : 2;
+  static constexpr int XSTAGE = BM * GD_K * 2;
+};
 
 struct GdArgs {
   const half_t* x;
@@ -115,10 +119,12 @@ template <int NBITS> struct GdMeta {   // (zero, scale) DMA: one dword = the two
   static constexpr int SLOT = NI * 256;                        // bytes per wave and pair of steps
 };
 
-template <int NBITS, bool SUB, int NW>
+template <int NBITS, bool SUB, int NW, int BM>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
   constexpr int PER = 8 / NBITS;
-  constexpr int GD_WAVES = NW, GD_T = 64 * NW, GD_PROWS = 16 * NW, XP = 16 / NW;   // XP: x DMA pieces (1 KiB = 8 token rows) per wave and step
+  using CF = GdCfg<NW, BM>;
+  constexpr int GD_BM = BM, GD_MT = BM / 16, GD_DX = CF::DX, GD_PX = CF::PX, GD_DW = CF::DW, GD_PW = CF::PW, GD_DM = CF::DM, GD_XSTAGE = CF::XSTAGE;
+  constexpr int GD_WAVES = NW, GD_T = 64 * NW, GD_PROWS = 16 * NW, XP = BM / 8 / NW;   // XP: x DMA pieces (1 KiB = 8 token rows) per wave and step
   using MD = GdMeta<NBITS>;
   constexpr int X_BYTES = GD_DX * GD_XSTAGE;                   // 64 KiB
   constexpr int W_BYTES = GD_DW * GD_WAVES * 1024;             // 32 / 64 KiB
@@ -130,7 +136,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, c = lane >> 4;
-  const int b = blockIdx.x;
+  // XCD-aware order (workgroup b runs on XCD b % 8 — observed; a speed assumption only): each XCD gets a contiguous run of logical
+  // tiles, i.e. a band of token tiles x all feature tiles — its L2 then holds a few x tiles and one pass over the packed weights
+  // instead of every x tile of the round.  Bijective for any grid size.
+  int b;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
   const int nt = b % a.n_tiles, rest = b / a.n_tiles, mt = rest % a.m_tiles, ks = rest / a.m_tiles;
   const int N = a.N, K = a.K, M = a.M, G = a.G;
   const int rows_per_slab = N / PER;
@@ -216,53 +230,72 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   rebuild(read_w(0), 0, a0[0], a1[0]);
 
   // ---- main loop, one step per iteration (unrolled by two: the (zero, scale) ring moves every other step).  With one wave per SIMD
-  //      nothing hides an LDS round trip but the wave's own MFMAs, so the step is cut in two token halves and every fragment read is
-  //      issued one half ahead of the MFMAs that use it — the workgroup barrier sits in the MIDDLE of a step's MFMA work.  Iteration i:
+  //      nothing hides an LDS round trip but the wave's own MFMAs, so the step is cut in parts of 64 tokens and every fragment read is
+  //      issued one part ahead of the MFMAs that use it — the workgroup barrier sits INSIDE a step's MFMA work.  Iteration i (two parts):
   //        LDS    B fragments of (step i, tokens 64..127)
   //        MFMA   (step i, tokens 0..63)            [fragments read during iteration i - 1]
   //        wait   all but the DMA instructions of iteration i - 1: x of step i + 1 and the weights of step i + 1 have landed; barrier
   //        DMA    weights of step i + 5 (+ constants), x of step i + 3   [the slots they overwrite were last read before this barrier]
   //        LDS    B fragments of (step i + 1, tokens 0..63); packed bytes (+ constants) of step i + 1
   //        MFMA   (step i, tokens 64..127), and under them the VALU rebuild of step i + 1 into the other A fragment set ----
-  constexpr int HT = GD_MT / 2;           // token tiles per half
-  h8_t bl0[HT], bl1[HT], bh0[HT], bh1[HT];   // B fragments of the low / high token half
-  auto read_b = [&](int step, int half, h8_t (&f0)[HT], h8_t (&f1)[HT]) {
+  constexpr int HT = 4, NQ = GD_MT / HT;   // the step's tokens in NQ parts of 64 (2 at 128 tokens per tile, 4 at 256)
+  h8_t bA0[HT], bA1[HT], bB0[HT], bB1[HT];   // B fragments of the even / odd parts
+  auto read_b = [&](int step, int part, h8_t (&f0)[HT], h8_t (&f1)[HT]) {
     const uint8_t* xs = xring + (step % GD_DX) * GD_XSTAGE;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
-      const int row = (half * HT + j) * 16 + r;
+      const int row = (part * HT + j) * 16 + r;
       f0[j] = *reinterpret_cast<const h8_t*>(xs + row * 128 + (((2 * c) ^ gd_swz(row)) << 4));
       f1[j] = *reinterpret_cast<const h8_t*>(xs + row * 128 + (((2 * c + 1) ^ gd_swz(row)) << 4));
     }
   };
-  auto mma = [&](int half, const h8_t (&ca0)[PER], const h8_t (&ca1)[PER], const h8_t (&f0)[HT], const h8_t (&f1)[HT]) {
+  auto mma = [&](int part, const h8_t (&ca0)[PER], const h8_t (&ca1)[PER], const h8_t (&f0)[HT], const h8_t (&f1)[HT]) {
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
-      for (int j = 0; j < HT; ++j) acc[s][half * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca0[s], f0[j], acc[s][half * HT + j], 0, 0, 0);
+      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca0[s], f0[j], acc[s][part * HT + j], 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
-      for (int j = 0; j < HT; ++j) acc[s][half * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca1[s], f1[j], acc[s][half * HT + j], 0, 0, 0);
+      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca1[s], f1[j], acc[s][part * HT + j], 0, 0, 0);
   };
-  read_b(0, 0, bl0, bl1);
+  read_b(0, 0, bA0, bA1);
+  // DMA instructions issued after the ones the next step needs: the groups of the PX - 2 iterations in between
   auto iter = [&](int i, auto parity, h8_t (&ca0)[PER], h8_t (&ca1)[PER], h8_t (&na0)[PER], h8_t (&na1)[PER]) {
     constexpr int par = decltype(parity)::value;   // i & 1
-    read_b(i, 1, bh0, bh1);
-    __builtin_amdgcn_sched_barrier(0);   // reads first: left alone the scheduler sinks them below the MFMAs they were meant to hide under
-    mma(0, ca0, ca1, bl0, bl1);
+    constexpr int N_OUT = GD_PX == 3 ? 1 + XP + (((par + GD_PW) & 1) ? MD::NI : 0) : 0;   // PX = 3: what iteration i - 1 issued; PX = 2: nothing
+#pragma unroll
+    for (int q = 1; q < NQ; ++q) {
+      if (q & 1) read_b(i, q, bB0, bB1); else read_b(i, q, bA0, bA1);
+      __builtin_amdgcn_sched_barrier(0);   // reads first: left alone the scheduler sinks them below the MFMAs they were meant to hide under
+      if (q & 1) mma(q - 1, ca0, ca1, bA0, bA1); else mma(q - 1, ca0, ca1, bB0, bB1);
+    }
     // (lgkmcnt(0): this wave's fragment reads have left the LDS before another wave's DMA may overwrite the stage)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + XP + (((par + GD_PW) & 1) ? MD::NI : 0)) : "memory");   // N = what iteration i - 1 issued
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_OUT) : "memory");
     __builtin_amdgcn_s_barrier();
-    issue_w(i + GD_PW);
-    if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
-    issue_x(i + GD_PX);
-    read_b(i + 1, 0, bl0, bl1);
+    constexpr bool SPREAD = NW == 8;   // measured: +5 % with two waves per SIMD, -3..9 % with one (there the earlier issue matters more)
+    auto issue_all = [&]() {
+      issue_w(i + GD_PW);
+      if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
+      issue_x(i + GD_PX);
+    };
+    if constexpr (!SPREAD) issue_all();
+    read_b(i + 1, 0, bA0, bA1);
     if constexpr (par == 1) fetch_meta(i + 1);
     const u32x4 raw = read_w(i + 1);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SPREAD) issue_all();   // the DMA issue (60-185 cycles a piece in a burst) goes UNDER the last part's MFMAs, like the rebuild's VALU work
     rebuild(raw, i + 1, na0, na1);
-    mma(1, ca0, ca1, bh0, bh1);
+    mma(NQ - 1, ca0, ca1, bB0, bB1);
+    if constexpr (SPREAD) {
+      constexpr int NMF = PER * HT * 2, NDMA = 1 + XP + MD::NI;
+#pragma unroll
+      for (int t = 0; t < NMF; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (100 + NMF - 1) / NMF, 0);
+        if (t * NDMA / NMF != (t + 1) * NDMA / NMF) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one DMA piece every NMF / NDMA MFMAs
+      }
+    }
   };
   for (int i = 0; i < nsteps; i += 2) {
     iter(i, std::integral_constant<int, 0>{}, a0[0], a1[0], a0[1], a1[1]);
@@ -311,9 +344,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
 // Second launch of a split-K call: output quad (tile, slab s, token tile j, thread) = the sum of the KS parked tiles in split order
 // (four tiles' loads of a thread in flight at once, every CU takes part), rounded once, + bias.  One finishing workgroup per tile
 // inside the first kernel (ticket scheme) read its KS x 64 KiB alone and cost 2-3 us per split.
-template <int NBITS, int NW>
+template <int NBITS, int NW, int BM>
 __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs a) {
-  constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW;
+  constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW, GD_BM = BM, GD_MT = BM / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, c = lane >> 4;
   const int sj = blockIdx.x % (PER * GD_MT), tile = blockIdx.x / (PER * GD_MT);
@@ -353,14 +386,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
-struct GpPlan { int NW, n_tiles, m_tiles, KS, kps; };
+struct GpPlan { int NW, BM, n_tiles, m_tiles, KS, kps; };
 
-static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int ks) {
+static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm, int ks) {
   GpPlan p;
   const int64_t rows_per_slab = N / (8 / nbits);
   const int nk = static_cast<int>(K / GD_K);
   p.NW = nw;
-  p.m_tiles = static_cast<int>((M + GD_BM - 1) / GD_BM);
+  p.BM = bm;
+  p.m_tiles = static_cast<int>((M + bm - 1) / bm);
   p.n_tiles = static_cast<int>((rows_per_slab + 16 * nw - 1) / (16 * nw));
   if (ks > GD_MAX_KS) ks = GD_MAX_KS;
   if (ks < 1) ks = 1;
@@ -378,9 +412,10 @@ static double gp_cost(const GpPlan& p, int64_t M, int64_t N) {
   const double wgs = static_cast<double>(p.n_tiles) * p.m_tiles * p.KS;
   const double rounds = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
   const double active = wgs < 256.0 ? wgs : 256.0;
-  const double tstep = (p.NW == 4 ? 0.50 : 0.85) * (1.0 + 0.45 * active / 256.0);
+  const double base = p.BM == 256 ? GP_TSTEP_256 : (p.NW == 4 ? 0.50 : 0.85);
+  const double tstep = base * (1.0 + 0.45 * active / 256.0);
   double t = rounds * (p.kps * tstep + 5.0);
-  if (p.KS > 1) t += 1.5 + 0.4 * p.KS * static_cast<double>(p.m_tiles) * GD_BM * static_cast<double>(N) * 4.0 / 1.0e6;
+  if (p.KS > 1) t += 1.5 + 0.4 * p.KS * static_cast<double>(p.m_tiles) * p.BM * static_cast<double>(N) * 4.0 / 1.0e6;
   return t;
 }
 
@@ -390,14 +425,17 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
   const int nk = static_cast<int>(K / GD_K);
   const int forced_ks = static_cast<int>(opts >> 24);
   const int forced_nw = (opts & HQQ_OPT_GEMM_WIDE) ? 8 : (opts & HQQ_OPT_GEMM_NARROW) ? 4 : 0;
+  const bool both = (opts & HQQ_OPT_GEMM_WIDE) && (opts & HQQ_OPT_GEMM_NARROW);   // both bits: the 256-token tile (8 waves)
   static const int KSS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
-  GpPlan best = gp_make(nbits, M, N, K, forced_nw ? forced_nw : 4, forced_ks ? forced_ks : 1);
+  static const int SHAPES[3][2] = {{4, 128}, {8, 128}, {8, 256}};
+  GpPlan best = gp_make(nbits, M, N, K, both ? 8 : (forced_nw ? forced_nw : 4), both && nbits != 2 ? 256 : 128, forced_ks ? forced_ks : 1);
   double best_cost = gp_cost(best, M, N);
-  for (int nw = 4; nw <= 8; nw += 4) {
-    if (forced_nw && nw != forced_nw) continue;
+  for (const auto& sh : SHAPES) {
+    if (both ? sh[1] != 256 : (forced_nw && (sh[0] != forced_nw || sh[1] != 128))) continue;
+    if (sh[1] == 256 && nbits == 2) continue;   // four slabs x 16 token tiles of accumulators do not fit the register file
     for (int ks : KSS) {
       if (forced_ks && ks != 1) continue;
-      const GpPlan p = gp_make(nbits, M, N, K, nw, forced_ks ? forced_ks : ks);
+      const GpPlan p = gp_make(nbits, M, N, K, sh[0], sh[1], forced_ks ? forced_ks : ks);
       // at least sixteen steps (1024 k) per split: below that the prologue and the parked tile cost more than the split saves
       if (!forced_ks && p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
       const double c = gp_cost(p, M, N);
@@ -411,16 +449,15 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   if (p.KS <= 1) return 0;
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
-  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * GD_BM * (16 * p.NW) * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
+  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * p.BM * (16 * p.NW) * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
 }
 
 // Where this kernel beats "dequantise kernel + library GEMM" on MI355X (profiles/r02_prefill_sweep.md, Llama-2-7B shapes, int4): up to
-// 256 rows everywhere (1.15-2.65x), and up to 512 rows as long as the planned workgroups fit one round (o, down: 1.1-1.4x; q|k|v: level);
-// with more workgroups than CUs the second, partly filled round costs more than the library's tile scheduler loses, and from ~768 rows
-// on the library's 256 x 256 tiles are ahead (0.6-0.8 PFLOP/s here against 0.8-1.45).
+// 512 rows everywhere (1.04-2.7x; the dequantise pass is as long as the GEMM there).  Beyond, the library's tile scheduler and hand-tuned
+// loop are ahead by 2-30 % in most shapes (0.95-1.14 PFLOP/s here at 8192 rows against 1.2-1.4 for the composition), so the hint says no.
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
-  const GpPlan p = gp_plan(nbits, M, N, K, 0);
-  return M <= 256 || (M <= 512 && static_cast<int64_t>(p.n_tiles) * p.m_tiles * p.KS <= 256);
+  (void)nbits; (void)N; (void)K;
+  return M <= 512;
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {
@@ -430,23 +467,27 @@ bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, in
   return N % per == 0 && (N / per) % 4 == 0 && gs == 64 && K % 128 == 0 && M >= 1;
 }
 
-template <int NBITS, bool SUB, int NW>
+template <int NBITS, bool SUB, int NW, int BM>
 static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
-  constexpr int lds_bytes = GD_DX * GD_XSTAGE + GD_DW * NW * 1024 + GD_DM * NW * GdMeta<NBITS>::SLOT;
-  static bool attr_done = false;   // (idempotent; a race sets it twice)
+  using CF = GdCfg<NW, BM>;
+  constexpr int lds_bytes = CF::DX * CF::XSTAGE + CF::DW * NW * 1024 + CF::DM * NW * GdMeta<NBITS>::SLOT;
+  static bool done_on[64] = {};    // per device (the attribute belongs to the function ON a device); idempotent: a race sets it twice
+  int devid = 0;
+  (void)hipGetDevice(&devid);
+  bool& attr_done = done_on[devid & 63];
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB, NW, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       set_error("hqq_hip_gemm: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
       return static_cast<int>(e);   // (positive: a HIP error, as check_launch reports them)
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
+  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW, BM>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
   int rc = check_launch("hqq_hip_gemm(pipelined)");
   if (rc || a.KS <= 1) return rc;
-  const int64_t rblocks = static_cast<int64_t>(a.n_tiles) * a.m_tiles * ((8 / NBITS) * GD_MT);
-  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
+  const int64_t rblocks = static_cast<int64_t>(a.n_tiles) * a.m_tiles * ((8 / NBITS) * (BM / 16));
+  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW, BM>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
 
@@ -455,7 +496,7 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
   const int64_t blocks = tiles * p.KS;
-  if (blocks * ((8 / nbits) * GD_MT) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
+  if (blocks * ((8 / nbits) * (p.BM / 16)) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
   GdArgs a;
   a.x = static_cast<const half_t*>(x); a.Wq = static_cast<const uint8_t*>(Wq); a.scale = static_cast<const half_t*>(scale);
   a.zero = static_cast<const half_t*>(zero); a.bias = static_cast<const half_t*>(bias); a.y = static_cast<half_t*>(y);
@@ -472,12 +513,13 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTER_BYTES);
   }
   const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0;
-#define GP_GO(NB) (p.NW == 8 ? (sub ? gp_launch<NB, true, 8>(a, blocks, st) : gp_launch<NB, false, 8>(a, blocks, st)) \
-                             : (sub ? gp_launch<NB, true, 4>(a, blocks, st) : gp_launch<NB, false, 4>(a, blocks, st)))
+#define GP_GO2(NB, SB) (p.BM == 256 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 256>(a, blocks, st) /* (never planned at 2 bits: 256 accumulator registers) */ : p.NW == 8 ? gp_launch<NB, SB, 8, 128>(a, blocks, st) : gp_launch<NB, SB, 4, 128>(a, blocks, st))
+#define GP_GO(NB) (sub ? GP_GO2(NB, true) : GP_GO2(NB, false))
   if (nbits == 8) return GP_GO(8);
   if (nbits == 4) return GP_GO(4);
   return GP_GO(2);
 #undef GP_GO
+#undef GP_GO2
 }
 
 }  // namespace hqq

@@ -90,6 +90,32 @@ def test_split_k_is_reproducible_and_order_is_fixed(ops, nbits):
         assert torch.equal(ops.gemm(e, P, s, z, None, N, K, 64, nbits, opts=o), Wd[:, cols].t().contiguous())
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+def test_every_tile_shape_forced(ops, oracle, nbits):
+    """the three tile shapes (4 waves x 128 tokens, 8 x 128, 8 x 256; the last not at 2 bits) forced on ragged M and N: same exact
+    weights (one-hot probes), results within the oracle tolerance, and the plan's own choice equals one of them bit for bit"""
+    for (M, N, K) in ((300, 272, 1024), (520, 1040, 512)):
+        U, s, z = _layer(N, K, nbits, M + N, True)
+        P = oracle.pack(nbits, U.numpy())
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).half()
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half()
+        yo, _ = oracle.matmul(x.numpy(), oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, 64, 1), bias.numpy(), 1)
+        Pd, sd, zd, xd, bd = dev(P), s.cuda(), z.cuda(), x.cuda(), bias.cuda()
+        Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, 64, nbits)
+        e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+        cols = torch.arange(M, device="cuda") * 13 % K
+        e[torch.arange(M, device="cuda"), cols] = 1.0
+        outs = []
+        for tile in (ops.OPT_GEMM_NARROW, ops.OPT_GEMM_WIDE, ops.OPT_GEMM_NARROW | ops.OPT_GEMM_WIDE):
+            o = ops.OPT_META_SCALABLE | tile
+            y = ops.gemm(xd, Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
+            torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=2e-3, atol=2e-3)   # (one fp16 ulp: fp32 summation order vs the oracle's double)
+            assert torch.equal(ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=o), Wdev[:, cols].t().contiguous())
+            outs.append(y)
+        auto = ops.gemm(xd, Pd, sd, zd, bd, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE)
+        assert any(torch.equal(auto, y) for y in outs)
+
+
 def test_full_size_layers_one_hot_exact_and_linear(ops):
     """Llama-2-7B shapes at 128 and 1000 rows: every weight the kernel multiplies is the dequantised weight (one-hot rows), and the
     result is linear in x — size-independent properties, no oracle needed"""
@@ -114,13 +140,11 @@ def test_routing_workspace_and_variants(ops):
     from hqq_amd import _C
     L = _C.lib()
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 512, 22016, 4096, 64, 1) == 0     # 344 tiles of 8 waves: more than one round of workgroups
-    assert L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 0
-    assert L.hqq_hip_forward_prefers_fused(4, 2048, 4096, 4096, 64, 1) == 0
+    assert L.hqq_hip_forward_prefers_fused(4, 512, 22016, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 513, 4096, 4096, 64, 1) == 0      # long prompts: the composition is ahead
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 128, 1) == 0     # group_size 128: not this kernel
     assert L.hqq_hip_forward_prefers_fused(3, 128, 4096, 4096, 64, 1) == 0
-    assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 1024, 12288, 4096, 64, 1, 0) == 0
+    assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 8192, 12288, 4096, 64, 1, 0) == 0
     N, K, M = 1024, 2048, 128
     U, s, z = _layer(N, K, 4, 11, True)
     P = ops.pack(4, U.cuda())

@@ -5,7 +5,7 @@ sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from hqq_amd import ops
 gs, nbits = 64, 4
 g = torch.Generator().manual_seed(0)
-CASES = [(128, 4096, 4096), (128, 22016, 4096), (256, 12288, 4096), (512, 4096, 4096), (512, 22016, 4096), (1024, 4096, 4096), (1024, 12288, 4096), (1024, 4096, 11008)]
+CASES = [(2048, 4096, 4096), (8192, 4096, 4096), (8192, 12288, 4096), (4096, 22016, 4096), (8192, 22016, 4096), (8192, 4096, 11008)] if len(sys.argv) > 2 else [(128, 4096, 4096), (128, 22016, 4096), (256, 12288, 4096), (512, 4096, 4096), (512, 22016, 4096), (1024, 4096, 4096), (1024, 12288, 4096), (1024, 4096, 11008)]
 res = []
 for M, N, K in CASES:
     R = N * K // gs
