@@ -115,7 +115,7 @@ def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16
         Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4))
         # HQQLinear.cuda(): meta is cast to compute_dtype (quantize.py:515-583)
         L.Wq, L.scale, L.zero = Wq, s.to(cd), z.to(cd)
-    L.opts = ops.OPT_META_SCALABLE if (cd == torch.float16 and nbits in (8, 4, 2) and ops.meta_scalable(L.scale, L.zero, N, K, 64, nbits)) else 0
+    L.opts = ops.OPT_META_SCALABLE if (cd == torch.float16 and nbits in (8, 4, 3, 2) and ops.meta_scalable(L.scale, L.zero, N, K, 64, nbits)) else 0
     return L
 
 

@@ -250,7 +250,7 @@ class HQQLinear(nn.Module):
         """per-call option bits of the fused forward that depend on this layer's meta only (checked once, when it lands on the GPU)"""
         m = self.meta
         try:
-            if (m["axis"] == 1 and m["scale"].dtype == float16 and m["packing"] in ("8bit_u8", "4bit_u8", "2bit_u8", "1bit_u8")
+            if (m["axis"] == 1 and m["scale"].dtype == float16 and m["packing"] in ("8bit_u8", "4bit_u8", "3bit_32", "2bit_u8", "1bit_u8")
                     and m["scale"].is_cuda and bool(m["group_size"])):
                 N, K = m["shape"]
                 if ops.meta_scalable(m["scale"].reshape(-1), m["zero"].reshape(-1), N, K, m["group_size"], Quantizer._packing_bits[m["packing"]]):

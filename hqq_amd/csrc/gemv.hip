@@ -632,6 +632,24 @@ __global__ __launch_bounds__(256) void meta_check_kernel(const half_t* __restric
   }
   if (bad) atomicAdd(fails, bad);   // rare
 }
+// 3-bit (slab-sharing kernel, gemv3s.hip): group row r sits in slab r / step, whose field lies e(slab) bits above a byte-pair boundary
+__global__ __launch_bounds__(256) void meta_check3_kernel(const half_t* __restrict__ scale, const half_t* __restrict__ zero, int64_t R, int64_t step,
+                                                          uint32_t* __restrict__ fails) {
+  uint32_t bad = 0;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; r < R; r += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int t = static_cast<int>(r / step);
+    const int J = 9 - static_cast<int>((0x0361472503ull >> (4 * t)) & 15ull);   // e of slabs 0..9 = 3,0,5,2,7,4,1,6,3,0 (S3Slab<T>::e)
+    const half_t dn = static_cast<half_t>(1.0f / static_cast<float>(1 << J)), up = static_cast<half_t>(static_cast<float>(1 << J));
+    const half_t z = zero[r], sc = scale[r];
+    const half_t zp = z * dn;
+    const half_t back = zp * up;
+    const half_t sp = sc * up;
+    const float zf = static_cast<float>(z), spf = static_cast<float>(sp);
+    const bool ok = (back == z) && (zf <= 32768.0f) && (zf >= -32768.0f) && (spf - spf == 0.0f);
+    bad += ok ? 0u : 1u;
+  }
+  if (bad) atomicAdd(fails, bad);
+}
 }  // namespace hqq
 
 using namespace hqq;
@@ -767,8 +785,18 @@ extern "C" int hqq_hip_meta_check(int nbits, const void* scale, const void* zero
   clear_stale_error();
   if (!scale || !zero || !fail_count) { set_error("hqq_hip_meta_check: null argument"); return HQQ_ERR_SHAPE; }
   if (N <= 0 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_meta_check: bad N/K/group_size"); return HQQ_ERR_SHAPE; }
-  if (nbits != 8 && nbits != 4 && nbits != 2 && nbits != 1) { set_error("hqq_hip_meta_check: nbits=%d has no three-op rebuild", nbits); return HQQ_ERR_UNSUPPORTED; }
+  if (nbits != 8 && nbits != 4 && nbits != 3 && nbits != 2 && nbits != 1) { set_error("hqq_hip_meta_check: nbits=%d has no three-op rebuild", nbits); return HQQ_ERR_UNSUPPORTED; }
   if (dtype != HQQ_F16) { set_error("hqq_hip_meta_check: the three-op rebuild is an fp16 sequence (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (nbits == 3) {
+    const int64_t R3 = N * (K / group_size);
+    if (R3 > INT32_MAX) { set_error("hqq_hip_meta_check: size overflow"); return HQQ_ERR_SHAPE; }
+    hipStream_t st3 = as_stream(stream);
+    hipError_t e3 = hipMemsetAsync(fail_count, 0, sizeof(uint32_t), st3);
+    if (e3 != hipSuccess) { set_error("hqq_hip_meta_check: hipMemsetAsync: %s", hipGetErrorString(e3)); return static_cast<int>(e3); }
+    const int grid3 = static_cast<int>((R3 + 255) / 256 > 2048 ? 2048 : (R3 + 255) / 256);
+    hipLaunchKernelGGL(meta_check3_kernel, dim3(grid3), dim3(256), 0, st3, static_cast<const half_t*>(scale), static_cast<const half_t*>(zero), R3, (R3 + 9) / 10, fail_count);
+    return check_launch("hqq_hip_meta_check");
+  }
   const int per = 8 / nbits;
   if (N % per) { set_error("hqq_hip_meta_check: N must divide by %d", per); return HQQ_ERR_SHAPE; }
   const int64_t G = K / group_size, R = N * G;

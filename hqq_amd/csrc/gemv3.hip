@@ -290,7 +290,7 @@ static int g3_launch(const G3Args& a, hipStream_t st) {
 bool gemv3s_covers(int64_t M, int64_t K, int64_t group_size);   // gemv3s.hip: each packed word loaded once for all ten slabs
 size_t gemv3s_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K);
 int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, void* ws, size_t ws_bytes, hipStream_t st);
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, uint32_t opts, void* ws, size_t ws_bytes, hipStream_t st);
 
 // which of the two 3-bit kernels a launch takes: the slab-sharing one (gemv3s.hip) from 19 MB of packed weights on — 2.2 TB/s of
 // packed bytes at the margin against 1.2 here, but ~10 us of fixed cost (a task is a 4 us chain of instructions in one wave, plus
@@ -342,7 +342,7 @@ int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* co
     a.e_end[i] = static_cast<int>(ents);
     if (G > a.step[i]) { set_error("hqq_hip_gemv: 3-bit layer with fewer than 10 output rows per slab is not covered"); return HQQ_ERR_UNSUPPORTED; }
   }
-  if (gemv3_wants_slabs(n_layers, N, M, K, group_size, opts)) return gemv3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, ws, ws_bytes, st);
+  if (gemv3_wants_slabs(n_layers, N, M, K, group_size, opts)) return gemv3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, opts, ws, ws_bytes, st);
   for (int i = n_layers; i < G3_MAXL; ++i) {
     a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
     a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.e_end[i] = a.e_end[n_layers - 1];

@@ -93,6 +93,8 @@ template <int T> struct S3Slab {
   static constexpr int cls = T >= 7 ? 0 : T >= 4 ? 1 : T >= 2 ? 2 : 3;                      // bytes (0,1) / (1,2) / (2,3) / (3)
   static constexpr int e = (27 - 3 * T) - (cls == 0 ? 0 : cls == 1 ? 8 : cls == 2 ? 16 : 24);   // 0 .. 7: F = 2^e, 7 F < 1024
 };
+// the same e for a run-time slab index (0x0363_1472_5303 read from the low nibble up: e of slabs 0..9 = 3,0,5,2,7,4,1,6,3,0)
+__host__ __device__ __forceinline__ constexpr int s3_field_e(int t) { return static_cast<int>((0x0361472503ull >> (4 * t)) & 15ull); }
 __device__ __forceinline__ constexpr uint32_t s3_sel(int cls) {
   return cls == 0 ? 0x05040100u : cls == 1 ? 0x06050201u : cls == 2 ? 0x07060302u : 0x0C070C03u;
 }
@@ -102,7 +104,7 @@ struct S3Unit {
   uint16_t z[3], sc[3];   // load q: zero / scale of (slab 4 q + o, packed row p0 + c)
 };
 
-template <int M>
+template <int M, bool SUB>
 __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // x[M][K + 1024] fp16
 
@@ -165,6 +167,11 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
       const int t = 4 * q + o, p = p0 + c;
       const bool ok = t < 10 && p < ly.step && p + t * ly.step < R;
       zs[q] = ok ? (static_cast<uint32_t>(un.z[q]) | (static_cast<uint32_t>(un.sc[q]) << 16)) : 0u;
+      if constexpr (SUB) {   // three-op rebuild (decode_common.h): (z, s) -> (z 2^-J, s 2^J), J = 9 - e(slab); exact by hqq_hip_meta_check
+        const int J = 9 - s3_field_e(t < 10 ? t : 0);
+        const half2_t f = {__builtin_bit_cast(half_t, static_cast<uint16_t>((15 - J) << 10)), __builtin_bit_cast(half_t, static_cast<uint16_t>((15 + J) << 10))};   // (2^-J, 2^J)
+        zs[q] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2_t, zs[q]) * f);
+      }
     }
     // the two bytes that hold a slab's field, from word pairs (k, k + 1): pk[class][load][pair]
     uint32_t pk[4][4][2];
@@ -197,10 +204,16 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
         const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          uint32_t b;
-          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(pk[cls][i][h]), "s"(msk), "v"(magic));
-          const half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, b), k1, k2);   // exact level
-          w[i][h] = (q - zz) * ss;                                                             // two roundings, as Quantizer.dequantize
+          if constexpr (SUB) {   // the masked field read as fp16 is the subnormal q 2^(e-24): one fma lifts it and subtracts z 2^-J (rounding 1), one mul by s 2^J (rounding 2)
+            const half2_t lift = {static_cast<half_t>(32768.0f), static_cast<half_t>(32768.0f)};
+            const half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, pk[cls][i][h] & msk), lift, -zz);
+            w[i][h] = q * ss;
+          } else {
+            uint32_t b;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(b) : "v"(pk[cls][i][h]), "s"(msk), "v"(magic));
+            const half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, b), k1, k2);   // exact level
+            w[i][h] = (q - zz) * ss;                                                             // two roundings, as Quantizer.dequantize
+          }
         }
       }
       float sa[M], sb[M];
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(256) void gemv3s_finish_kernel(const S3Args a) {
   }
 }
 
-template <int M>
+template <int M, bool SUB>
 static int s3_launch(S3Args& a, int max_n, void* ws, size_t ws_bytes, hipStream_t st) {
   const size_t lds = static_cast<size_t>(M) * (a.K + S3_ROWS * 64) * 2;
   const size_t need = WS_COUNTER_BYTES + static_cast<size_t>(a.total_tasks) * 10 * 2 * M * sizeof(float);   // (the head belongs to the split-K counters)
@@ -324,7 +337,7 @@ static int s3_launch(S3Args& a, int max_n, void* ws, size_t ws_bytes, hipStream_
   per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
   const int wgs = (a.total_tasks + S3_WAVES - 1) / S3_WAVES;
   const int cap = n_cus * per_cu;
-  auto kern = gemv3s_kernel<M>;
+  auto kern = gemv3s_kernel<M, SUB>;
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
@@ -357,7 +370,7 @@ size_t gemv3s_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t
 }
 
 int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, void* ws, size_t ws_bytes, hipStream_t st) {
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, uint32_t opts, void* ws, size_t ws_bytes, hipStream_t st) {
   S3Args a;
   const int64_t G = K / 64;
   int64_t tasks = 0, max_n = 0;
@@ -386,11 +399,12 @@ int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* c
   a.G = static_cast<int>(G);
   a.total_tasks = static_cast<int>(tasks);
   a.n_layers = n_layers;
+  const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0;
   switch (M) {
-    case 1: return s3_launch<1>(a, static_cast<int>(max_n), ws, ws_bytes, st);
-    case 2: return s3_launch<2>(a, static_cast<int>(max_n), ws, ws_bytes, st);
-    case 3: return s3_launch<3>(a, static_cast<int>(max_n), ws, ws_bytes, st);
-    case 4: return s3_launch<4>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 1: return sub ? s3_launch<1, true>(a, static_cast<int>(max_n), ws, ws_bytes, st) : s3_launch<1, false>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 2: return sub ? s3_launch<2, true>(a, static_cast<int>(max_n), ws, ws_bytes, st) : s3_launch<2, false>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 3: return sub ? s3_launch<3, true>(a, static_cast<int>(max_n), ws, ws_bytes, st) : s3_launch<3, false>(a, static_cast<int>(max_n), ws, ws_bytes, st);
+    case 4: return sub ? s3_launch<4, true>(a, static_cast<int>(max_n), ws, ws_bytes, st) : s3_launch<4, false>(a, static_cast<int>(max_n), ws, ws_bytes, st);
   }
   return HQQ_ERR_SHAPE;
 }

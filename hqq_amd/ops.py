@@ -121,7 +121,7 @@ def meta_scalable(scale: Tensor, zero: Tensor, N: int, K: int, group_size: int, 
     """True when every (zero, scale) pair of the layer can take the three-op exact weight rebuild (hqq_hip_meta_check == 0 failing
     groups): pass OPT_META_SCALABLE for it then.  Synchronises (one 4-byte read-back): call it when a layer is prepared, not per forward."""
     _dev(scale, zero)
-    if scale.dtype != torch.float16 or zero.dtype != torch.float16 or nbits not in (8, 4, 2, 1) or N % PER[nbits]:
+    if scale.dtype != torch.float16 or zero.dtype != torch.float16 or nbits not in (8, 4, 3, 2, 1) or (nbits != 3 and N % PER[nbits]):
         return False
     cnt = torch.empty(1, dtype=torch.int32, device=scale.device)
     with torch.cuda.device(scale.device):

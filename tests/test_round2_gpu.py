@@ -114,6 +114,27 @@ def test_three_op_rebuild_is_bit_identical_where_the_meta_check_allows_it(ops, n
             assert torch.equal(ops.gemv(e, Wq, s, z, None, N, K, gs, nbits, opts=ops.OPT_META_SCALABLE)[0], Wd[:, k0])
 
 
+def test_three_op_rebuild_3bit_slab_kernel(ops):
+    """3-bit, slab-sharing kernel (gemv3s.hip): the three-op rebuild (field read as an fp16 subnormal, per-slab power-of-two scaling of
+    zero / scale) gives the bits of the four-op one, and of the dequantise kernel on one-hot probes; hqq_hip_meta_check (3-bit: per-slab J)
+    refuses a layer with a zero-point that does not survive the scaling"""
+    N, K = 1024, 4096
+    Wq, s, z = _qlayer(ops, N, K, 3, seed=31)
+    assert ops.meta_scalable(s, z, N, K, 64, 3), "solver-produced 3-bit meta of a N(0, sigma) layer is expected to pass"
+    Wd = ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, 64, 3)
+    for M in (1, 3, 4):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().cuda()
+        y4 = ops.gemv(x, Wq, s, z, None, N, K, 64, 3, opts=ops.OPT_GEMV3_SLABS)
+        assert torch.equal(ops.gemv(x, Wq, s, z, None, N, K, 64, 3, opts=ops.OPT_GEMV3_SLABS | ops.OPT_META_SCALABLE), y4)
+        torch.testing.assert_close(y4.float(), x.float() @ Wd.float().t(), rtol=1e-3, atol=1e-3)
+    for k0 in (0, 1, 63, 64, 1000, K - 1):
+        e = torch.zeros(1, K, dtype=torch.float16, device="cuda"); e[0, k0] = 1.0
+        assert torch.equal(ops.gemv(e, Wq, s, z, None, N, K, 64, 3, opts=ops.OPT_GEMV3_SLABS | ops.OPT_META_SCALABLE)[0], Wd[:, k0])
+    z2 = z.clone()
+    z2[12345, 0] = torch.tensor(0x0001, dtype=torch.int16).view(torch.float16)   # the smallest subnormal: lost by any down-scaling
+    assert not ops.meta_scalable(s, z2, N, K, 64, 3)
+
+
 def test_meta_check_flags_exactly_the_unsafe_groups(ops):
     """hqq_hip_meta_check counts the groups whose zero * 2^-J is inexact in fp16 (tiny zero-points with low bits set), whose
     |zero| > 2^15, or whose scale * 2^J overflows; a layer with such a group must not be given HQQ_OPT_META_SCALABLE — and the
