@@ -468,12 +468,12 @@ def main():
         out.update({
             "metric": f"int{nbits} gs=64 dequant-GEMM prefill throughput, Llama-2-7B block M={M} (tok/s; TFLOP/s alongside)",
             "value": round(M / sec_per_step, 2), "unit": "tok/s (one block's 7 linears)", "tflops": round(tfl, 2),
-            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens, fp16 " + ("dequantise kernel + library GEMM" if a.library_gemm else "fused MFMA dequant-GEMM"),
+            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens, fp16 " + ("dequantise kernel + library GEMM" if a.library_gemm else "fused MFMA dequant-GEMM (hqq_hip_gemm: pipelined kernel)"),
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather"},
         })
         ach = flops_per_step_rank / dev_sec_per_step / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "kernel": "hqq::dequant + hipBLASLt" if a.library_gemm else "hqq::gemm_f16_kernel"}
+                           "traffic": None, "kernel": "hqq::dequantize + hipBLASLt" if a.library_gemm else "hqq::gemm_pipe_f16_kernel (LDS-DMA rings, weights rebuilt into MFMA fragments)"}
 
     # ---- the other shapes the metric names, same resident weights (N = 1, default decode only) ----
     if decode and world == 1 and not a.no_legs and not big and M == 1 and a.dtype == "f16" and S == 1 and nbits in (4, 2, 8):

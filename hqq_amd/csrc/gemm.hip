@@ -446,7 +446,7 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype);
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
-                  int64_t M, int64_t N, int64_t K, int64_t gs, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
+                  int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // which fused GEMM serves a call: the pipelined kernel (gemm_pipe.hip) wherever it applies — it is ahead of the output-tile kernels
 // below at every M (0.8-1.14 PFLOP/s against 0.5-0.84 from 2048 rows on, 2-4x below 512) —, the output-tile kernels for the group sizes
@@ -496,7 +496,7 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
   if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || N * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemm: size overflow"); return HQQ_ERR_SHAPE; }
   if (!aligned16(x) || !aligned16(Wq) || !aligned16(y)) { set_error("hqq_hip_gemm: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
   hipStream_t st = as_stream(stream);
-  if (use_pipe(nbits, M, N, K, group_size, dtype, opts)) return gemm_pipe_run(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, opts, workspace, workspace_bytes, st);
+  if (use_pipe(nbits, M, N, K, group_size, dtype, opts)) return gemm_pipe_run(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, st);
   if (nbits != 4 && nbits != 2) { set_error("hqq_hip_gemm: nbits=%d not covered by the fused GEMM", nbits); return HQQ_ERR_UNSUPPORTED; }
   const int per = 8 / nbits;
   if (N % per || (N / per) % 4 || group_size % 16 || K % GB_K) {

@@ -1,5 +1,5 @@
 // gemm_pipe.hip — fused unpack -> dequantize -> MFMA GEMM for the rows between decode and long prefill (65 <= M <= ~1024: batched
-// decode, speculative verification, short prompts), gfx950, fp16, 8-/4-/2-bit.
+// decode, speculative verification, short prompts) and beyond, gfx950, fp16 / bf16, 8-/4-/2-bit.
 //
 // Reference chain replaced (axis=1): BitPack.unpack_* -> (W_r - zero) * scale -> torch.matmul(x, W.t()) (+ bias)
 //   hqq/core/bitpack.py:31-64, hqq/core/quantize.py:183-199, :880-898.
@@ -113,13 +113,61 @@ struct GdSlab {   // the lane's 16 k-values of slab S (dwords with swapped middl
   }
 };
 
+// bf16 compute dtype: the reference's two roundings are to bf16 (quantize.py:198 on bf16 tensors).  gfx950 has no packed bf16
+// arithmetic, so a weight goes through fp32 (as in skinny.hip): v_cvt_f32_ubyteN lifts the masked byte F q, one fma forms q - z exactly,
+// v_cvt_pk_bf16_f32 rounds it (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds
+// again — 8 VALU ops per weight pair against 3.  Bytes are taken in natural k order, so the dwords are NOT byte-swapped on this path.
+typedef __bf16 gd_bf2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 gd_bf8_t __attribute__((ext_vector_type(8)));
+typedef float gd_f2_t __attribute__((ext_vector_type(2)));
+template <int B> __device__ __forceinline__ float gd_ubyte(uint32_t v) { return static_cast<float>((v >> (8 * B)) & 0xFFu); }   // v_cvt_f32_ubyteB
+template <int NBITS, int S, int PER>
+struct GdSlabBF {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint16_t (&z)[PER], const uint16_t (&s)[PER], u32x4 (&a0)[PER], u32x4 (&a1)[PER]) {
+    constexpr int sh = NBITS * (PER - 1 - S);
+    constexpr uint32_t m1 = ((NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u)) << sh;
+    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+    const float zf = __uint_as_float(static_cast<uint32_t>(z[S]) << 16);
+    const gd_bf2_t s_lo = __builtin_bit_cast(gd_bf2_t, static_cast<uint32_t>(s[S]));          // (s, 0)
+    const gd_bf2_t s_hi = __builtin_bit_cast(gd_bf2_t, static_cast<uint32_t>(s[S]) << 16);    // (0, s)
+    uint32_t o[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t fq = (NBITS == 8) ? w[d] : (w[d] & (m1 * 0x01010101u));
+      const gd_f2_t dq[2] = {{__builtin_fmaf(gd_ubyte<0>(fq), inv, -zf), __builtin_fmaf(gd_ubyte<1>(fq), inv, -zf)},    // k 4d, 4d+1
+                             {__builtin_fmaf(gd_ubyte<2>(fq), inv, -zf), __builtin_fmaf(gd_ubyte<3>(fq), inv, -zf)}};   // k 4d+2, 4d+3
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const gd_bf2_t dr = __builtin_convertvector(dq[h], gd_bf2_t);                 // rounding 1
+        const gd_f2_t pw = {__builtin_amdgcn_fdot2_f32_bf16(dr, s_lo, 0.f, false), __builtin_amdgcn_fdot2_f32_bf16(dr, s_hi, 0.f, false)};
+        o[2 * d + h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, gd_bf2_t));   // rounding 2
+      }
+    }
+    a0[S] = u32x4{o[0], o[1], o[2], o[3]};
+    a1[S] = u32x4{o[4], o[5], o[6], o[7]};
+    if constexpr (S + 1 < PER) GdSlabBF<NBITS, S + 1, PER>::run(w, z, s, a0, a1);
+  }
+};
+// one fp32 accumulator -> the compute dtype, + bias in the compute dtype (`out += bias` on the rounded matmul result, quantize.py:896-897)
+template <bool BF> __device__ __forceinline__ uint16_t gd_out(float v, const half_t* bias, int n) {
+  if constexpr (BF) {
+    uint16_t o = f32_to_bf16(v);
+    if (bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(bias)[n]));
+    return o;
+  } else {
+    half_t o = static_cast<half_t>(v);
+    if (bias) o = o + bias[n];
+    return __builtin_bit_cast(uint16_t, o);
+  }
+}
+
 template <int NBITS> struct GdMeta {   // (zero, scale) DMA: one dword = the two steps' values of one (row, slab, zero | scale)
   static constexpr int PER = 8 / NBITS;
   static constexpr int NI = (PER * 2 * 16 + 63) / 64;         // DMA instructions per wave and pair of steps
   static constexpr int SLOT = NI * 256;                        // bytes per wave and pair of steps
 };
 
-template <int NBITS, bool SUB, int NW, int BM>
+template <int NBITS, bool SUB, int NW, int BM, bool BF>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
   constexpr int PER = 8 / NBITS;
   using CF = GdCfg<NW, BM>;
@@ -172,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
     const int prow = (p0 + er) < rows_per_slab ? p0 + er : rows_per_slab - 1;
     msrc[t] = (which ? a.scale : a.zero) + (static_cast<int64_t>(es) * rows_per_slab + prow) * G + kt0;
   }
-  const half_t smask = w_active ? static_cast<half_t>(1.0f) : static_cast<half_t>(0.0f);
+  const uint16_t smask = w_active ? 0xFFFFu : 0u;   // rows past the end of the slab: scale 0 -> exact zero weights
 
   auto issue_w = [&](int step) {   // packed weights of `step`
     const int sc = step < nsteps ? step : nsteps - 1;   // past the range: the last step again (cached; lands in a slot nobody reads)
@@ -190,24 +238,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   };
 
   // ---- the lane's packed bytes and group constants of a step, out of the rings; rebuilt into A fragments ----
-  half_t zc[2][PER], sc_[2][PER];   // (zero, scale) of the current pair of steps, per slab: [parity][slab]
+  uint16_t zc[2][PER], sc_[2][PER];   // (zero, scale) bits of the current pair of steps, per slab: [parity][slab]
   auto fetch_meta = [&](int step) {   // step even: both steps' constants in one read per (slab, zero | scale)
     const uint8_t* slot = mring + (((step >> 1) % GD_DM) * GD_WAVES + wave) * MD::SLOT;
 #pragma unroll
     for (int s = 0; s < PER; ++s) {
       const uint32_t zd = *reinterpret_cast<const uint32_t*>(slot + ((0 * PER + s) * 16 + r) * 4);
       const uint32_t sd = *reinterpret_cast<const uint32_t*>(slot + ((1 * PER + s) * 16 + r) * 4);
-      const half2_t zp = as_h2(zd), sp = as_h2(sd);
-      zc[0][s] = zp.x; zc[1][s] = zp.y;
-      sc_[0][s] = sp.x * smask; sc_[1][s] = sp.y * smask;
+      zc[0][s] = static_cast<uint16_t>(zd); zc[1][s] = static_cast<uint16_t>(zd >> 16);
+      sc_[0][s] = static_cast<uint16_t>(sd) & smask; sc_[1][s] = static_cast<uint16_t>(sd >> 16) & smask;
     }
   };
   auto read_w = [&](int step) { return *reinterpret_cast<const u32x4*>(wring + ((step % GD_DW) * GD_WAVES + wave) * 1024 + lane * 16); };
-  auto rebuild = [&](const u32x4& raw, int step, h8_t (&a0)[PER], h8_t (&a1)[PER]) {
-    u32x4 w;
+  auto rebuild = [&](const u32x4& raw, int step, u32x4 (&a0)[PER], u32x4 (&a1)[PER]) {
+    if constexpr (BF) {
+      GdSlabBF<NBITS, 0, PER>::run(raw, zc[step & 1], sc_[step & 1], a0, a1);
+    } else {
+      u32x4 w;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_perm(raw[d], raw[d], 0x03010200u);   // bytes (b0,b1,b2,b3) -> (b0,b2,b1,b3)
-    GdSlab<NBITS, 0, PER, SUB>::run(w, zc[step & 1], sc_[step & 1], a0, a1);
+      for (int d = 0; d < 4; ++d) w[d] = __builtin_amdgcn_perm(raw[d], raw[d], 0x03010200u);   // bytes (b0,b1,b2,b3) -> (b0,b2,b1,b3)
+      half_t zh[PER], sh_[PER];
+      h8_t h0[PER], h1[PER];
+#pragma unroll
+      for (int s = 0; s < PER; ++s) { zh[s] = __builtin_bit_cast(half_t, zc[step & 1][s]); sh_[s] = __builtin_bit_cast(half_t, sc_[step & 1][s]); }
+      GdSlab<NBITS, 0, PER, SUB>::run(w, zh, sh_, h0, h1);
+#pragma unroll
+      for (int s = 0; s < PER; ++s) { a0[s] = __builtin_bit_cast(u32x4, h0[s]); a1[s] = __builtin_bit_cast(u32x4, h1[s]); }
+    }
   };
 
   f32x4 acc[PER][GD_MT];
@@ -225,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  h8_t a0[2][PER], a1[2][PER];   // A fragments of the current / next step
+  u32x4 a0[2][PER], a1[2][PER];   // A fragments of the current / next step (8 fp16 / bf16 values each)
   fetch_meta(0);
   rebuild(read_w(0), 0, a0[0], a1[0]);
 
@@ -239,29 +296,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   //        LDS    B fragments of (step i + 1, tokens 0..63); packed bytes (+ constants) of step i + 1
   //        MFMA   (step i, tokens 64..127), and under them the VALU rebuild of step i + 1 into the other A fragment set ----
   constexpr int HT = 4, NQ = GD_MT / HT;   // the step's tokens in NQ parts of 64 (2 at 128 tokens per tile, 4 at 256)
-  h8_t bA0[HT], bA1[HT], bB0[HT], bB1[HT];   // B fragments of the even / odd parts
-  auto read_b = [&](int step, int part, h8_t (&f0)[HT], h8_t (&f1)[HT]) {
+  u32x4 bA0[HT], bA1[HT], bB0[HT], bB1[HT];   // B fragments of the even / odd parts
+  auto read_b = [&](int step, int part, u32x4 (&f0)[HT], u32x4 (&f1)[HT]) {
     const uint8_t* xs = xring + (step % GD_DX) * GD_XSTAGE;
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
       const int row = (part * HT + j) * 16 + r;
-      f0[j] = *reinterpret_cast<const h8_t*>(xs + row * 128 + (((2 * c) ^ gd_swz(row)) << 4));
-      f1[j] = *reinterpret_cast<const h8_t*>(xs + row * 128 + (((2 * c + 1) ^ gd_swz(row)) << 4));
+      f0[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c) ^ gd_swz(row)) << 4));
+      f1[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c + 1) ^ gd_swz(row)) << 4));
     }
   };
-  auto mma = [&](int part, const h8_t (&ca0)[PER], const h8_t (&ca1)[PER], const h8_t (&f0)[HT], const h8_t (&f1)[HT]) {
+  auto mfma = [&](const u32x4& A, const u32x4& B, f32x4 C) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gd_bf8_t, A), __builtin_bit_cast(gd_bf8_t, B), C, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, A), __builtin_bit_cast(h8_t, B), C, 0, 0, 0);
+  };
+  auto mma = [&](int part, const u32x4 (&ca0)[PER], const u32x4 (&ca1)[PER], const u32x4 (&f0)[HT], const u32x4 (&f1)[HT]) {
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
-      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca0[s], f0[j], acc[s][part * HT + j], 0, 0, 0);
+      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = mfma(ca0[s], f0[j], acc[s][part * HT + j]);
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
-      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca1[s], f1[j], acc[s][part * HT + j], 0, 0, 0);
+      for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = mfma(ca1[s], f1[j], acc[s][part * HT + j]);
   };
   read_b(0, 0, bA0, bA1);
   // DMA instructions issued after the ones the next step needs: the groups of the PX - 2 iterations in between
-  auto iter = [&](int i, auto parity, h8_t (&ca0)[PER], h8_t (&ca1)[PER], h8_t (&na0)[PER], h8_t (&na1)[PER]) {
+  auto iter = [&](int i, auto parity, u32x4 (&ca0)[PER], u32x4 (&ca1)[PER], u32x4 (&na0)[PER], u32x4 (&na1)[PER]) {
     constexpr int par = decltype(parity)::value;   // i & 1
     constexpr int N_OUT = GD_PX == 3 ? 1 + XP + (((par + GD_PW) & 1) ? MD::NI : 0) : 0;   // PX = 3: what iteration i - 1 issued; PX = 2: nothing
 #pragma unroll
@@ -323,13 +384,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
     for (int j = 0; j < GD_MT; ++j) {
       const int m = m0 + 16 * j + r;
       if (m >= M) continue;
-      half_t o[4];
+      uint16_t o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[i] = static_cast<half_t>(acc[s][j][i]);
-        if (a.bias && pb + i < rows_per_slab) o[i] = o[i] + a.bias[n + i];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-      }
-      half_t* dst = a.y + static_cast<int64_t>(m) * N + n;
+      for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(acc[s][j][i], (a.bias && pb + i < rows_per_slab) ? a.bias : nullptr, n + i);
+      uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + static_cast<int64_t>(m) * N + n;
       if (pb + 3 < rows_per_slab) {
         *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
       } else {
@@ -344,7 +402,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
 // Second launch of a split-K call: output quad (tile, slab s, token tile j, thread) = the sum of the KS parked tiles in split order
 // (four tiles' loads of a thread in flight at once, every CU takes part), rounded once, + bias.  One finishing workgroup per tile
 // inside the first kernel (ticket scheme) read its KS x 64 KiB alone and cost 2-3 us per split.
-template <int NBITS, int NW, int BM>
+template <int NBITS, int NW, int BM, bool BF>
 __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs a) {
   constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW, GD_BM = BM, GD_MT = BM / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,13 +427,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
   const int m = mt * GD_BM + 16 * j + r;
   if (pb >= rows_per_slab || m >= a.M) return;
   const int n = s * rows_per_slab + pb;
-  half_t o[4];
+  uint16_t o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    o[i] = static_cast<half_t>(sum[i]);
-    if (a.bias && pb + i < rows_per_slab) o[i] = o[i] + a.bias[n + i];
-  }
-  half_t* dst = a.y + static_cast<int64_t>(m) * a.N + n;
+  for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(sum[i], (a.bias && pb + i < rows_per_slab) ? a.bias : nullptr, n + i);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + static_cast<int64_t>(m) * a.N + n;
   if (pb + 3 < rows_per_slab) {
     *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
   } else {
@@ -461,13 +516,13 @@ bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {
-  if (dtype != HQQ_F16 || (nbits != 8 && nbits != 4 && nbits != 2)) return false;
+  if ((dtype != HQQ_F16 && dtype != HQQ_BF16) || (nbits != 8 && nbits != 4 && nbits != 2)) return false;
   const int per = 8 / nbits;
   // group_size 64 = one step: a step's weights share one (zero, scale) per row; K / 64 even: two steps' constants per DMA dword
   return N % per == 0 && (N / per) % 4 == 0 && gs == 64 && K % 128 == 0 && M >= 1;
 }
 
-template <int NBITS, bool SUB, int NW, int BM>
+template <int NBITS, bool SUB, int NW, int BM, bool BF>
 static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
   using CF = GdCfg<NW, BM>;
   constexpr int lds_bytes = CF::DX * CF::XSTAGE + CF::DW * NW * 1024 + CF::DM * NW * GdMeta<NBITS>::SLOT;
@@ -476,23 +531,23 @@ static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
   (void)hipGetDevice(&devid);
   bool& attr_done = done_on[devid & 63];
   if (!attr_done) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB, NW, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_f16_kernel<NBITS, SUB, NW, BM, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) {
       set_error("hqq_hip_gemm: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
       return static_cast<int>(e);   // (positive: a HIP error, as check_launch reports them)
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW, BM>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
+  hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW, BM, BF>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
   int rc = check_launch("hqq_hip_gemm(pipelined)");
   if (rc || a.KS <= 1) return rc;
   const int64_t rblocks = static_cast<int64_t>(a.n_tiles) * a.m_tiles * ((8 / NBITS) * (BM / 16));
-  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW, BM>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
+  hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW, BM, BF>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
 
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
-                  int64_t M, int64_t N, int64_t K, int64_t gs, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                  int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
   const int64_t blocks = tiles * p.KS;
@@ -512,14 +567,14 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
     }
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTER_BYTES);
   }
-  const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0;
-#define GP_GO2(NB, SB) (p.BM == 256 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 256>(a, blocks, st) /* (never planned at 2 bits: 256 accumulator registers) */ : p.NW == 8 ? gp_launch<NB, SB, 8, 128>(a, blocks, st) : gp_launch<NB, SB, 4, 128>(a, blocks, st))
-#define GP_GO(NB) (sub ? GP_GO2(NB, true) : GP_GO2(NB, false))
+  const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0 && dtype == HQQ_F16;
+#define GP_GO3(NB, SB, BF_) (p.BM == 256 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 256, BF_>(a, blocks, st) /* (never planned at 2 bits: 256 accumulator registers) */ : p.NW == 8 ? gp_launch<NB, SB, 8, 128, BF_>(a, blocks, st) : gp_launch<NB, SB, 4, 128, BF_>(a, blocks, st))
+#define GP_GO(NB) (dtype == HQQ_BF16 ? GP_GO3(NB, false, true) : sub ? GP_GO3(NB, true, false) : GP_GO3(NB, false, false))
   if (nbits == 8) return GP_GO(8);
   if (nbits == 4) return GP_GO(4);
   return GP_GO(2);
+#undef GP_GO3
 #undef GP_GO
-#undef GP_GO2
 }
 
 }  // namespace hqq

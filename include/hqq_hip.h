@@ -88,9 +88,9 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
  * workspace may be NULL).  Contract: 16-byte aligned device memory, ZERO when first used — the caller clears it once when
  * allocating it; every call leaves the counter area zero again — and not shared by calls that may run concurrently.  A larger
  * workspace than asked for is fine: one buffer sized for the largest launch serves a whole model.
- * hqq_hip_gemm: fp16; nbits in {8,4,2} with group_size 64, K % 128 == 0 (the pipelined kernel: all operands by LDS-DMA, K split
+ * hqq_hip_gemm: fp16 / bf16, nbits in {8,4,2} with group_size 64, K % 128 == 0 (the pipelined kernel: all operands by LDS-DMA, K split
  * across workgroups until the chip is full, fp32 partial tiles parked in the workspace and summed in split order by a second launch;
- * used up to 1024 rows, 8-bit at any M); nbits in {4,2}, K % 64 == 0, group_size % 16 == 0 (the output-tile kernels, any M).
+ * any M); fp16, nbits in {4,2}, K % 64 == 0, group_size % 16 == 0 (the output-tile kernels: the other group sizes, any M).
  * Anything else -> HQQ_ERR_UNSUPPORTED (the caller may compose hqq_hip_dequantize + its own GEMM).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_GEMV_MAX_M 16

@@ -116,6 +116,41 @@ def test_every_tile_shape_forced(ops, oracle, nbits):
         assert any(torch.equal(auto, y) for y in outs)
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+@pytest.mark.parametrize("M,N,K", [(65, 256, 128), (300, 272, 1024), (520, 1040, 512), (130, 512, 11008)])
+def test_pipelined_gemm_bf16(ops, oracle, nbits, M, N, K):
+    """bf16 compute dtype (two bf16 roundings per weight, quantize.py:198 on bf16 tensors): one-hot probes bit-exact against the bf16
+    dequantise kernel (itself bit-exact against the oracle), results within one bf16 ulp (2^-7 relative, fp32 summation order) of the
+    oracle's double-accumulated matmul; every tile shape forced"""
+    per = 8 // nbits
+    g = torch.Generator().manual_seed(M + N + K + nbits)
+    R = N * K // 64
+    U = torch.randint(0, 2 ** nbits, (R, 64), generator=g, dtype=torch.uint8)
+    s = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).bfloat16()
+    z = (torch.rand(R, 1, generator=g) * (2 ** nbits - 1)).bfloat16()
+    P = oracle.pack(nbits, U.numpy())
+    x = torch.randn(M, K, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g).bfloat16()
+    z.view(-1)[::5] = 0.00836                                   # zero-points far below one level: q - z must still round once
+    raw = lambda t: t.view(torch.int16).numpy().view(np.uint16)   # noqa: E731  (the oracle takes raw bf16 bits)
+    Wd = oracle.dequantize(nbits, P, raw(s), raw(z), N, K, 64, 2)
+    yo, _ = oracle.matmul(raw(x), Wd, raw(bias), 2)
+    yo32 = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+    Pd, sd, zd, xd, bd = dev(P), s.cuda(), z.cuda(), x.cuda(), bias.cuda()
+    Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, 64, nbits)
+    assert Wdev.dtype == torch.bfloat16 and np.array_equal(Wdev.view(torch.int16).cpu().numpy().view(np.uint16), np.asarray(Wd).reshape(N, K))
+    e = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    cols = torch.arange(M, device="cuda") * 29 % K
+    e[torch.arange(M, device="cuda"), cols] = 1.0
+    for tile in (0, ops.OPT_GEMM_NARROW, ops.OPT_GEMM_WIDE, ops.OPT_GEMM_NARROW | ops.OPT_GEMM_WIDE):
+        y = ops.gemm(xd, Pd, sd, zd, bd, N, K, 64, nbits, opts=tile)
+        assert y.dtype == torch.bfloat16
+        # one bf16 ulp of the matmul result BEFORE the bias add (out = bf16(bf16(acc) + bias): a last-bit flip of bf16(acc) survives the add)
+        bound = 2.0 ** -7 * (yo32.abs() + bias.float().abs()[None, :]) + 2e-3
+        assert bool(((y.float().cpu() - yo32).abs() <= bound).all())
+        assert torch.equal(ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=tile), Wdev[:, cols].t().contiguous())
+
+
 def test_full_size_layers_one_hot_exact_and_linear(ops):
     """Llama-2-7B shapes at 128 and 1000 rows: every weight the kernel multiplies is the dequantised weight (one-hot rows), and the
     result is linear in x — size-independent properties, no oracle needed"""
