@@ -146,7 +146,7 @@ __device__ __forceinline__ u32x4 sk_permute_x8(u32x4 v) {   // (k0..k7) -> (k0,k
 
 // one 64-k block of one slab: dequantise the lane's 16 weights exactly as Quantizer.dequantize does (two fp16 roundings) ONCE,
 // then contract them with every m-tile's activation octets on the matrix core
-template <int NBITS, int MT, int S, int PER>
+template <int NBITS, int MT, int S, int PER, bool SUB = false>
 struct SkSlab {
   static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const sk_h8_t (&b0)[MT], const sk_h8_t (&b1)[MT],
                                              f32x4 (&acc)[PER][MT], uint32_t magic) {
@@ -154,6 +154,19 @@ struct SkSlab {
     const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
     half2_t q[8];
     uint32_t o[8];
+    if constexpr (SUB) {   // three-op rebuild (decode_common.h): the table holds (z 2^-J, s 2^J); the masked field is the subnormal q 2^(sh-24)
+      constexpr int sh = NBITS * (PER - 1 - S);
+      constexpr uint32_t m1 = ((NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u)) << sh;
+      constexpr uint32_t m = m1 | (m1 << 16);
+      const half2_t lift = {static_cast<half_t>(32768.0f), static_cast<half_t>(32768.0f)};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        q[2 * d] = sk_h2(w[d] & m);              // bytes (4d+0, 4d+2)
+        q[2 * d + 1] = sk_h2((w[d] >> 8) & m);   // bytes (4d+1, 4d+3)
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], lift, -zz);   // rounding 1
+    } else {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       q[2 * d] = sk_levels<NBITS, S>(w[d], magic);            // bytes (4d+0, 4d+2)
@@ -161,6 +174,7 @@ struct SkSlab {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = q[i] - zz;                                  // rounding 1
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = sk_u32(q[i] * ss);                          // rounding 2
     const sk_h8_t a0 = __builtin_bit_cast(sk_h8_t, u32x4{o[0], o[1], o[2], o[3]});   // k = 16c + 0..7 (permuted inside the octet)
@@ -170,7 +184,7 @@ struct SkSlab {
       acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0[t], acc[S][t], 0, 0, 0);
       acc[S][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1[t], acc[S][t], 0, 0, 0);
     }
-    if constexpr (S + 1 < PER) SkSlab<NBITS, MT, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
+    if constexpr (S + 1 < PER) SkSlab<NBITS, MT, S + 1, PER, SUB>::run(w, zs, b0, b1, acc, magic);
   }
 };
 
@@ -229,7 +243,7 @@ struct SkUnit {   // one wave's share of one chunk: SK_BPW KiB of packed weights
   u32x4 w[SK_BPW];
 };
 
-template <int NBITS, int MT, bool BF16>
+template <int NBITS, int MT, bool BF16, bool SUB = false>
 __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       }
       if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else
-      SkSlab<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
+      SkSlab<NBITS, MT, 0, PER, SUB>::run(cur.w[jl], zs, b0, b1, acc, magic);
     }
   };
 
@@ -380,10 +394,18 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       const int cc = rd * 4 + (tid & 3);
       if (cc < c1 - c0) {
         uint16_t* dst = reinterpret_cast<uint16_t*>(mz + (row * PER + s) * mstride + cc * SK_BLK) + hi;
-        dst[0] = static_cast<uint16_t>(mv[rd][pass].x);
-        dst[2] = static_cast<uint16_t>(mv[rd][pass].x >> 16);
-        dst[4] = static_cast<uint16_t>(mv[rd][pass].y);
-        dst[6] = static_cast<uint16_t>(mv[rd][pass].y >> 16);
+        u32x2 v = mv[rd][pass];
+        if constexpr (SUB) {   // (z, s) -> (z 2^-J, s 2^J), J = 9 - shift of the slab: exact for every group (hqq_hip_meta_check)
+          const int J = 9 - NBITS * (PER - 1 - s);
+          const uint16_t fb = static_cast<uint16_t>((hi ? 15 + J : 15 - J) << 10);
+          const half2_t f = {__builtin_bit_cast(half_t, fb), __builtin_bit_cast(half_t, fb)};
+          v.x = sk_u32(sk_h2(v.x) * f);
+          v.y = sk_u32(sk_h2(v.y) * f);
+        }
+        dst[0] = static_cast<uint16_t>(v.x);
+        dst[2] = static_cast<uint16_t>(v.x >> 16);
+        dst[4] = static_cast<uint16_t>(v.y);
+        dst[6] = static_cast<uint16_t>(v.y >> 16);
       }
     }
   SK_TS();   // 4: group constants in LDS
@@ -550,7 +572,7 @@ static size_t sk_part_bytes(int nbits, int ks, int total_panels, int mt) {
   return ks > 1 ? static_cast<size_t>(ks) * total_panels * SK_ROWS * (8 / nbits) * 16 * mt * sizeof(float) : 0;
 }
 
-template <int NBITS, bool BF16>
+template <int NBITS, bool BF16, bool SUB = false>
 static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
   const int nchunks = a.K / SK_KC;
@@ -574,7 +596,7 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
 #define HQQ_SK_CASE(MT)                                                                                       \
   case MT: {                                                                                                  \
-    auto kern = skinny_f16_kernel<NBITS, MT, BF16>;                                                               \
+    auto kern = skinny_f16_kernel<NBITS, MT, BF16, SUB>;                                                          \
     if (lds > 64 * 1024) {                                                                                    \
       static bool raised = false;                                                                             \
       if (!raised) {                                                                                          \
@@ -643,6 +665,8 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
   a.M = static_cast<int>(M);
   a.x = static_cast<const half_t*>(x);
   if (dtype == HQQ_BF16) return nbits == 4 ? sk_launch<4, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, true>(a, opts, ws, ws_bytes, st);
+  if (opts & HQQ_OPT_META_SCALABLE)
+    return nbits == 4 ? sk_launch<4, false, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, false, true>(a, opts, ws, ws_bytes, st);
   return nbits == 4 ? sk_launch<4, false>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false>(a, opts, ws, ws_bytes, st) : sk_launch<8, false>(a, opts, ws, ws_bytes, st);
 }
 

@@ -114,6 +114,32 @@ def test_three_op_rebuild_is_bit_identical_where_the_meta_check_allows_it(ops, n
             assert torch.equal(ops.gemv(e, Wq, s, z, None, N, K, gs, nbits, opts=ops.OPT_META_SCALABLE)[0], Wd[:, k0])
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+def test_three_op_rebuild_in_the_skinny_kernel(ops, nbits):
+    """5..64 activation rows (skinny.hip): the group-constant table is scaled once per workgroup and the three-op rebuild gives the
+    four-op bits — single layers with and without K splits, a grouped launch, one-hot probes against the dequantise kernel"""
+    for (N, K) in ((512, 2048), (4096, 1024)):
+        Wq, s, z = _qlayer(ops, N, K, nbits, seed=nbits + N)
+        assert ops.meta_scalable(s, z, N, K, 64, nbits)
+        Wd = ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, 64, nbits)
+        for M in (5, 16, 33, 64):
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().cuda()
+            y4 = ops.gemv(x, Wq, s, z, None, N, K, 64, nbits, opts=0)
+            assert torch.equal(ops.gemv(x, Wq, s, z, None, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE), y4)
+        e = torch.zeros(8, K, dtype=torch.float16, device="cuda")
+        cols = [0, 1, 2, 3, 17, 255, K - 64, K - 1]
+        for i, k0 in enumerate(cols): e[i, k0] = 1.0
+        assert torch.equal(ops.gemv(e, Wq, s, z, None, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE), Wd[:, cols].t().contiguous())
+    layers = []
+    for i, N in enumerate((512, 256, 1024)):
+        Wq, s, z = _qlayer(ops, N, 2048, nbits, seed=50 + i)
+        layers.append((Wq, s, z, None, N))
+    x = torch.randn(32, 2048, generator=torch.Generator().manual_seed(9)).half().cuda()
+    a = ops.gemv_grouped(x, layers, 2048, 64, nbits, opts=0)
+    b = ops.gemv_grouped(x, layers, 2048, 64, nbits, opts=ops.OPT_META_SCALABLE)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 def test_three_op_rebuild_3bit_slab_kernel(ops):
     """3-bit, slab-sharing kernel (gemv3s.hip): the three-op rebuild (field read as an fp16 subnormal, per-slab power-of-two scaling of
     zero / scale) gives the bits of the four-op one, and of the dequantise kernel on one-hot probes; hqq_hip_meta_check (3-bit: per-slab J)
