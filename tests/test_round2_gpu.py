@@ -474,6 +474,26 @@ def test_quantize_tensorwise_vs_oracle_large(ops, oracle):
     assert bool(torch.isnan(s)) and bool(torch.isnan(z))
 
 
+def test_hqqlinear_per_channel_group_size_none(ops, oracle):
+    """group_size=None (one group per output row, quantize.py:434-439): the generic-group-size solver, bit-exact against the oracle,
+    and a forward that agrees with dequantize() — whatever kernel or composition serves that group size"""
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQLinear
+    N, K = 96, 512
+    W = torch.randn(N, K, generator=torch.Generator().manual_seed(21)) * 0.05
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data = W.clone()
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=4, group_size=None, axis=1), compute_dtype=torch.float16, device="cuda")
+    o = oracle.quantize(W.numpy(), nbits=4, group_size=K)
+    assert np.array_equal(layer.W_q.data.cpu().numpy(), oracle.pack(4, o["Wq"]))
+    assert tuple(layer.meta["scale"].shape) == (N, 1) and layer.meta["group_size"] == K   # initialize() resolves None to in_features, as the reference does
+    Wd = layer.dequantize()
+    assert np.array_equal(Wd.cpu().numpy().view(np.uint16), oracle.dequantize(4, oracle.pack(4, o["Wq"]), oracle.to_cd(o["scale"], 1), oracle.to_cd(o["zero"], 1), N, K, K, 1).view(np.uint16))
+    for M in (1, 7, 100):
+        x = torch.randn(M, K, generator=torch.Generator().manual_seed(M)).half().cuda()
+        ref = x.float() @ Wd.float().t() + layer.bias.float()
+        torch.testing.assert_close(layer(x).float(), ref, rtol=2e-3, atol=2e-3)
+
+
 def test_quantize_axis0_vs_oracle_large(ops, oracle):
     """a 1024 x 1024 layer (16384 groups): the oracle (pinned to the reference on the fixtures above) agrees bit for bit"""
     W = (torch.randn(1024, 1024, generator=torch.Generator().manual_seed(5)) * 0.02)
