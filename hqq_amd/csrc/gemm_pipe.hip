@@ -32,9 +32,6 @@ namespace hqq {
 
 constexpr int GD_K = 64;   // k per step.  Waves per workgroup NW (4 or 8: 16 NW packed rows per tile) and tokens per tile BM (128 or 256) are template parameters
 constexpr int GD_MAX_KS = 16;
-#ifndef GP_TSTEP_256
-#define GP_TSTEP_256 1.45   /* us per step of the 8-wave, 256-token tile at low load (cost model) */
-#endif
 template <int NW, int BM> struct GdCfg {   // LDS rings: x stages / steps ahead, packed-weight slots / steps ahead (odd), (zero, scale) slots of two steps
   static constexpr int DX = BM == 128 ? 4 : 3, PX = DX - 1;
   static constexpr int DW = BM == 128 ? 8 : 4, PW = BM == 128 ? 5 : 3;
@@ -467,8 +464,10 @@ static double gp_cost(const GpPlan& p, int64_t M, int64_t N) {
   const double wgs = static_cast<double>(p.n_tiles) * p.m_tiles * p.KS;
   const double rounds = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
   const double active = wgs < 256.0 ? wgs : 256.0;
-  const double base = p.BM == 256 ? GP_TSTEP_256 : (p.NW == 4 ? 0.50 : 0.85);
-  const double tstep = base * (1.0 + 0.45 * active / 256.0);
+  // us per 64-k step at low load, and its growth with the number of CUs at work (fitted to tools/lab_pipe_plan.py, 640..2048 rows)
+  const double base = p.BM == 256 ? 1.37 : (p.NW == 4 ? 0.50 : 0.85);
+  const double slope = p.BM == 256 ? 0.20 : (p.NW == 4 ? 0.40 : 0.28);
+  const double tstep = base * (1.0 + slope * active / 256.0);
   double t = rounds * (p.kps * tstep + 5.0);
   if (p.KS > 1) t += 1.5 + 0.4 * p.KS * static_cast<double>(p.m_tiles) * p.BM * static_cast<double>(N) * 4.0 / 1.0e6;
   return t;
@@ -508,11 +507,15 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
 }
 
 // Where this kernel beats "dequantise kernel + library GEMM" on MI355X (profiles/r02_prefill_sweep.md, Llama-2-7B shapes, int4): up to
-// 512 rows everywhere (1.04-2.7x; the dequantise pass is as long as the GEMM there).  Beyond, the library's tile scheduler and hand-tuned
-// loop are ahead by 2-30 % in most shapes (0.95-1.14 PFLOP/s here at 8192 rows against 1.2-1.4 for the composition), so the hint says no.
+// 640 rows everywhere (1.04-2.6x; below 512 the dequantise pass is as long as the GEMM), and up to 1024 rows when the plan fills the
+// chip in one round (192..256 workgroups: o, down 1.0-1.15x; the other shapes are within +-6 % there and go to the library).  Beyond,
+// the library's tile scheduler and hand-tuned loop are ahead (1.13-1.21 PFLOP/s here at 8192 rows against 1.23-1.45 for the composition).
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
-  (void)nbits; (void)N; (void)K;
-  return M <= 512;
+  if (M <= 640) return true;
+  if (M > 1024) return false;
+  const GpPlan p = gp_plan(nbits, M, N, K, 0);
+  const int64_t wgs = static_cast<int64_t>(p.n_tiles) * p.m_tiles * p.KS;
+  return wgs >= 192 && wgs <= 256;
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {

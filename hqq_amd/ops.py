@@ -314,10 +314,10 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None
 
 # Which path `forward` takes by the number of activation rows M (measured on MI355X, tools/sweep_prefill.py -> profiles/):
 #   M <= 16 (<= 64 where skinny_covers): the weight-streaming decode kernels;
-#   65 <= M <= 512 (hqq_hip_forward_prefers_fused): the pipelined split-K fused GEMM — 1.04-2.7x the composition below, whose
-#       dequantise pass (11-36 us per layer) is as long as its GEMM at these sizes;
+#   65 <= M <= 640, to 1024 when the plan fills the chip in one round (hqq_hip_forward_prefers_fused): the pipelined split-K fused GEMM —
+#       1.0-2.6x the composition below, whose dequantise pass (11-36 us per layer) is as long as its GEMM at these sizes;
 #   otherwise: the HIP dequantise kernel + a plain library GEMM (hipBLASLt through torch.matmul) — one extra write + read of the
-#       fp16 weights (11-36 us), then 1.2-1.4 PFLOP/s at M = 8192 against 0.96-1.10 for the fused kernel.
+#       fp16 weights (11-36 us), then 1.23-1.45 PFLOP/s at M = 8192 against 1.13-1.21 for the fused kernel.
 # `fused=True` forces the fused kernels for every M.  LIBRARY_GEMM_MIN_M applies to the decode-sized cases the skinny kernel does not cover.
 LIBRARY_GEMM_MIN_M = 17
 

@@ -45,12 +45,12 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_gemv_workspace_bytes(4, 1, N1, 1, 4096, 64, 1, 0) == 0
     assert L.hqq_hip_gemv_workspace_bytes(4, 1, N1, 32, 4096, 64, 1, 0) > 256 * 1024
     # the fused GEMM's plan is host arithmetic too: 128 rows of a 4096 x 4096 layer split K (partial tiles in the workspace), 8192 rows do not;
-    # the routing hint: fused up to 512 rows where the pipelined kernel applies (group_size 64), never for what it does not cover
+    # the routing hint: fused up to 640 rows (1024 when the plan fills the chip in one round) where the pipelined kernel applies (group_size 64)
     assert L.hqq_hip_gemm_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 256 * 1024
     assert L.hqq_hip_gemm_workspace_bytes(4, 8192, 4096, 4096, 64, 1, 0) == 0
     assert L.hqq_hip_forward_workspace_bytes(4, 1, 4096, 4096, 64, 1, 0) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 1) == 1 and L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 2) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 513, 4096, 4096, 64, 1) == 0 and L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 32, 1) == 0
+    assert L.hqq_hip_forward_prefers_fused(4, 1025, 4096, 4096, 64, 1) == 0 and L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 32, 1) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 32, 4096, 4096, 64, 1) == 1
     # the decode plan: sizes and argument checks on the host
     assert L.hqq_hip_decode_plan_bytes(0) == 0 and L.hqq_hip_decode_plan_bytes(128) == 256 + 128 * 256 + 1280

@@ -175,8 +175,10 @@ def test_routing_workspace_and_variants(ops):
     from hqq_amd import _C
     L = _C.lib()
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 512, 22016, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 513, 4096, 4096, 64, 1) == 0      # long prompts: the composition is ahead
+    assert L.hqq_hip_forward_prefers_fused(4, 640, 22016, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 1     # 256 workgroups: one full round
+    assert L.hqq_hip_forward_prefers_fused(4, 768, 11008, 4096, 64, 1) == 0     # 129 workgroups: half the chip idle, the library is ahead
+    assert L.hqq_hip_forward_prefers_fused(4, 1025, 4096, 4096, 64, 1) == 0     # long prompts: the composition is ahead
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 128, 1) == 0     # group_size 128: not this kernel
     assert L.hqq_hip_forward_prefers_fused(3, 128, 4096, 4096, 64, 1) == 0
     assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 8192, 12288, 4096, 64, 1, 0) == 0

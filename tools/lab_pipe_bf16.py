@@ -11,7 +11,8 @@ def t(f, reps=10):
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
         for _ in range(reps): f()
-    gr.replay(); torch.cuda.synchronize()
+    for _ in range(10): gr.replay()   # warm replays (clocks ramp with load: a cold first timing reads up to 25 % slow)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3): gr.replay()

@@ -22,15 +22,20 @@ def timeit(fn, reps):
     with torch.cuda.graph(g):
         for _ in range(reps):
             fn()
-    g.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
+    for _ in range(max(2, int(3000 / (reps * 30)))):   # warm replays (clocks ramp with load: a cold first timing reads up to 25 % slow)
         g.replay()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (3 * reps)
+    best = None
+    for _ in range(3):   # best of three timing passes
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (3 * reps)
+        best = us if best is None or us < best else best
+    return best
 
 
 def main():
