@@ -31,6 +31,7 @@ SYMBOLS = {
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_forward_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemm_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
+    "hqq_hip_gemm_plan": (_i32, [_i32, _i64, _i64, _i64, _i64, _i32, _u32, _vp]),
     "hqq_hip_forward_prefers_fused": (_i32, [_i32, _i64, _i64, _i64, _i64, _i32]),
     "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_decode_plan_bytes": (_sz, [_i32]),

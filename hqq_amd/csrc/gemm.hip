@@ -445,6 +445,7 @@ struct GpPlan;
 size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts);
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype);
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K);
+void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                   int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
 
@@ -479,6 +480,14 @@ size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t 
       N % (8 / nbits) == 0)
     return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
   return hqq_hip_gemm_workspace_bytes(nbits, M, N, K, group_size, dtype, opts);
+}
+
+int hqq_hip_gemm_plan(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, int* out8) {
+  if (!out8) return HQQ_ERR_SHAPE;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  if (M < 1 || N <= 0 || K <= 0 || group_size <= 0 || !use_pipe(nbits, M, N, K, group_size, dtype, opts)) return HQQ_ERR_UNSUPPORTED;
+  gemm_pipe_describe(nbits, M, N, K, opts, out8);
+  return 0;
 }
 
 int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {

@@ -46,8 +46,9 @@ struct GdArgs {
   const half_t* zero;
   const half_t* bias;
   half_t* y;
-  float* part;     // [KS][tiles][PER * 8 accumulator quads][256 threads] x 4 fp32 (KS > 1 only)
+  float* part;     // [KS][split tiles][PER * BM / 16 accumulator quads][threads] x 4 fp32 (KS > 1 only)
   int M, N, K, G, n_tiles, m_tiles, KS, kps;
+  int full;        // the first `full` tiles run whole (no split); the remaining tiles x KS splits follow (full = 0: every tile is split, or KS = 1)
 };
 
 // chunk position (16 B units) inside a 128-byte row of the x stage: chunk ^ gd_swz(row).  Found by search over the GF(2)-linear maps
@@ -184,19 +185,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   // XCD-aware order (workgroup b runs on XCD b % 8 — observed; a speed assumption only): each XCD gets a contiguous run of logical
   // tiles, i.e. a band of token tiles x all feature tiles — its L2 then holds a few x tiles and one pass over the packed weights
   // instead of every x tile of the round.  Bijective for any grid size.
-  int b;
+  // A plan with more tiles than CUs whose last round would be partly empty runs the full rounds whole and splits only the tiles of
+  // the last round (they are the highest workgroup ids: dispatched last, finishing together with K / KS steps each).
+  const int tiles_all = a.n_tiles * a.m_tiles;
+  const bool whole = static_cast<int>(blockIdx.x) < a.full || a.KS == 1;
+  int tile, ks;
   {
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int base = whole ? 0 : a.full;
+    const int nwg = whole ? (a.KS == 1 ? static_cast<int>(gridDim.x) : a.full) : static_cast<int>(gridDim.x) - a.full;
+    const int h = static_cast<int>(blockIdx.x) - base, xcd = h & 7, idx = h >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
-    b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int split_tiles = tiles_all - a.full;
+    tile = whole ? L : a.full + L % split_tiles;
+    ks = whole ? 0 : L / split_tiles;
   }
-  const int nt = b % a.n_tiles, rest = b / a.n_tiles, mt = rest % a.m_tiles, ks = rest / a.m_tiles;
+  const int nt = tile % a.n_tiles, mt = tile / a.n_tiles;
   const int N = a.N, K = a.K, M = a.M, G = a.G;
   const int rows_per_slab = N / PER;
   const int p0 = nt * GD_PROWS + wave * 16, m0 = mt * GD_BM;
   const int nk = K / GD_K;
   const int kt0 = ks * a.kps;                                   // even (gp_plan)
-  const int nsteps = (kt0 + a.kps < nk ? kt0 + a.kps : nk) - kt0;
+  const int nsteps = whole ? nk : (kt0 + a.kps < nk ? kt0 + a.kps : nk) - kt0;
 
   // ---- per-lane DMA sources (rows past the end of the slab read the last row and are masked by a zero scale below; token rows past
   //      M read row 0: their accumulator columns are never stored, and a column depends on its own x row only) ----
@@ -362,10 +372,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the clamped DMAs past the last step: nothing may land in LDS after the workgroup is gone)
 
   // ---- D layout: lane (column r = token inside tile j, rows 4 c + i = packed row inside the wave's 16) ----
-  const int tile = mt * a.n_tiles + nt;
-  if (a.KS > 1) {   // park the split's fp32 tile in accumulator order (a wave writes 1 KiB of consecutive bytes per instruction)
-    const int64_t tiles = static_cast<int64_t>(a.n_tiles) * a.m_tiles;
-    f32x4* mine = reinterpret_cast<f32x4*>(a.part) + (static_cast<int64_t>(ks) * tiles + tile) * (PER * GD_MT * GD_T) + tid;
+  if (!whole) {   // park the split's fp32 tile in accumulator order (a wave writes 1 KiB of consecutive bytes per instruction)
+    const int64_t tiles = tiles_all - a.full;
+    f32x4* mine = reinterpret_cast<f32x4*>(a.part) + (static_cast<int64_t>(ks) * tiles + (tile - a.full)) * (PER * GD_MT * GD_T) + tid;
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
@@ -404,11 +413,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
   constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW, GD_BM = BM, GD_MT = BM / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, c = lane >> 4;
-  const int sj = blockIdx.x % (PER * GD_MT), tile = blockIdx.x / (PER * GD_MT);
+  const int sj = blockIdx.x % (PER * GD_MT), stile = blockIdx.x / (PER * GD_MT), tile = a.full + stile;   // (the split tiles only)
   const int s = sj / GD_MT, j = sj % GD_MT;
   const int nt = tile % a.n_tiles, mt = tile / a.n_tiles;
-  const int64_t tiles = static_cast<int64_t>(a.n_tiles) * a.m_tiles;
-  const f32x4* src = reinterpret_cast<const f32x4*>(a.part) + (static_cast<int64_t>(tile) * (PER * GD_MT) + sj) * GD_T + tid;
+  const int64_t tiles = static_cast<int64_t>(a.n_tiles) * a.m_tiles - a.full;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.part) + (static_cast<int64_t>(stile) * (PER * GD_MT) + sj) * GD_T + tid;
   const int64_t kstride = tiles * (PER * GD_MT * GD_T);
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < a.KS; k0 += 4) {
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
-struct GpPlan { int NW, BM, n_tiles, m_tiles, KS, kps; };
+struct GpPlan { int NW, BM, n_tiles, m_tiles, KS, kps, full; };   // full: tiles that run whole before the split ones (0 unless the plan is a hybrid)
 
 static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm, int ks) {
   GpPlan p;
@@ -446,6 +455,7 @@ static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm
   const int nk = static_cast<int>(K / GD_K);
   p.NW = nw;
   p.BM = bm;
+  p.full = 0;
   p.m_tiles = static_cast<int>((M + bm - 1) / bm);
   p.n_tiles = static_cast<int>((rows_per_slab + 16 * nw - 1) / (16 * nw));
   if (ks > GD_MAX_KS) ks = GD_MAX_KS;
@@ -460,16 +470,22 @@ static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm
 // rounds of workgroups x (steps x time per step + a fixed 5 us), the time per step growing with the number of CUs that pull the same x
 // tiles through L2 at once; a split adds the second launch and 0.4 us per MiB of parked fp32 tiles.  Picks the measured-best
 // (waves, splits) for 15 of the 16 Llama-2-7B cases swept and is within 12 % of the measured time everywhere.
-static double gp_cost(const GpPlan& p, int64_t M, int64_t N) {
-  const double wgs = static_cast<double>(p.n_tiles) * p.m_tiles * p.KS;
-  const double rounds = static_cast<double>((static_cast<int64_t>(wgs) + 255) / 256);
-  const double active = wgs < 256.0 ? wgs : 256.0;
+static double gp_tstep(const GpPlan& p, double active) {
   // us per 64-k step at low load, and its growth with the number of CUs at work (fitted to tools/lab_pipe_plan.py, 640..2048 rows)
   const double base = p.BM == 256 ? 1.37 : (p.NW == 4 ? 0.50 : 0.85);
   const double slope = p.BM == 256 ? 0.20 : (p.NW == 4 ? 0.40 : 0.28);
-  const double tstep = base * (1.0 + slope * active / 256.0);
-  double t = rounds * (p.kps * tstep + 5.0);
-  if (p.KS > 1) t += 1.5 + 0.4 * p.KS * static_cast<double>(p.m_tiles) * p.BM * static_cast<double>(N) * 4.0 / 1.0e6;
+  return base * (1.0 + slope * active / 256.0);
+}
+static double gp_cost(const GpPlan& p, int64_t M, int64_t N, int nk) {
+  const double tiles = static_cast<double>(p.n_tiles) * p.m_tiles;
+  const double split_tiles = tiles - p.full;
+  double t = 0.0;
+  if (p.full > 0) t += (p.full / 256) * (nk * gp_tstep(p, 256.0) + 5.0);           // whole rounds of unsplit tiles (full is a multiple of 256)
+  const double wgs = p.KS > 1 ? split_tiles * p.KS : tiles;
+  const int64_t rounds = (static_cast<int64_t>(wgs) + 255) / 256;
+  const double active = wgs < 256.0 ? wgs : 256.0;
+  t += static_cast<double>(rounds) * ((p.KS > 1 ? p.kps : nk) * gp_tstep(p, active) + 5.0);
+  if (p.KS > 1) t += 1.5 + 0.4 * p.KS * split_tiles * p.BM * (16.0 * p.NW * (static_cast<double>(N) / p.n_tiles / (16.0 * p.NW))) * 4.0 / 1.0e6;
   return t;
 }
 
@@ -483,17 +499,24 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
   static const int KSS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
   static const int SHAPES[3][2] = {{4, 128}, {8, 128}, {8, 256}};
   GpPlan best = gp_make(nbits, M, N, K, both ? 8 : (forced_nw ? forced_nw : 4), both && nbits != 2 ? 256 : 128, forced_ks ? forced_ks : 1);
-  double best_cost = gp_cost(best, M, N);
+  double best_cost = gp_cost(best, M, N, nk);
   for (const auto& sh : SHAPES) {
     if (both ? sh[1] != 256 : (forced_nw && (sh[0] != forced_nw || sh[1] != 128))) continue;
     if (sh[1] == 256 && nbits == 2) continue;   // four slabs x 16 token tiles of accumulators do not fit the register file
     for (int ks : KSS) {
       if (forced_ks && ks != 1) continue;
-      const GpPlan p = gp_make(nbits, M, N, K, sh[0], sh[1], forced_ks ? forced_ks : ks);
+      GpPlan p = gp_make(nbits, M, N, K, sh[0], sh[1], forced_ks ? forced_ks : ks);
       // at least sixteen steps (1024 k) per split: below that the prologue and the parked tile cost more than the split saves
       if (!forced_ks && p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
-      const double c = gp_cost(p, M, N);
+      const double c = gp_cost(p, M, N, nk);
       if (c < best_cost) { best = p; best_cost = c; }
+      // hybrid: more tiles than CUs and a partly filled last round -> the full rounds whole, the last round's tiles split `ks` ways
+      const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
+      if (!forced_ks && !(opts & HQQ_OPT_GEMM_NOHYBRID) && p.KS > 1 && tiles > 256 && tiles % 256 != 0 && (tiles % 256) * p.KS <= 256) {
+        p.full = static_cast<int>(tiles / 256 * 256);
+        const double ch = gp_cost(p, M, N, nk);
+        if (ch < best_cost) { best = p; best_cost = ch; }
+      }
     }
   }
   return best;
@@ -502,7 +525,7 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
 size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   if (p.KS <= 1) return 0;
-  const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
+  const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full;
   return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * p.BM * (16 * p.NW) * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
 }
 
@@ -514,8 +537,14 @@ bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
   if (M <= 640) return true;
   if (M > 1024) return false;
   const GpPlan p = gp_plan(nbits, M, N, K, 0);
-  const int64_t wgs = static_cast<int64_t>(p.n_tiles) * p.m_tiles * p.KS;
+  const int64_t wgs = (static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full) * p.KS;   // (the last round of a hybrid plan)
   return wgs >= 192 && wgs <= 256;
+}
+
+void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]) {
+  const GpPlan p = gp_plan(nbits, M, N, K, opts);
+  out[0] = p.NW; out[1] = p.BM; out[2] = p.n_tiles; out[3] = p.m_tiles; out[4] = p.KS; out[5] = p.kps; out[6] = p.full;
+  out[7] = static_cast<int>(p.full + (static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full) * p.KS);
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {
@@ -544,7 +573,7 @@ static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
   hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW, BM, BF>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
   int rc = check_launch("hqq_hip_gemm(pipelined)");
   if (rc || a.KS <= 1) return rc;
-  const int64_t rblocks = static_cast<int64_t>(a.n_tiles) * a.m_tiles * ((8 / NBITS) * (BM / 16));
+  const int64_t rblocks = (static_cast<int64_t>(a.n_tiles) * a.m_tiles - a.full) * ((8 / NBITS) * (BM / 16));
   hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW, BM, BF>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
@@ -553,14 +582,14 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
                   int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
-  const int64_t blocks = tiles * p.KS;
+  const int64_t blocks = p.full + (tiles - p.full) * p.KS;
   if (blocks * ((8 / nbits) * (p.BM / 16)) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
   GdArgs a;
   a.x = static_cast<const half_t*>(x); a.Wq = static_cast<const uint8_t*>(Wq); a.scale = static_cast<const half_t*>(scale);
   a.zero = static_cast<const half_t*>(zero); a.bias = static_cast<const half_t*>(bias); a.y = static_cast<half_t*>(y);
   a.part = nullptr;
   a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K); a.G = static_cast<int>(K / gs);
-  a.n_tiles = p.n_tiles; a.m_tiles = p.m_tiles; a.KS = p.KS; a.kps = p.kps;
+  a.n_tiles = p.n_tiles; a.m_tiles = p.m_tiles; a.KS = p.KS; a.kps = p.kps; a.full = p.full;
   if (!aligned16(scale) || !aligned16(zero)) { set_error("hqq_hip_gemm: scale / zero must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
   if (p.KS > 1) {
     const size_t need = gemm_pipe_workspace_bytes(nbits, M, N, K, opts);

@@ -111,7 +111,8 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_SKINNY_KS(n) ((uint32_t)(n) << 24)   /* 5..64 rows, and the split-K fused GEMM: force n K-splits (tuning; 0 = built-in rule) */
 #define HQQ_OPT_GEMM_NARROW  64u   /* pipelined fused GEMM: force 4 waves per workgroup (64 packed rows per tile) — tuning */
 #define HQQ_OPT_GEMM_WIDE   128u   /* pipelined fused GEMM: force 8 waves per workgroup (128 packed rows per tile) — tuning */
-#define HQQ_OPT_ALL (255u | (255u << 24))
+#define HQQ_OPT_GEMM_NOHYBRID 256u  /* pipelined fused GEMM: never split only the last round of tiles (tuning) */
+#define HQQ_OPT_ALL (511u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.
@@ -168,6 +169,10 @@ size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */
 size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);
+/* introspection (host arithmetic only): how the pipelined fused GEMM would run this shape — out8 = {waves per workgroup, tokens per tile,
+ * feature tiles, token tiles, K splits, steps per split, tiles that run unsplit before the split ones, workgroups}; HQQ_ERR_UNSUPPORTED
+ * when another kernel serves the shape */
+int hqq_hip_gemm_plan(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, int* out8);
 size_t hqq_hip_gemm_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);   /* hqq_hip_gemm called directly, any M */
 /* 1 when, for this shape, the fused kernels behind hqq_hip_forward are measured faster on MI355X than hqq_hip_dequantize + a library
  * GEMM on the result (the caller's alternative for M > HQQ_GEMV_MAX_M_SKINNY), else 0: a speed hint, never a correctness matter. */

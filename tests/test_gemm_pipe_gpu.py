@@ -151,6 +151,33 @@ def test_pipelined_gemm_bf16(ops, oracle, nbits, M, N, K):
         assert torch.equal(ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=tile), Wdev[:, cols].t().contiguous())
 
 
+@pytest.mark.parametrize("nbits,M,N,K", [(4, 2176, 4096, 4096), (4, 1664, 5120, 4096), (8, 1150, 4096, 4096), (4, 3328, 5120, 2048)])
+def test_hybrid_plan_full_rounds_whole_last_round_split(ops, nbits, M, N, K):
+    """more tiles than CUs with a partly filled last round: the plan runs the full rounds unsplit and splits only the last round's
+    tiles (hqq_hip_gemm_plan reports it) — same exact weights on every row of y (one-hot probes incl. rows served by split tiles),
+    results equal to the unsplit plan's up to fp32 summation order, reproducible bits"""
+    import ctypes
+    from hqq_amd import _C
+    plan = (ctypes.c_int * 8)()
+    assert _C.lib().hqq_hip_gemm_plan(nbits, M, N, K, 64, 1, 0, plan) == 0
+    assert plan[6] > 0 and plan[6] % 256 == 0 and plan[4] > 1, list(plan)      # a hybrid plan on a 256-CU device
+    U, s, z = _layer(N, K, nbits, M + N + K, True)
+    P = ops.pack(nbits, U.cuda())
+    s, z = s.cuda(), z.cuda()
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(2)).half().cuda()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3)).half().cuda()
+    y = ops.gemm(x, P, s, z, bias, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE)
+    assert torch.equal(y, ops.gemm(x, P, s, z, bias, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE))
+    y1 = ops.gemm(x, P, s, z, bias, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE | ops.OPT_GEMM_NOHYBRID)
+    torch.testing.assert_close(y.float(), y1.float(), rtol=2e-3, atol=2e-2)
+    Wd = ops.dequantize(P, s.reshape(-1), z.reshape(-1), N, K, 64, nbits)
+    torch.testing.assert_close(y.float(), x.float() @ Wd.float().t() + bias.float(), rtol=2e-3, atol=2e-3 * float(y.float().abs().max()) / 4 + 2e-3)
+    e = torch.zeros(M, K, dtype=torch.float16, device="cuda")
+    cols = torch.arange(M, device="cuda") * 37 % K
+    e[torch.arange(M, device="cuda"), cols] = 1.0
+    assert torch.equal(ops.gemm(e, P, s, z, None, N, K, 64, nbits, opts=ops.OPT_META_SCALABLE), Wd[:, cols].t().contiguous())
+
+
 def test_full_size_layers_one_hot_exact_and_linear(ops):
     """Llama-2-7B shapes at 128 and 1000 rows: every weight the kernel multiplies is the dequantised weight (one-hot rows), and the
     result is linear in x — size-independent properties, no oracle needed"""
