@@ -254,6 +254,31 @@ def cpu_baseline(nbits):
             out["tok_s_7b_stack_equiv"] = round(1.0 / (t * stack_calls), 4)
     except Exception as e:   # the oracle is optional here (it is the checker, not the product)
         out["c_port"] = {"error": repr(e)}
+    # ---- (3) the other hot path: Quantizer.quantize (solver + final levels) through the C oracle, bounded sample ----
+    try:
+        from oracle import hqq_oracle as orc
+        rng = np.random.default_rng(1)
+        Wn = (rng.standard_normal((512, 4096), dtype=np.float32) * 0.02)   # 1/8 of a 4096 x 4096 layer: groups are independent
+        import ctypes
+        try:
+            gomp = ctypes.CDLL("libgomp.so.1")
+        except OSError:
+            gomp = None
+        best = None
+        for th in (sorted({min(cores, 8), min(cores, 32), cores}) if gomp is not None else [0]):   # OpenMP does not scale to every core of a big host either
+            if gomp is not None:
+                gomp.omp_set_num_threads(int(th))
+            t0 = time.perf_counter()
+            r = orc.quantize(Wn, nbits=nbits if nbits in (8, 4, 3, 2) else 4, group_size=64)
+            el = time.perf_counter() - t0
+            if best is None or el < best[0]:
+                best = (el, th, int(r["iters_run"]))
+        el, th, its = best
+        out["quantize"] = {"s_per_4096x4096_layer": round(el * 8, 3), "iters_run": its, "threads": th,
+                           "sample": f"oracle/hqq_oracle.c quantize (the reference's CPU float32 solver restated, OpenMP, {th or 'default'} threads: the fastest of 8/32/{cores}) "
+                                     f"on 512 x 4096 weights: {el:.2f} s, x 8 for the layer"}
+    except Exception as e:
+        out["quantize"] = {"error": repr(e)}
     return out
 
 
@@ -510,6 +535,27 @@ def main():
                 legs[-1]["status"] = p2.status()
             except Exception as e:
                 legs.append({"name": "persistent decode engine", "error": repr(e)})
+        # the other hot path: Quantizer.quantize = solver + packing, one HIP launch chain per layer
+        try:
+            qres = []
+            for nm, N_, K_ in (("4096x4096", 4096, 4096), ("11008x4096", 11008, 4096), ("4096x11008", 4096, 11008)):
+                Wsrc = (torch.randn(N_, K_, device=dev, generator=gx) * 0.02).half()
+                ops.quantize(Wsrc, nbits=nbits, group_size=64, round_zero=(nbits == 4))
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    _, _, _, info = ops.quantize(Wsrc, nbits=nbits, group_size=64, round_zero=(nbits == 4), return_info=True)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                its = int(info[0].item())
+                qres.append({"layer": nm, "ms": round(ms, 3), "iters_run": its, "G_element_iters_per_s": round(N_ * K_ * 20 / (ms * 1e-3) / 1e9, 1),
+                             "hbm_floor_ms": round((2 + nbits / 8) * N_ * K_ / (HBM_PEAK_GBS * 1e9) * 1e3, 4)})
+            out["quantize"] = {"layers": qres, "note": "Quantizer.quantize (20 proximal iterations computed, stop index applied as the reference does) + bit-packing, fp16 weights in HBM; "
+                               "bound: VALU / transcendental (one double-precision pow per element and iteration), hbm_floor = one read of W + one write of W_q"}
+        except Exception as e:
+            out["quantize"] = {"error": repr(e)}
         # 128 rows through every layer of the stack (batched decode / speculative verification / short prompts): the pipelined split-K
         # fused GEMM (csrc/gemm_pipe.hip) against the alternative a caller has — dequantise kernel + library GEMM on the result
         if nbits in (8, 4, 2):
