@@ -553,7 +553,8 @@ def main():
                 qres.append({"layer": nm, "ms": round(ms, 3), "iters_run": its, "G_element_iters_per_s": round(N_ * K_ * 20 / (ms * 1e-3) / 1e9, 1),
                              "hbm_floor_ms": round((2 + nbits / 8) * N_ * K_ / (HBM_PEAK_GBS * 1e9) * 1e3, 4)})
             out["quantize"] = {"layers": qres, "note": "Quantizer.quantize (20 proximal iterations computed, stop index applied as the reference does) + bit-packing, fp16 weights in HBM; "
-                               "bound: VALU / transcendental (one double-precision pow per element and iteration), hbm_floor = one read of W + one write of W_q"}
+                               "bound: VALU (float32 division, rounding, clamp, sign, the ATen-ordered row sum; the double-precision pow of the shrinkage is evaluated only in waves "
+                               "where it can matter), hbm_floor = one read of W + one write of W_q"}
         except Exception as e:
             out["quantize"] = {"error": repr(e)}
         # 128 rows through every layer of the stack (batched decode / speculative verification / short prompts): the pipelined split-K

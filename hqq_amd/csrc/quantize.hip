@@ -40,6 +40,16 @@ template <> __device__ __forceinline__ float load_f32<bf16_t>(const bf16_t* p, i
 
 __device__ __forceinline__ float sgnf(float e) { return static_cast<float>((e > 0.f) - (e < 0.f)); }
 
+// |e|^(p-1) evaluated in double and rounded once to float (ATen's Sleef powf is <= 1 ulp; this matched it on every fixture)
+__device__ __forceinline__ float pow_lp(float a, double pexp) {
+#ifdef SOLVE_LAB_NOPOW
+  return a * static_cast<float>(pexp);   // lab: timing without the transcendental (wrong numerics)
+#else
+  return static_cast<float>(pow(static_cast<double>(a), pexp));   // a = 0 -> +inf
+#endif
+}
+
+
 struct SolveParams {
   int64_t R;          // number of groups
   int gs;
@@ -49,7 +59,22 @@ struct SolveParams {
   float inv_beta;     // (float)(1.0 / beta)
   double pexp;        // (double)(float)(lp_norm - 1)
   int lp_is_one;
+  float a_skip;       // |e| below this: the shrinkage is provably clamped to 0, no pow needed (0: always evaluate)
 };
+
+// shrink_lp_op's argument before clamp_min_(0) (optimize.py:96-108): |e| - (1/beta) |e|^(p-1).  The double-precision pow was 84 % of the
+// solver's time, and for 0 < p < 1 it is only needed near and above a* = (1/beta)^(1/(2-p)), where the argument changes sign: with
+// a = c a*, the argument is a* (c - c^(p-1)) — increasing in c, and <= -0.1 a* for c <= 0.9, far outside any rounding.  Below
+// a_skip = 0.9 a* the caller's clamp gives exactly 0 either way, so the wave skips the pow unless one of its lanes needs it (errors of
+// a quantised layer are ~1e-3 against a* = 0.17 at the reference's beta = 10, p = 0.7: practically every wave skips).  Bit-identical.
+__device__ __forceinline__ float shrink_arg(float a, const SolveParams& p) {
+  if (p.lp_is_one) return a - p.inv_beta;
+  const bool need = !(a < p.a_skip);                      // (NaN: evaluate, it must stay NaN)
+  if (__builtin_amdgcn_ballot_w64(need) == 0) return -1.0f;   // any negative value: clamped to 0 by the caller
+  const float pw = pow_lp(a, p.pexp);                     // a = 0 -> +inf
+  const float t = p.inv_beta * pw;
+  return a - t;                                           // 0 - inf = -inf -> clamped by the caller
+}
 
 // workspace: s_ws[R] | zero_hist[(iters+1)][R] | err_part[nblocks][iters] (double) | err_mean[iters] (double)
 template <typename WT, int EPL>
@@ -95,14 +120,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WT* __restri
       const float e = wf - wr;                 // :204
       const float a = fabsf(e);
       eabs += a;                               // :239 (partial of the layer-global mean)
-      float t;                                 // shrink_lp_op, optimize.py:96-108
-      if (p.lp_is_one) {
-        t = a - p.inv_beta;
-      } else {
-        const float pw = static_cast<float>(pow(static_cast<double>(a), p.pexp));   // a = 0 -> +inf
-        t = p.inv_beta * pw;
-        t = a - t;                             // 0 - inf = -inf -> clamped below
-      }
+      float t = shrink_arg(a, p);              // shrink_lp_op, optimize.py:96-108
       t = (t < 0.f) ? 0.f : t;                 // clamp_min_(0); NaN stays NaN
       const float we = t * sgnf(e);
       float u = wf - we;                       // :205
@@ -201,14 +219,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_generic_kernel(const WT* 
       const float e = wf - wr;
       const float a = fabsf(e);
       eabs += static_cast<double>(a);
-      float t;
-      if (p.lp_is_one) {
-        t = a - p.inv_beta;
-      } else {
-        const float pw = static_cast<float>(pow(static_cast<double>(a), p.pexp));
-        t = p.inv_beta * pw;
-        t = a - t;
-      }
+      float t = shrink_arg(a, p);
       t = (t < 0.f) ? 0.f : t;
       const float we = t * sgnf(e);
       float u = wf - we;
@@ -383,14 +394,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
         const float e = wf - wr;
         const float aa = fabsf(e);
         eabs += static_cast<double>(aa);
-        float t;
-        if (p.lp_is_one) {
-          t = aa - p.inv_beta;
-        } else {
-          const float pw = static_cast<float>(pow(static_cast<double>(aa), p.pexp));
-          t = p.inv_beta * pw;
-          t = aa - t;
-        }
+        float t = shrink_arg(aa, p);
         t = (t < 0.f) ? 0.f : t;
         const float we = t * sgnf(e);
         float u = wf - we;
@@ -419,9 +423,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
           const float wr = (q - ze) / sc;
           const float e = wf - wr;
           const float aa = fabsf(e);
-          float t;
-          if (p.lp_is_one) t = aa - p.inv_beta;
-          else { const float pw = static_cast<float>(pow(static_cast<double>(aa), p.pexp)); t = p.inv_beta * pw; t = aa - t; }
+          float t = shrink_arg(aa, p);
           t = (t < 0.f) ? 0.f : t;
           const float we = t * sgnf(e);
           float u = wf - we; u = u * sc;
@@ -570,6 +572,7 @@ static int run_quantize(const void* W, int64_t numel, int64_t gs, int max_v, int
   p.inv_beta = static_cast<float>(1.0 / static_cast<double>(beta));
   p.pexp = static_cast<double>(static_cast<float>(static_cast<double>(lp_norm) - 1.0));
   p.lp_is_one = (lp_norm == 1.0f);
+  p.a_skip = (p.pexp < 0.0 && p.pexp > -1.0 && p.inv_beta > 0.f && true) ? static_cast<float>(0.9 * pow(static_cast<double>(p.inv_beta), 1.0 / (1.0 - p.pexp))) : 0.f;
   int rc = dispatch_solve<WT>(W, p, s_ws, zh, ep, L.nblocks, st);
   if (rc) return rc;
   if (iters > 0) {
@@ -599,6 +602,7 @@ static int run_quantize_axis0(const void* W, int64_t numel, int64_t gs, int max_
   p.inv_beta = static_cast<float>(1.0 / static_cast<double>(beta));
   p.pexp = static_cast<double>(static_cast<float>(static_cast<double>(lp_norm) - 1.0));
   p.lp_is_one = (lp_norm == 1.0f);
+  p.a_skip = (p.pexp < 0.0 && p.pexp > -1.0 && p.inv_beta > 0.f && true) ? static_cast<float>(0.9 * pow(static_cast<double>(p.inv_beta), 1.0 / (1.0 - p.pexp))) : 0.f;
   const int64_t nblocks = (C + 255) / 256;   // (<= the axis-1 block count the workspace was sized for)
   hipLaunchKernelGGL((solve0_kernel<WT>), dim3(static_cast<unsigned>(nblocks)), dim3(256), sizeof(double) * 256 * (iters > 0 ? iters : 1), st,
                      static_cast<const WT*>(W), p, C, s_ws, zh, ep);

@@ -474,6 +474,29 @@ def test_quantize_tensorwise_vs_oracle_large(ops, oracle):
     assert bool(torch.isnan(s)) and bool(torch.isnan(z))
 
 
+@pytest.mark.parametrize("nbits,std", [(2, 1.0), (3, 1.0), (4, 3.0), (4, 0.02)])
+def test_solver_pow_skip_is_bit_identical(ops, oracle, nbits, std):
+    """the solver evaluates |e|^(p-1) only in waves where some |e| reaches 0.9 a* (a* = (1/beta)^(1/(2-p)) = 0.170: below it the
+    shrinkage is clamped to 0 whatever the pow returns).  Layers with errors on both sides of the threshold — coarse grids on N(0, 1)
+    weights, where the pow IS needed for many elements — and an ordinary layer stay bit-identical to the oracle, which always evaluates it"""
+    W = torch.randn(256, 1024, generator=torch.Generator().manual_seed(nbits)) * std
+    W[7, 100] = 25.0 * std                                     # an outlier group: errors far above the threshold
+    o = oracle.quantize(W.numpy(), nbits=nbits, group_size=64)
+    Wq, s, z = ops.quantize(W.cuda(), nbits=nbits, group_size=64, round_zero=(nbits == 4))
+    assert np.array_equal(Wq.cpu().numpy(), oracle.pack(nbits, o["Wq"]))
+    assert np.array_equal(z.cpu().numpy().view(np.uint32), o["zero"].view(np.uint32))
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), o["scale"].view(np.uint32))
+    err = np.abs(W.numpy().reshape(-1, 64) - (o["Wq"].astype(np.float32) - o["zero"]) * o["scale"])
+    if std >= 1.0:
+        assert (err > 0.16).mean() > 0.01 and (err < 0.1).mean() > 0.01    # both sides of the threshold are populated
+    # other norms: p = 1 has no pow; p > 1 and beta variations never skip or move the threshold
+    for lp, beta in ((1.0, 10.0), (0.5, 4.0), (1.5, 10.0)):
+        o2 = oracle.quantize(W.numpy(), nbits=nbits, group_size=64, lp_norm=lp, beta=beta)
+        Wq2, s2, z2 = ops.quantize(W.cuda(), nbits=nbits, group_size=64, round_zero=(nbits == 4), lp_norm=lp, beta=beta)
+        assert np.array_equal(Wq2.cpu().numpy(), oracle.pack(nbits, o2["Wq"]))
+        assert np.array_equal(z2.cpu().numpy().view(np.uint32), o2["zero"].view(np.uint32))
+
+
 def test_hqqlinear_per_channel_group_size_none(ops, oracle):
     """group_size=None (one group per output row, quantize.py:434-439): the generic-group-size solver, bit-exact against the oracle,
     and a forward that agrees with dequantize() — whatever kernel or composition serves that group size"""
