@@ -445,6 +445,7 @@ struct GpPlan;
 size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts);
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype);
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K);
+bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);   // skinny.hip
 void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                   int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
@@ -492,7 +493,8 @@ int hqq_hip_gemm_plan(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_
 
 int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
-  if (M <= HQQ_GEMV_MAX_M_SKINNY) return 1;   // decode-sized: always the weight-streaming kernels where they apply
+  if (M <= HQQ_GEMV_MAX_M) return 1;          // decode: always the weight-streaming kernels (hqq_hip_gemv reports what it does not cover)
+  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, &N, 1)) return 1;
   return gemm_pipe_covers(nbits, M, N, K, group_size, dtype) && gemm_pipe_wins(nbits, M, N, K) ? 1 : 0;
 }
 

@@ -354,7 +354,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
     if fused is None:
         fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
             (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M)) or \
-            (M > SKINNY_MAX_M and x.is_cuda and nbits in (8, 4, 2) and x.dtype in _DT and
+            (M > GEMV_MAX_M and x.is_cuda and nbits in (8, 4, 2) and x.dtype in _DT and
              bool(_C.lib().hqq_hip_forward_prefers_fused(int(nbits), M, int(N), int(K), int(group_size or 0), _dt(x.dtype))))
     if fused:
         return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
