@@ -62,18 +62,29 @@ struct SolveParams {
   float a_skip;       // |e| below this: the shrinkage is provably clamped to 0, no pow needed (0: always evaluate)
 };
 
-// shrink_lp_op's argument before clamp_min_(0) (optimize.py:96-108): |e| - (1/beta) |e|^(p-1).  The double-precision pow was 84 % of the
+// shrink_lp_op (optimize.py:96-108): W_e = sign(e) max(|e| - (1/beta) |e|^(p-1), 0).  The double-precision pow was 84 % of the
 // solver's time, and for 0 < p < 1 it is only needed near and above a* = (1/beta)^(1/(2-p)), where the argument changes sign: with
 // a = c a*, the argument is a* (c - c^(p-1)) — increasing in c, and <= -0.1 a* for c <= 0.9, far outside any rounding.  Below
 // a_skip = 0.9 a* the caller's clamp gives exactly 0 either way, so the wave skips the pow unless one of its lanes needs it (errors of
 // a quantised layer are ~1e-3 against a* = 0.17 at the reference's beta = 10, p = 0.7: practically every wave skips).  Bit-identical.
-__device__ __forceinline__ float shrink_arg(float a, const SolveParams& p) {
-  if (p.lp_is_one) return a - p.inv_beta;
-  const bool need = !(a < p.a_skip);                      // (NaN: evaluate, it must stay NaN)
-  if (__builtin_amdgcn_ballot_w64(need) == 0) return -1.0f;   // any negative value: clamped to 0 by the caller
-  const float pw = pow_lp(a, p.pexp);                     // a = 0 -> +inf
-  const float t = p.inv_beta * pw;
-  return a - t;                                           // 0 - inf = -inf -> clamped by the caller
+// returns u = (W_f - W_e) * scale of optimize.py:204-205 with W_e = shrink(e), e = W_f - W_r, a = |e|
+__device__ __forceinline__ float shrink_u(float wf, float e, float a, float sc, const SolveParams& p) {
+  float t;
+  if (p.lp_is_one) {
+    t = a - p.inv_beta;
+  } else {
+    const bool need = !(a < p.a_skip);                          // (NaN: evaluate, it must stay NaN)
+    // nobody in the wave can get a non-zero W_e: it is +-0, and (W_f - (+-0)) * scale = W_f * scale (the sign of a zero is dropped by
+    // the subtraction from the level that follows) — no pow, no clamp, no sign
+    if (__builtin_amdgcn_ballot_w64(need) == 0) return wf * sc;
+    const float pw = pow_lp(a, p.pexp);                         // a = 0 -> +inf
+    t = p.inv_beta * pw;
+    t = a - t;                                                  // 0 - inf = -inf -> clamped below
+  }
+  t = (t < 0.f) ? 0.f : t;                                      // clamp_min_(0); NaN stays NaN
+  const float we = t * sgnf(e);
+  const float u = wf - we;                                      // :205
+  return u * sc;
 }
 
 // workspace: s_ws[R] | zero_hist[(iters+1)][R] | err_part[nblocks][iters] (double) | err_mean[iters] (double)
@@ -120,11 +131,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WT* __restri
       const float e = wf - wr;                 // :204
       const float a = fabsf(e);
       eabs += a;                               // :239 (partial of the layer-global mean)
-      float t = shrink_arg(a, p);              // shrink_lp_op, optimize.py:96-108
-      t = (t < 0.f) ? 0.f : t;                 // clamp_min_(0); NaN stays NaN
-      const float we = t * sgnf(e);
-      float u = wf - we;                       // :205
-      u = u * sc;
+      const float u = shrink_u(wf, e, a, sc, p);   // shrink_lp_op, optimize.py:96-108, :205
       t3[v] = q - u;
     }
     // row sum in ATen order: 4 interleaved accumulators over the 8-wide vectors, leftovers to acc 0,
@@ -219,11 +226,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_generic_kernel(const WT* 
       const float e = wf - wr;
       const float a = fabsf(e);
       eabs += static_cast<double>(a);
-      float t = shrink_arg(a, p);
-      t = (t < 0.f) ? 0.f : t;
-      const float we = t * sgnf(e);
-      float u = wf - we;
-      u = u * sc;
+      const float u = shrink_u(wf, e, a, sc, p);
       const float t3 = q - u;
       if (v < size_ilp * 4) {
         const int k = v & 3;
@@ -394,11 +397,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
         const float e = wf - wr;
         const float aa = fabsf(e);
         eabs += static_cast<double>(aa);
-        float t = shrink_arg(aa, p);
-        t = (t < 0.f) ? 0.f : t;
-        const float we = t * sgnf(e);
-        float u = wf - we;
-        u = u * sc;
+        const float u = shrink_u(wf, e, aa, sc, p);
         const float t3 = q - u;
         if (casc_col) {
           c0.add(t3);
@@ -423,10 +422,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
           const float wr = (q - ze) / sc;
           const float e = wf - wr;
           const float aa = fabsf(e);
-          float t = shrink_arg(aa, p);
-          t = (t < 0.f) ? 0.f : t;
-          const float we = t * sgnf(e);
-          float u = wf - we; u = u * sc;
+          const float u = shrink_u(wf, e, aa, sc, p);
           sum += q - u;
         }
         sum += c1.total();
