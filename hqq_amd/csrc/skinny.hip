@@ -301,7 +301,11 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       f = f < 8 * MT ? f : 8 * MT - 1;   // (8 MT not a multiple of the wave count: the spare pieces repeat the last fragment)
       const int t = f >> 3, j = (f & 7) >> 1, h = f & 1;
       const int m = 16 * t + r;
+#ifdef SK_LAB_NOX      // lab: no x loads
+      xr[set][i] = u32x4{0x3C003C00u + static_cast<uint32_t>(m + chunk + j + h), 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+#else
       xr[set][i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
+#endif
     }
   };
   auto xstore = [&](int buf, int set) {
@@ -376,7 +380,11 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       int pm = (panel - ly.panel0) * SK_ROWS + row;
       pm = pm < rows_per_slab ? pm : rows_per_slab - 1;
       const half_t* src = (hi ? ly.scale : ly.zero) + static_cast<int64_t>(pm + s * rows_per_slab) * G + (c0 + (cc < c1 - c0 ? cc : 0)) * SK_BLK;
+#ifdef SK_LAB_NOMETA   // lab (tools/r2_lab_skinny.sh): no group-constant loads — timing only, wrong results
+      mv[rd][pass] = u32x2{0x3C003C00u + static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 0u), 0x3C003C00u};
+#else
       mv[rd][pass] = *reinterpret_cast<const u32x2*>(src);
+#endif
     }
   SK_TS();   // 2: group constants requested
   xload(c0, 0);
@@ -460,7 +468,12 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   //      instruction), the LAST split of the row group to arrive — a ticket from an atomic counter, no waiting — adds all KS tiles
   //      in split order and goes on to the store below.  Fixed order, so the bits do not depend on which split finished last;
   //      no second launch (the finishing kernel this replaces cost one graph-node gap + ~1 us per call). ----
+#ifdef SK_LAB_NOFIN    // lab: no partial tiles, no ticket
+  if (a.KS > 1 && ks != 0) { SK_TS_FLUSH(); return; }
+  if (false) {
+#else
   if (a.KS > 1) {
+#endif
     constexpr int TILE = PER * MT * 4 * 64;   // floats per (split, panel, row group)
     const int64_t slot = static_cast<int64_t>(panel) * SK_RG + rg;
     const int64_t kstride = static_cast<int64_t>(a.total_panels) * SK_RG * TILE;
