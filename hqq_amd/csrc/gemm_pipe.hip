@@ -309,8 +309,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
       const int row = (part * HT + j) * 16 + r;
+#ifdef GP_LAB_NODSR   // lab switches (tools/r2_lab_pipe.sh): one part of a step compiled out — timing only, wrong results
+      f0[j] = u32x4{0x3C003C00u + static_cast<uint32_t>(row), 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}; f1[j] = f0[j];
+      (void)xs;
+#else
       f0[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c) ^ gd_swz(row)) << 4));
       f1[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c + 1) ^ gd_swz(row)) << 4));
+#endif
     }
   };
   auto mfma = [&](const u32x4& A, const u32x4& B, f32x4 C) {
@@ -318,6 +323,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, A), __builtin_bit_cast(h8_t, B), C, 0, 0, 0);
   };
   auto mma = [&](int part, const u32x4 (&ca0)[PER], const u32x4 (&ca1)[PER], const u32x4 (&f0)[HT], const u32x4 (&f1)[HT]) {
+#ifdef GP_LAB_NOMFMA
+#pragma unroll
+    for (int j = 0; j < HT; ++j) { acc[0][part * HT + j][0] += __uint_as_float(ca0[0][0] ^ f0[j][0]); acc[PER - 1][part * HT + j][1] += __uint_as_float(ca1[PER - 1][1] ^ f1[j][1]); }
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
@@ -340,9 +350,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
     }
     // (lgkmcnt(0): this wave's fragment reads have left the LDS before another wave's DMA may overwrite the stage)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_OUT) : "memory");
+#ifndef GP_LAB_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     constexpr bool SPREAD = NW == 8;   // measured: +5 % with two waves per SIMD, -3..9 % with one (there the earlier issue matters more)
     auto issue_all = [&]() {
+#ifdef GP_LAB_NODMA
+      return;
+#endif
       issue_w(i + GD_PW);
       if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
       issue_x(i + GD_PX);
@@ -353,7 +368,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
     const u32x4 raw = read_w(i + 1);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SPREAD) issue_all();   // the DMA issue (60-185 cycles a piece in a burst) goes UNDER the last part's MFMAs, like the rebuild's VALU work
+#ifndef GP_LAB_NOVALU
     rebuild(raw, i + 1, na0, na1);
+#endif
     mma(NQ - 1, ca0, ca1, bB0, bB1);
     if constexpr (SPREAD) {
       constexpr int NMF = PER * HT * 2, NDMA = 1 + XP + MD::NI;

@@ -1,5 +1,7 @@
 #!/bin/bash
-# lab: which part of a pipelined-GEMM step costs what (variants built by tools/build_variant.sh with one part compiled out)
+# lab: which part of a pipelined-GEMM step costs what.  Build the variants first, e.g.
+#   for v in NODMA NOVALU NOMFMA NOBAR NODSR; do bash tools/build_variant.sh gp_$v gemm_pipe.hip "-DGP_LAB_$v"; done
+#   bash tools/build_variant.sh gp_ONLYDSR gemm_pipe.hip "-DGP_LAB_NODMA -DGP_LAB_NOVALU -DGP_LAB_NOMFMA"   (and so on)
 R=$GRAFT_REPO_ROOT
 cat > /tmp/t.py <<'PY'
 import sys, torch
@@ -28,6 +30,6 @@ for M, KS in ((128, 1), (128, 8), (1024, 1)):
     print(f"  M={M} KS={KS}: {e0.elapsed_time(e1) * 1e3 / 60:.1f} us", end="")
 print()
 PY
-for v in "" gp_NODMA gp_NOXDMA gp_NOVALU gp_NOMFMA gp_NOBAR $EXTRA_VARIANTS; do
+for v in "" gp_NODMA gp_NOVALU gp_NOMFMA gp_NOBAR gp_NODSR $EXTRA_VARIANTS; do
   if [ -z "$v" ]; then echo -n "shipped:"; python /tmp/t.py $R; else echo -n "$v:"; HQQ_AMD_LIB=$R/tools/libhqq_hip_$v.so python /tmp/t.py $R; fi
 done
