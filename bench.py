@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0, help="decoder blocks (default: 32 for the 7B stack, 80 for the 70B one)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
+    ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, 70B strong scaling: skip timing the unsharded stack on rank 0 alone")
     ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
     ap.add_argument("--engine", action="store_true", help="headline through the persistent decode engine (one launch per token) instead of 128 launches")
@@ -488,6 +489,35 @@ def main():
             out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5), "all_gathers_per_step": stages_per_step,
                                "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK),
                                "note": "all-gather + un-permute of every exchange point, timed without the GEMV launches"}
+            if strong and not a.no_single_gpu_reference:
+                # the SAME fixed stack on ONE GPU (rank 0 alone, the others wait): the single-GPU time a strong-scaling figure refers to
+                single = None
+                if rank == 0:
+                    try:
+                        fb = []
+                        for b_ in range(nblocks):
+                            fb.append({name: make_layer(ops, name, N, K, nbits, dev, seed=424242 + 16 * b_ + i, random_codes=True, cd=cd)
+                                       for i, (name, N, K) in enumerate(BLOCK)})
+                        fo = {grp: [torch.empty(M, fb[0][n].N, device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+
+                        def full_step():
+                            for blk in fb:
+                                for grp in EXCHANGE_GROUPS:
+                                    Ls = [blk[name] for name in grp]
+                                    ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
+                                                     outs=fo[grp], opts=group_opts(Ls))
+                        frun, fg = _graphed(full_step, not a.no_graph, rank)
+                        fw, fd = _timed(frun, max(5, a.steps // 2), 3)
+                        fbytes = nblocks * sum(gemv_bytes(N, K, nbits, M) for _, N, K in BLOCK)
+                        single = {"ms_per_step": round(fw * 1e3, 5), "value": round(fbytes / fw / 1e9, 2), "unit": "GB/s", "graph": fg,
+                                  "note": "the whole (unsharded) stack of this workload on rank 0's GPU alone, random codes, same kernels, no exchange"}
+                        del fb, fo
+                        torch.cuda.empty_cache()
+                    except Exception as e:   # (memory, mostly: 35 GB of int4 70B weights beside the shard)
+                        single = {"error": repr(e)}
+                dist.barrier()
+                if rank == 0:
+                    out["single_gpu"] = single
     else:
         tfl = world * flops_per_step_rank / sec_per_step / 1e12
         out.update({
