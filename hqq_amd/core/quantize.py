@@ -426,6 +426,9 @@ class HQQLinear(nn.Module):
     forward_pytorch_compile = forward_pytorch
     forward_aten_backprop = forward_pytorch_backprop
     forward_aten = forward_pytorch
+    matmul_compile = matmul                      # (quantize.py:884-886: torch.compile of the same call)
+    dequantize_aten = dequantize                 # (quantize.py:899-976: the hqq_aten dequantise kernels; here one HIP kernel, both axes)
+    dequantize_aten_with_streams = dequantize
 
     def forward_aten_int8(self, x: Tensor) -> Tensor:
         raise NotImplementedError("hqq_amd: the experimental int8-activation path (quantize.py:1034-1073) is not covered")
