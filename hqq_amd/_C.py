@@ -43,6 +43,7 @@ SYMBOLS = {
                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hqq_hip_quantize_axis0": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
                                       _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hqq_hip_optimize": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

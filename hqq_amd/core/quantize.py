@@ -32,6 +32,9 @@ _META_TYPE = {
 }
 
 
+from .optimize import optimize_weights_proximal
+
+
 class Quantizer:
     """hqq/core/quantize.py:36-253.  quantize() runs the half-quadratic solver + bit-packing in one HIP call."""
     SUPPORTED_BITS = [8, 6, 5, 4, 3, 2, 1.58, 1]
@@ -42,6 +45,7 @@ class Quantizer:
               "2bit_u8": BitPack.unpack_2bit_u8, "1bit_u8": BitPack.unpack_1bit_u8}
     unpack_view_dtype = {"8bit_u8": uint8, "4bit_u8": uint8, "3bit_32": int32, "2bit_u8": uint8, "1bit_u8": uint8}
     _packing_bits = {"8bit_u8": 8, "4bit_u8": 4, "3bit_32": 3, "2bit_u8": 2, "1bit_u8": 1}
+    optimize_weights = optimize_weights_proximal   # (quantize.py:72; quantize() below runs the same solver fused with the initialisation and the packing)
 
     @classmethod
     def quantize(cls, tensor: Tensor, nbits: float = 4, channel_wise: bool = True, group_size: int = 64, optimize: bool = True,

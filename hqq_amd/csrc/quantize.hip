@@ -60,6 +60,8 @@ struct SolveParams {
   double pexp;        // (double)(float)(lp_norm - 1)
   int lp_is_one;
   float a_skip;       // |e| below this: the shrinkage is provably clamped to 0, no pow needed (0: always evaluate)
+  const float* scale_in;   // hqq_hip_optimize: start from the caller's scale / zero instead of the group's min / max (else nullptr)
+  const float* zero_in;
 };
 
 // shrink_lp_op (optimize.py:96-108): W_e = sign(e) max(|e| - (1/beta) |e|^(p-1), 0).  The double-precision pow was 84 % of the
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_kernel(const WT* __restri
   sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
+  if (p.scale_in) { sc = p.scale_in[live ? r : 0]; ze = p.zero_in[live ? r : 0]; }   // optimize_weights_proximal_legacy called on its own
   if (live && j == 0) { s_ws[r] = sc; zero_hist[r] = ze; }
 
   // ---- proximal iterations (optimize.py:237-247), all `iters` of them; the stop index is chosen later ----
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void solve_generic_kernel(const WT* 
   sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
+  if (p.scale_in) { sc = p.scale_in[live ? r : 0]; ze = p.zero_in[live ? r : 0]; }   // optimize_weights_proximal_legacy called on its own
   if (live && j == 0) { s_ws[r] = sc; zero_hist[r] = ze; }
   for (int it = 0; it < p.iters; ++it) {
     double eabs = 0.0;   // (up to 2^16 elements per lane: keep the per-lane partial of the layer-global error exact enough)
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256) void solve0_kernel(const WT* __restrict__ W, S
   sc = (sc > 2e4f) ? 2e4f : sc;   // clamp(max=2e4) keeps a NaN, as torch.clamp does
   float ze = (-mn) * sc;
   if (p.round_zero) ze = rintf(ze);
+  if (p.scale_in) { sc = p.scale_in[live ? j : 0]; ze = p.zero_in[live ? j : 0]; }
   if (live) { s_ws[j] = sc; zero_hist[j] = ze; }
   const int size4 = (gs / 4) * 4;
   for (int it = 0; it < p.iters; ++it) {
@@ -555,7 +560,7 @@ static int dispatch_finalize(int pack_bits, const void* W, const float* s_ws, co
 template <typename WT>
 static int run_quantize(const void* W, int64_t numel, int64_t gs, int max_v, int pack_bits, int round_zero, int iters,
                         float beta, float lp_norm, void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
-                        void* ws, hipStream_t st) {
+                        void* ws, hipStream_t st, const float* scale_in = nullptr, const float* zero_in = nullptr) {
   const WsLayout L = ws_layout(numel, gs, iters);
   char* base = static_cast<char*>(ws);
   float* s_ws = reinterpret_cast<float*>(base + L.s_off);
@@ -568,6 +573,7 @@ static int run_quantize(const void* W, int64_t numel, int64_t gs, int max_v, int
   p.inv_beta = static_cast<float>(1.0 / static_cast<double>(beta));
   p.pexp = static_cast<double>(static_cast<float>(static_cast<double>(lp_norm) - 1.0));
   p.lp_is_one = (lp_norm == 1.0f);
+  p.scale_in = scale_in; p.zero_in = zero_in;
   p.a_skip = (p.pexp < 0.0 && p.pexp > -1.0 && p.inv_beta > 0.f && true) ? static_cast<float>(0.9 * pow(static_cast<double>(p.inv_beta), 1.0 / (1.0 - p.pexp))) : 0.f;
   int rc = dispatch_solve<WT>(W, p, s_ws, zh, ep, L.nblocks, st);
   if (rc) return rc;
@@ -585,7 +591,7 @@ static int run_quantize(const void* W, int64_t numel, int64_t gs, int max_v, int
 template <typename WT>
 static int run_quantize_axis0(const void* W, int64_t numel, int64_t gs, int max_v, int pack_bits, int round_zero, int iters,
                               float beta, float lp_norm, void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
-                              void* ws, hipStream_t st) {
+                              void* ws, hipStream_t st, const float* scale_in = nullptr, const float* zero_in = nullptr) {
   const WsLayout L = ws_layout(numel, gs, iters);
   char* base = static_cast<char*>(ws);
   float* s_ws = reinterpret_cast<float*>(base + L.s_off);
@@ -598,6 +604,7 @@ static int run_quantize_axis0(const void* W, int64_t numel, int64_t gs, int max_
   p.inv_beta = static_cast<float>(1.0 / static_cast<double>(beta));
   p.pexp = static_cast<double>(static_cast<float>(static_cast<double>(lp_norm) - 1.0));
   p.lp_is_one = (lp_norm == 1.0f);
+  p.scale_in = scale_in; p.zero_in = zero_in;
   p.a_skip = (p.pexp < 0.0 && p.pexp > -1.0 && p.inv_beta > 0.f && true) ? static_cast<float>(0.9 * pow(static_cast<double>(p.inv_beta), 1.0 / (1.0 - p.pexp))) : 0.f;
   const int64_t nblocks = (C + 255) / 256;   // (<= the axis-1 block count the workspace was sized for)
   hipLaunchKernelGGL((solve0_kernel<WT>), dim3(static_cast<unsigned>(nblocks)), dim3(256), sizeof(double) * 256 * (iters > 0 ? iters : 1), st,
@@ -763,6 +770,33 @@ int hqq_hip_quantize_tensor(const void* W, int w_dtype, int64_t rows, int64_t co
     case HQQ_BF16: return run_quantize_tensor<bf16_t>(W, rows, cols, max_v, pack_bits, round_zero, Wq_out, scale_out, zero_out, workspace, st);
   }
   set_error("hqq_hip_quantize_tensor: bad w_dtype %d", w_dtype);
+  return HQQ_ERR_DTYPE;
+}
+
+int hqq_hip_optimize(const void* W, int w_dtype, int64_t numel, int64_t group_size, int axis, int max_v, const float* scale_in, const float* zero_in,
+                     int iters, float beta, float lp_norm, void* levels_out, float* zero_out, int32_t* info_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+  clear_stale_error();
+  if (numel <= 0 || group_size <= 0 || numel % group_size || (axis != 0 && axis != 1)) { set_error("hqq_hip_optimize: bad numel / group_size / axis"); return HQQ_ERR_SHAPE; }
+  if (!scale_in || !zero_in || !levels_out || !zero_out) { set_error("hqq_hip_optimize: null argument"); return HQQ_ERR_SHAPE; }
+  if (max_v < 1 || max_v > 255) { set_error("hqq_hip_optimize: max_v=%d out of range", max_v); return HQQ_ERR_SHAPE; }
+  if (iters < 0 || iters > MAX_ITERS) { set_error("hqq_hip_optimize: iters=%d outside [0,%d]", iters, MAX_ITERS); return HQQ_ERR_SHAPE; }
+  if (axis == 0 && (group_size >= 65536 || numel / group_size < 8)) { set_error("hqq_hip_optimize: axis 0 needs group_size < 2^16 and at least 8 groups"); return HQQ_ERR_UNSUPPORTED; }
+  const int64_t R = numel / group_size;
+  const size_t need = ws_layout(numel, group_size, iters).total + static_cast<size_t>(R) * sizeof(float);   // (+ a scratch row for the inverted scale the packing step writes)
+  if (!workspace || workspace_bytes < need) { set_error("hqq_hip_optimize: workspace %zu < %zu bytes (hqq_hip_quantize_workspace_bytes + 4 bytes per group)", workspace_bytes, need); return HQQ_ERR_WORKSPACE; }
+  if (!aligned16(W) || !aligned16(levels_out) || !aligned16(workspace)) { set_error("hqq_hip_optimize: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  float* inv_scale_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_layout(numel, group_size, iters).total);
+  hipStream_t st = as_stream(stream);
+#define HQQ_OPT_GO(T) (axis == 1 ? run_quantize<T>(W, numel, group_size, max_v, 8, 0, iters, beta, lp_norm, levels_out, inv_scale_scratch, zero_out, info_out, workspace, st, scale_in, zero_in) \
+                                 : run_quantize_axis0<T>(W, numel, group_size, max_v, 8, 0, iters, beta, lp_norm, levels_out, inv_scale_scratch, zero_out, info_out, workspace, st, scale_in, zero_in))
+  switch (w_dtype) {
+    case HQQ_F32: return HQQ_OPT_GO(float);
+    case HQQ_F16: return HQQ_OPT_GO(half_t);
+    case HQQ_BF16: return HQQ_OPT_GO(bf16_t);
+  }
+#undef HQQ_OPT_GO
+  set_error("hqq_hip_optimize: bad w_dtype %d", w_dtype);
   return HQQ_ERR_DTYPE;
 }
 

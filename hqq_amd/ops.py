@@ -412,6 +412,32 @@ def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False,
     return W_q, scale, zero
 
 
+def optimize(W: Tensor, scale: Tensor, zero: Tensor, max_v: int, axis: int = 1, iters: int = 20, beta: float = 10.0, lp_norm: float = 0.7):
+    """optimize_weights_proximal_legacy on its own (optimize.py:208-255): W is the grouped 2-D view ([groups, gs] for axis=1, [gs, groups] for
+    axis=0), scale / zero float32 with one value per group.  Returns (levels uint8 in W's shape, zero float32 in zero's shape)."""
+    _dev(W, scale, zero)
+    if W.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        W = W.float()
+    W = W.contiguous()
+    gs = W.shape[1] if axis == 1 else W.shape[0]
+    R = W.numel() // gs
+    sc, ze = scale.reshape(-1).float().contiguous(), zero.reshape(-1).float().contiguous()
+    if sc.numel() != R or ze.numel() != R:
+        raise ValueError(f"hqq_amd: scale / zero must hold one value per group ({R}), got {sc.numel()} / {ze.numel()}")
+    dev = W.device
+    levels = torch.empty(W.shape, dtype=torch.uint8, device=dev)
+    zero_out = torch.empty(zero.shape, dtype=torch.float32, device=dev)
+    info = torch.zeros((2,), dtype=torch.int32, device=dev)
+    L = _C.lib()
+    ws_bytes = int(L.hqq_hip_quantize_workspace_bytes(W.numel(), gs, int(iters))) + 4 * R
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.hqq_hip_optimize(_p(W), _dt(W.dtype), W.numel(), gs, int(axis), int(max_v), _p(sc), _p(ze), int(iters), float(beta), float(lp_norm),
+                                _p(levels), _p(zero_out), _p(info), _p(ws), ws_bytes, _stream())
+    _C.check(rc, "hqq_hip_optimize")
+    return levels, zero_out
+
+
 def quantize_tensorwise(W: Tensor, nbits=4, round_zero: bool = False):
     """Quantizer.quantize(channel_wise=False) (quantize.py:114-116): one scale / zero from the tensor's min and max, no solver; the
     levels packed in the tensor's own 2-D shape.  Returns (W_q packed [packed_rows(rows), cols], scale 0-d f32 (inverted), zero 0-d f32)."""

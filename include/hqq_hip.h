@@ -211,6 +211,16 @@ int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t gr
                            void* Wq_out, float* scale_out, float* zero_out, int32_t* info_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* optimize_weights_proximal_legacy called on its own (optimize.py:208-255; `Quantizer.optimize_weights`): the same solver, started from the
+ * CALLER's scale and zero instead of the group's min / max.  W viewed as [numel / group_size, group_size] (axis 1: a group per row) or
+ * [group_size, numel / group_size] (axis 0: a group per column); scale_in / zero_in one float32 per group (scale as the quantiser uses it,
+ * NOT inverted).  levels_out: the final W_q = clamp(rint(W * scale + zero), 0, max_v) as uint8 in W's view; zero_out: the solved zero per
+ * group (scale is returned unchanged by the reference).  workspace: hqq_hip_quantize_workspace_bytes(numel, group_size, iters) + 4 bytes
+ * per group. */
+int hqq_hip_optimize(const void* W, int w_dtype, int64_t numel, int64_t group_size, int axis, int max_v, const float* scale_in, const float* zero_in,
+                     int iters, float beta, float lp_norm, void* levels_out, float* zero_out, int32_t* info_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* channel_wise=False (quantize.py:114-116, 146): one scale and one zero for the WHOLE [rows, cols] tensor from its min and max, no
  * solver; the levels are packed in the tensor's own shape — Wq_out [packed_rows(rows), cols].  scale_out / zero_out: one float32 each
  * (scale already inverted, quantize.py:154).  cols % 8 == 0, rows * cols < 2^31.  workspace: HQQ_QUANTIZE_TENSOR_WS_BYTES. */

@@ -497,6 +497,34 @@ def test_solver_pow_skip_is_bit_identical(ops, oracle, nbits, std):
         assert np.array_equal(z2.cpu().numpy().view(np.uint32), o2["zero"].view(np.uint32))
 
 
+@pytest.mark.parametrize("name,axis", [("quant_4b_192x256", 1), ("quant_3b_64x2048_normal", 1), ("quant_2b_16x128_edge", 1), ("quant_4b_16x4096_gs512", 1),
+                                       ("quant_axis0_4b_128x256", 0), ("quant_axis0_2b_128x256", 0)])
+def test_optimize_weights_proximal_on_its_own(ops, name, axis):
+    """hqq_amd.core.optimize.optimize_weights_proximal_legacy (the reference's `Quantizer.optimize_weights`, optimize.py:208-255) called by
+    hand: scale / zero initialised as Quantizer.quantize does it (quantize.py:118-134, on the CPU: exact), the solver from those values on the
+    GPU — levels and zero-points equal the reference's bit for bit, the scale is returned untouched"""
+    from hqq_amd.core.optimize import optimize_weights_proximal, optimize_weights_proximal_legacy
+    from hqq_amd.core.quantize import Quantizer
+    assert optimize_weights_proximal is optimize_weights_proximal_legacy and Quantizer.optimize_weights is optimize_weights_proximal
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    W = torch.from_numpy(g["W"]).float()
+    Wg = W.reshape(-1, gs) if axis == 1 else W.reshape(gs, -1)
+    _min, _max = Wg.min(axis=axis, keepdim=True)[0], Wg.max(axis=axis, keepdim=True)[0]
+    max_v = round(2 ** nbits - 1)
+    denom = _max - _min
+    scale = max_v / denom
+    scale = torch.where(denom.abs() <= 1e-4, torch.full_like(scale, 1.0), scale).clamp(max=2e4)
+    zero = -_min * scale
+    if nbits == 4:
+        zero = torch.round(zero)
+    W_q, scale2, zero2 = optimize_weights_proximal_legacy(tensor=Wg.cuda(), scale=scale.cuda(), zero=zero.cuda(), min_max=[0, max_v], axis=axis)
+    assert W_q.dtype == torch.float32 and W_q.shape == Wg.shape
+    assert np.array_equal(W_q.cpu().numpy().astype(np.uint8), g["Wq_unpacked"][:Wg.shape[0]])
+    assert np.array_equal(zero2.cpu().numpy().view(np.uint32), g["zero_f32"].reshape(zero.shape).view(np.uint32))
+    assert torch.equal(scale2.cpu(), scale) and np.array_equal((1.0 / scale).numpy().view(np.uint32), g["scale_f32"].reshape(scale.shape).view(np.uint32))
+
+
 def test_hqqlinear_per_channel_group_size_none(ops, oracle):
     """group_size=None (one group per output row, quantize.py:434-439): the generic-group-size solver, bit-exact against the oracle,
     and a forward that agrees with dequantize() — whatever kernel or composition serves that group size"""
