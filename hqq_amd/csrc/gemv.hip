@@ -14,10 +14,11 @@
 // Launch shape: a *group* of up to GV_MAXL layers that read the same activation rows (q/k/v, gate/up, or a single layer) is
 // one launch.  Their packed rows form one concatenated row space that a persistent grid (<= 4 workgroups of 4 waves per CU)
 // strides over; one wave owns one packed row (-> `per` output rows) at a time and walks it in 2 KiB units
-// (2 x global_load_dwordx4 per lane, non-temporal, 1 KiB per wave instruction).  The loads of unit i+1 are issued before unit i
-// is consumed (two register sets, no copies), every issue() emits the same number of loads so that the compiler's waits are
-// exact `s_waitcnt vmcnt(n)`, the very first unit is requested before x is staged, and the last unit of a wave has its own code
-// path with nothing issued behind it.  Few-row / long-K layers switch to K-split: the workgroup's waves share one row.
+// (2 x buffer_load_dwordx4 per lane, non-temporal, 1 KiB per wave instruction; descriptor + scalar row offset + one 32-bit lane
+// offset).  The loads of unit i+1 are issued before unit i is consumed (two register sets, no copies), every issue() emits the same
+// number of loads and the streaming loop has one shape and one exit, so that the compiler's waits are exact `s_waitcnt vmcnt(n)` and
+// none sits in front of a request; the very first unit is requested before x is staged.  Few-row / long-K layers switch to K-split:
+// the workgroup's waves share one row.
 //   x       staged once per workgroup in LDS, in the order the nibble extraction produces values
 //   meta    per unit the (zero, scale) of the <= 64 groups it spans are fetched with one coalesced 2-byte load per lane and slab
 //           and handed to the consuming lanes with ds_bpermute (group_size 64; other group sizes fetch per lane)
@@ -81,31 +82,97 @@ struct GvArgs {
 #endif
 };
 
+// What the kernel receives: two argument structs.  GvIn — everything the streaming loop reads — is fetched by one batch of scalar
+// loads at the top and lives in SGPRs; GvOut — where a finished row goes — is read with an indexed scalar load when a row ends
+// (once per row, scalar cache) instead of occupying 16 more SGPRs for the whole kernel (with them the loop spilled SGPRs into VGPR
+// lanes: ~25 v_readlane per row).  Two structs because one indexed access makes the compiler treat the whole struct as memory and
+// stage its loads behind each other.
+struct GvIn {
+  const uint8_t* Wq[GV_MAXL];
+  const half_t* scale[GV_MAXL];
+  const half_t* zero[GV_MAXL];
+  int N[GV_MAXL];
+  int prow_end[GV_MAXL];
+  const half_t* x;
+  int K, gs, G, total_prow, red_off, ksplit;
+#ifdef GV_LAB_TS
+  unsigned long long* ts;
+#endif
+};
+struct GvOut {
+  const half_t* bias[GV_MAXL];
+  half_t* y[GV_MAXL];
+};
+static_assert(GV_MAXL == 4, "the scalar parameter list below spells four layers out");
+#ifdef GV_LAB_TS
+#define GV_IN_TS_PARAM , unsigned long long* ts_
+#define GV_IN_TS_PACK , ts_
+#define GV_IN_TS_ARG(in) , (in).ts
+#else
+#define GV_IN_TS_PARAM
+#define GV_IN_TS_PACK
+#define GV_IN_TS_ARG(in)
+#endif
+#define GV_IN_PARAMS                                                                                                                       \
+  const uint8_t *Wq0, const uint8_t *Wq1, const uint8_t *Wq2, const uint8_t *Wq3, const half_t *sc0, const half_t *sc1, const half_t *sc2, \
+      const half_t *sc3, const half_t *ze0, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N0, int N1, int N2, int N3,       \
+      int pe0, int pe1, int pe2, int pe3, const half_t *x_, int K_, int gs_, int G_, int total_, int red_off_, int ksplit_ GV_IN_TS_PARAM
+#define GV_IN_PACK \
+  GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ GV_IN_TS_PACK }
+#define GV_IN_ARGS(in)                                                                                                                       \
+  (in).Wq[0], (in).Wq[1], (in).Wq[2], (in).Wq[3], (in).scale[0], (in).scale[1], (in).scale[2], (in).scale[3], (in).zero[0], (in).zero[1],    \
+      (in).zero[2], (in).zero[3], (in).N[0], (in).N[1], (in).N[2], (in).N[3], (in).prow_end[0], (in).prow_end[1], (in).prow_end[2],           \
+      (in).prow_end[3], (in).x, (in).K, (in).gs, (in).G, (in).total_prow, (in).red_off, (in).ksplit GV_IN_TS_ARG(in)
+
 // the layer a wave is currently streaming (all wave-uniform -> SGPRs)
 struct LayerCtx {
   const uint8_t* Wq;
   const half_t* scale;
   const half_t* zero;
-  const half_t* bias;
-  half_t* y;
   int N, row0, end;
 };
 
-__device__ __forceinline__ LayerCtx select_layer(const GvArgs& a, int prow) {
-  LayerCtx c{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], 0, a.prow_end[0]};
+// select between VALUES (arguments by value).  `c ? x : y` on two lvalues is itself an lvalue: the compiler selects the ADDRESS and
+// loads through it — a dependent scalar load (kernel-argument struct) or a scratch access (local struct) per select.
+template <class T>
+__device__ __forceinline__ T pick(bool c, T x, T y) { return c ? x : y; }
+
+__device__ __forceinline__ LayerCtx select_layer(const GvIn& a, int prow) {
+  LayerCtx c{a.Wq[0], a.scale[0], a.zero[0], a.N[0], 0, a.prow_end[0]};
 #pragma unroll
   for (int i = 1; i < GV_MAXL; ++i) {
     const bool in = prow >= a.prow_end[i - 1];   // entries past the last layer repeat it: never true for prow < total
-    c.Wq = in ? a.Wq[i] : c.Wq;
-    c.scale = in ? a.scale[i] : c.scale;
-    c.zero = in ? a.zero[i] : c.zero;
-    c.bias = in ? a.bias[i] : c.bias;
-    c.y = in ? a.y[i] : c.y;
-    c.N = in ? a.N[i] : c.N;
-    c.row0 = in ? a.prow_end[i - 1] : c.row0;
-    c.end = in ? a.prow_end[i] : c.end;
+    c.Wq = pick(in, a.Wq[i], c.Wq);
+    c.scale = pick(in, a.scale[i], c.scale);
+    c.zero = pick(in, a.zero[i], c.zero);
+    c.N = pick(in, a.N[i], c.N);
+    c.row0 = pick(in, a.prow_end[i - 1], c.row0);
+    c.end = pick(in, a.prow_end[i], c.end);
   }
   return c;
+}
+
+// what a finished row needs of its layer
+struct OutCtx {
+  const half_t* bias;
+  half_t* y;
+  int N, row0;
+};
+__device__ __forceinline__ OutCtx select_out(const GvIn& a, const GvOut& o, int prow) {
+  int li = 0, row0 = 0, N = a.N[0];
+#pragma unroll
+  for (int i = 1; i < GV_MAXL; ++i) {
+    const bool in = prow >= a.prow_end[i - 1];
+    li += in ? 1 : 0;
+    row0 = pick(in, a.prow_end[i - 1], row0);
+    N = pick(in, a.N[i], N);
+  }
+  return OutCtx{o.bias[li], o.y[li], N, row0};
+}
+
+// raw buffer descriptor over a whole allocation: base pointer, stride 0, no bound (offsets stay below 4 GiB per layer: checked on the host)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
 
 // one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
@@ -180,9 +247,9 @@ struct SlabExactBF16 {
 
 template <int NBITS, int S, int PER>
 struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the raw fp16 bit patterns
-  static __device__ __forceinline__ void run(const uint16_t* z, const uint16_t* sc, float (&c1)[PER], float (&c2)[PER]) {
-    const float zf = static_cast<float>(__builtin_bit_cast(half_t, z[S]));
-    const float sf = static_cast<float>(__builtin_bit_cast(half_t, sc[S]));
+  static __device__ __forceinline__ void run(const uint32_t* z, const uint32_t* sc, float (&c1)[PER], float (&c2)[PER]) {
+    const float zf = static_cast<float>(__builtin_bit_cast(half_t, static_cast<uint16_t>(z[S])));
+    const float sf = static_cast<float>(__builtin_bit_cast(half_t, static_cast<uint16_t>(sc[S])));
     c1[S] = sf * SlabF<NBITS, S>::invF;
     c2[S] = __builtin_fmaf(zf, SlabF<NBITS, S>::F, 1024.0f);
     if constexpr (S + 1 < PER) GroupConst<NBITS, S + 1, PER>::run(z, sc, c1, c2);
@@ -196,12 +263,22 @@ struct Unit {
   // raw 2-byte loads, combined only when consumed (combining at issue time would wait on the loads)
   // GS64: z[s], sc[s] = zero / scale of group (unit's first group + lane) of slab s
   // else: z[u * PER + s], sc[..] = those of the group the lane's own 16 k-values of load u fall into
-  uint16_t z[GS64 ? PER : GV_U * PER];
-  uint16_t sc[GS64 ? PER : GV_U * PER];
+  // (32-bit holders of the zero-extended 2-byte loads: a uint16_t carried round the loop gets masked — and so waited for — where the
+  // compiler places the phi, in front of the next unit's requests)
+  uint32_t z[GS64 ? PER : GV_U * PER];
+  uint32_t sc[GS64 ? PER : GV_U * PER];
 };
 
 template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false>
-__global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a) {
+__global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, const GvOut o) {
+  // (GvIn arrives as plain scalar parameters: values, not memory — passed as a struct the compiler turned selects of its loaded
+  //  pointers into loads of selected addresses and staged the loads behind each other: dependent scalar-load latencies in front of
+  //  the first weight request)
+  const GvIn a = GV_IN_PACK;
+  // all of them in ONE batch of scalar loads before anything else (the asm only needs them present: left alone the compiler fetched
+  // x and K first, requested x, and then fetched the rest — a second cold scalar-cache miss in front of the first weight request)
+  asm volatile("" ::"s"(Wq0), "s"(Wq1), "s"(Wq2), "s"(Wq3), "s"(sc0), "s"(sc1), "s"(sc2), "s"(sc3), "s"(ze0), "s"(ze1), "s"(ze2), "s"(ze3), "s"(N0), "s"(N1),
+               "s"(N2), "s"(N3), "s"(pe0), "s"(pe1), "s"(pe2), "s"(pe3), "s"(x_), "s"(K_), "s"(gs_), "s"(G_), "s"(total_), "s"(ksplit_), "s"(gridDim.x));
   static_assert(EXACT || !BF16, "bf16 is served by the exact-weights path only");
   static_assert(!SUB || (EXACT && !BF16), "the subnormal-field sequence is an fp16 exact-weights variant");
   constexpr int PER = 8 / NBITS;
@@ -209,9 +286,9 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
 
 #ifdef GV_LAB_TS
-  unsigned long long t_[8];
-  t_[0] = __builtin_readcyclecounter();
-#define GV_TS(i) t_[i] = __builtin_readcyclecounter();
+  unsigned long long t_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 100 MHz real-time counter: 10 ns ticks, comparable across CUs
+  t_[0] = __builtin_amdgcn_s_memrealtime();
+#define GV_TS(i) if (t_[i] == 0) t_[i] = __builtin_amdgcn_s_memrealtime();   // first occurrence
 #else
 #define GV_TS(i)
 #endif
@@ -228,59 +305,74 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
 
   // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
   // them: the wait for one unit is then an exact s_waitcnt vmcnt(<loads of the following unit>), never vmcnt(0).
-  // Past the end of the row space the loads are redirected to the first bytes of the wave's last row (cache hits).
+  // A dead unit (past the wave's last one) reads the first bytes of the wave's last row in every lane: one cache line.
+  // Buffer loads: wave-uniform descriptor (the layer's base pointer) + scalar row offset + one 32-bit lane offset — no 64-bit
+  // VALU address arithmetic (global loads with a per-lane group index cost ~12 VALU instructions per unit in 64-bit adds and
+  // multiplies, a tenth of this kernel's VALU work).  Offsets are bytes < 4 GiB per layer (checked on the host).
   auto issue = [&](Unit<PER, GS64>& un, const LayerCtx& c, int prow, int unit, bool live) {
     const int p = prow - c.row0;                               // packed row inside the layer
     const int rows_per_slab = c.N / PER;
-    const uint8_t* wrow = c.Wq + static_cast<int64_t>(p) * K;
+    const int Glive = live ? G : 0, Klive = live ? K : 0;      // scalar selects: a dead unit's lanes all fall back to offset 0
+    const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(c.Wq), rz = buffer_rsrc(c.zero), rs = buffer_rsrc(c.scale);
     // meta first: the consumer needs it before the first weight vector (loads return in issue order)
     if constexpr (GS64) {
       int g = unit * (GV_UNIT / 64) + lane;
-      g = (live && g < G) ? g : 0;
+      g = g < Glive ? g : 0;
 #pragma unroll
       for (int s = 0; s < PER; ++s) {
-        const int64_t r = static_cast<int64_t>(p + s * rows_per_slab) * G + g;
-        un.z[s] = __builtin_bit_cast(uint16_t, c.zero[r]);
-        un.sc[s] = __builtin_bit_cast(uint16_t, c.scale[r]);
+        const uint32_t row_off = static_cast<uint32_t>(p + s * rows_per_slab) * static_cast<uint32_t>(G) * 2u;   // wave-uniform
+        un.z[s] = __builtin_amdgcn_raw_buffer_load_b16(rz, g * 2, row_off, 0);
+        un.sc[s] = __builtin_amdgcn_raw_buffer_load_b16(rs, g * 2, row_off, 0);
       }
     } else {
 #pragma unroll
       for (int u = 0; u < GV_U; ++u) {
         int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
-        k0 = (live && k0 < K) ? k0 : 0;
-        const int g = k0 / gs;
+        k0 = k0 < Klive ? k0 : 0;
+        const int goff = (k0 / gs) * 2;
 #pragma unroll
         for (int s = 0; s < PER; ++s) {
-          const int64_t r = static_cast<int64_t>(p + s * rows_per_slab) * G + g;
-          un.z[u * PER + s] = __builtin_bit_cast(uint16_t, c.zero[r]);
-          un.sc[u * PER + s] = __builtin_bit_cast(uint16_t, c.scale[r]);
+          const uint32_t row_off = static_cast<uint32_t>(p + s * rows_per_slab) * static_cast<uint32_t>(G) * 2u;
+          un.z[u * PER + s] = __builtin_amdgcn_raw_buffer_load_b16(rz, goff, row_off, 0);
+          un.sc[u * PER + s] = __builtin_amdgcn_raw_buffer_load_b16(rs, goff, row_off, 0);
         }
       }
     }
+    const uint32_t wrow_off = static_cast<uint32_t>(p) * static_cast<uint32_t>(K);
 #pragma unroll
     for (int u = 0; u < GV_U; ++u) {
       // lanes past K (last step of a row) and whole steps past the row re-read the row start: their x is zero in LDS
       // (and its chunk sum), so they add exactly 0
       int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
-      k0 = (live && k0 < K) ? k0 : 0;
-      un.w[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + k0));
+      k0 = k0 < Klive ? k0 : 0;
+      un.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, k0, wrow_off, 2 /* nt: streamed once */);
     }
   };
 
-  // ---- prologue: the workgroup's first pass of x loads goes out first (their latency overlaps the kernarg-dependent row
-  //      set-up), then the first unit of this wave's first row, then x is written to LDS ----
+  // next unit of this wave: same row, or the wave's next row (re-selecting the layer when the row leaves it)
+  auto advance = [&](int& p, int& u, LayerCtx& c) {
+    u += ustep;
+    if (u >= nunits) {
+      u = ubase;
+      p += stride;
+      if (p >= c.end && p < total) c = select_layer(a, p);
+    }
+  };
+
+  // ---- prologue: the workgroup's first pass of x loads goes out first, then the first unit of this wave's first row, then x is
+  //      written to LDS.  (Measured and rejected, tools/gemv_lab.hip: the first unit in front of the x loads — loads return in
+  //      request order, the staging barrier then waits for the weights too: +5 % per launch; the first TWO units in front of the
+  //      staging — the second is requested 0.5 us earlier, but the burst only queues in the memory system, every wave's first unit
+  //      arrives later and so does the barrier: +5-8 %.) ----
   float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64], FACTORED only
   const int chunks_per_m = nsteps * 64;          // 16-k lane chunks per row of x, padded to whole steps
   // (m, j) = (row of x, 16-k chunk j = step * 64 + lane); no division on the way to the first loads
+  // buffer loads bounded by the row (K % 16 == 0): chunks past K come back as zeros from the hardware's range check — no branch
+  // and no zero-initialised registers on the way to the first requests
   auto load_chunk = [&](int m, int j, u32x4& v0, u32x4& v1) {
-    const int k = j * 16;
-    v0 = u32x4{0u, 0u, 0u, 0u};
-    v1 = u32x4{0u, 0u, 0u, 0u};
-    if (j < chunks_per_m && k < K) {   // K % 16 == 0
-      const u32x4* src = reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m) * K + k);
-      v0 = src[0];
-      v1 = src[1];
-    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.x + static_cast<int64_t>(m) * K), 0, K * 2, 0x00020000);
+    v0 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32, 0, 0);
+    v1 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32 + 16, 0, 0);
   };
   auto store_chunk = [&](int m, int j, const u32x4& v0, const u32x4& v1) {
     if (j >= chunks_per_m) return;
@@ -297,15 +389,19 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
       xsum_lds[m * chunks_per_m + j] = sum;
     }
   };
+  GV_TS(7)
   u32x4 xv0, xv1;
   load_chunk(0, tid, xv0, xv1);
+  __builtin_amdgcn_sched_barrier(0);   // x in front of the weights: loads return in request order, and the staging barrier waits for x only
 
   int prow = ksplit ? blockIdx.x : blockIdx.x * GV_WAVES + wave;
   int unit = ubase;
   // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
-  LayerCtx lc = select_layer(a, prow < total ? prow : total - 1);
+  const bool live0 = prow < total;
+  prow = live0 ? prow : total - 1;
+  LayerCtx lc = select_layer(a, prow);
   Unit<PER, GS64> ua, ub;
-  issue(ua, lc, prow < total ? prow : total - 1, unit, prow < total);
+  issue(ua, lc, prow, unit, live0);
   GV_TS(1)
 
   store_chunk(0, tid, xv0, xv1);
@@ -332,8 +428,8 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));   // opaque to the optimiser: stays in a VGPR
 
-  // `oc` is the layer context the unit was issued under (the issuing side may already have moved to the next layer)
-  auto consume = [&](const Unit<PER, GS64>& cur, const LayerCtx& oc, int prow, int unit) {
+  // (the issuing side may already have moved to the next layer: a finished row looks its layer up again)
+  auto consume = [&](const Unit<PER, GS64>& cur, int prow, int unit) {
     if constexpr (EXACT) {
 #pragma unroll
       for (int u = 0; u < GV_U; ++u) {
@@ -342,11 +438,11 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
 #pragma unroll
         for (int s = 0; s < PER; ++s) {
           if constexpr (GS64) {
-            uint32_t mine = static_cast<uint32_t>(cur.z[s]) | (static_cast<uint32_t>(cur.sc[s]) << 16);
+            uint32_t mine = cur.z[s] | (cur.sc[s] << 16);
             if constexpr (SUB) mine = scale_meta_sub<NBITS>(mine, s);
             zs[s] = __builtin_amdgcn_ds_bpermute((u * 16 + (lane >> 2)) << 2, mine);
           } else {
-            zs[s] = static_cast<uint32_t>(cur.z[u * PER + s]) | (static_cast<uint32_t>(cur.sc[u * PER + s]) << 16);
+            zs[s] = cur.z[u * PER + s] | (cur.sc[u * PER + s] << 16);
             if constexpr (SUB) zs[s] = scale_meta_sub<NBITS>(zs[s], s);
           }
         }
@@ -398,6 +494,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
     }
     // ---- row finished: one wave reduction per output row; lane (m * PER + s) writes its value ----
     if (unit + ustep >= nunits) {
+      const OutCtx oc = select_out(a, o, prow);
       const int p = prow - oc.row0;
       const int rows_per_slab = oc.N / PER;
       float mine = 0.f;
@@ -405,17 +502,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
       for (int m = 0; m < M; ++m)
 #pragma unroll
         for (int s = 0; s < PER; ++s) {
-          float part;
+          float v;
           if constexpr (EXACT) {
-            // D layout: lane (col j = lane & 15, rows 4 * (lane >> 4) + i); keep the diagonal element, if this lane has one
-            const int i = (lane & 15) - 4 * (lane >> 4);
-            part = i == 0 ? acc[m][s][0] : i == 1 ? acc[m][s][1] : i == 2 ? acc[m][s][2] : i == 3 ? acc[m][s][3] : 0.f;
+            v = diag_sum(acc[m][s]);   // D[i][i] only (decode_common.h)
             acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
           } else {
-            part = acc[m][s];
+            v = wave_sum(acc[m][s]);
             acc[m][s] = 0.f;
           }
-          const float v = wave_sum(part);
           mine = (lane == m * PER + s) ? v : mine;
         }
       if (ksplit) {   // the row's K range was shared by the workgroup's waves: add their partial sums (fixed order) in wave 0
@@ -447,42 +541,36 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(const GvArgs a)
     }
   };
 
-  // next unit of this wave: same row, or the wave's next row (re-selecting the layer when the row leaves it)
-  auto advance = [&](int& p, int& u, LayerCtx& c) {
-    u += ustep;
-    if (u >= nunits) {
-      u = ubase;
-      p += stride;
-      if (p >= c.end && p < total) c = select_layer(a, p);
-    }
-  };
-
-  // ---- ping-pong over the wave's units: request unit i+1, then consume unit i; no register copies.  The last unit of
-  //      a wave is consumed on its own code path with nothing issued behind it (its wait is then a plain vmcnt(0)). ----
-  LayerCtx la = lc;           // context unit A was issued under
-  if (prow < total) {
-    for (;;) {
+  // ---- ping-pong over the wave's units: request unit i+1, then consume unit i; no register copies.  Every iteration has the same
+  //      shape and the loop ONE exit, at the bottom: a unit past the wave's last one is still "requested" (one cache line, see
+  //      issue()) and simply not consumed.  So each consume has exactly one unit's loads behind it on every path: its wait is
+  //      s_waitcnt vmcnt(<that unit>), and nothing waits in front of a request.  (Until round 2 the last unit had its own path —
+  //      consume, then leave from the middle of the loop.  The structurised control flow ran that exit through the loop latch; at the
+  //      loop header the other register set then looked freshly requested on one incoming edge and the compiler drained vmcnt to 0
+  //      in front of every second request, and in front of the others it waited for the previous unit's meta loads to mask their
+  //      16-bit phis: about ONE unit in flight per wave instead of two.) ----
+  if (live0) {
+    bool more;
+    do {
       int p1 = prow, u1 = unit;
       advance(p1, u1, lc);
-      if (p1 >= total) { consume(ua, la, prow, unit); break; }
-      const LayerCtx lb = lc;   // context unit B is issued under
-      issue(ub, lb, p1, u1, true);
+      const bool live1 = p1 < total;
+      issue(ub, lc, live1 ? p1 : prow, u1, live1);
       GV_TS(4)
-      consume(ua, la, prow, unit);
+      consume(ua, prow, unit);
       GV_TS(5)
       int p2 = p1, u2 = u1;
       advance(p2, u2, lc);
-      if (p2 >= total) { consume(ub, lb, p1, u1); break; }
-      la = lc;
-      issue(ua, la, p2, u2, true);
-      consume(ub, lb, p1, u1);
+      more = p2 < total;   // (p1 >= total implies p2 >= total)
+      issue(ua, lc, more ? p2 : (live1 ? p1 : prow), u2, more);
+      if (live1) consume(ub, p1, u1);
       prow = p2;
       unit = u2;
-    }
+    } while (more);
   }
 #ifdef GV_LAB_TS
   GV_TS(6)
-  if (lane == 0 && a.ts) { const int wg = blockIdx.x * GV_WAVES + wave; for (int i = 0; i < 7; ++i) a.ts[wg * 8 + i] = t_[i]; }
+  if (lane == 0 && a.ts) { const int wg = blockIdx.x * GV_WAVES + wave; for (int i = 0; i < 8; ++i) a.ts[wg * 8 + i] = t_[i]; }
 #endif
 }
 
@@ -541,7 +629,17 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(GV_WAVES * 64), lds, st, a);
+  GvIn in;
+  GvOut out;
+  for (int i = 0; i < GV_MAXL; ++i) {
+    in.Wq[i] = a.Wq[i]; in.scale[i] = a.scale[i]; in.zero[i] = a.zero[i]; in.N[i] = a.N[i]; in.prow_end[i] = a.prow_end[i];
+    out.bias[i] = a.bias[i]; out.y[i] = a.y[i];
+  }
+  in.x = a.x; in.K = a.K; in.gs = a.gs; in.G = a.G; in.total_prow = a.total_prow; in.red_off = a.red_off; in.ksplit = a.ksplit;
+#ifdef GV_LAB_TS
+  in.ts = a.ts;
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(GV_WAVES * 64), lds, st, GV_IN_ARGS(in), out);
   return check_launch("hqq_hip_gemv");
 }
 
@@ -723,7 +821,8 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   int64_t total = 0;
   for (int i = 0; i < n_layers; ++i) {
     if (N[i] <= 0 || N[i] % per) { set_error("hqq_hip_gemv: needs N %% %d == 0 (got N=%lld)", per, (long long)N[i]); return N[i] <= 0 ? HQQ_ERR_SHAPE : HQQ_ERR_UNSUPPORTED; }
-    if (N[i] * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    // (the kernel addresses a layer with 32-bit byte offsets from its base pointers: packed weights and meta below 4 GiB per layer)
+    if (N[i] * (K / group_size) > INT32_MAX || (N[i] / per) * K > static_cast<int64_t>(UINT32_MAX)) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
     if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
     if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     total += N[i] / per;

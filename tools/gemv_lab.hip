@@ -4,6 +4,7 @@
 unsigned long long* g_lab_ts = nullptr;
 #include "../hqq_amd/csrc/gemv.hip"
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 struct LayerBuf { void *wq, *sc, *ze, *y; };
@@ -34,7 +35,7 @@ static double run_case(int nbits, int n_group, int N, int K, int M, int reps) {
     for (int p = 0; p < pool; ++p) {
       const void *wq[8], *sc[8], *ze[8]; void* y[8]; int64_t Ns[8];
       for (int i = 0; i < n_group; ++i) { auto& b = L[p * n_group + i]; wq[i] = b.wq; sc[i] = b.sc; ze[i] = b.ze; y[i] = b.y; Ns[i] = N; }
-      int rc = hqq_hip_gemv_grouped(nbits, n_group, x, wq, sc, ze, nullptr, y, Ns, M, K, gs, HQQ_F16, st);
+      int rc = hqq_hip_gemv_grouped(nbits, n_group, x, wq, sc, ze, nullptr, y, Ns, M, K, gs, HQQ_F16, getenv("LAB_EXACT4") ? 0u : HQQ_OPT_META_SCALABLE, nullptr, 0, st);
       if (rc) { printf("rc=%d %s\n", rc, hqq_hip_last_error()); exit(1); }
     }
   };
@@ -65,20 +66,27 @@ static double run_case(int nbits, int n_group, int N, int K, int M, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 3;
-  if (getenv("LAB_FACTORED")) hqq_hip_set_gemv_mode(HQQ_GEMV_FACTORED);
 #ifdef GV_LAB_TS
   {
+    // gemv_lab N K [layers in the group] [launches]: per-wave time stamps of the LAST of `launches` back-to-back launches
     const int nw = 1024 * 8;
     hipMalloc(&g_lab_ts, nw * 8 * 8); hipMemset(g_lab_ts, 0, nw * 8 * 8);
     setenv("LAB_EAGER", "1", 1);
-    run_case(4, 1, atoi(argv[1]), atoi(argv[2]), 1, 1);
+    setenv("LAB_POOL", argc > 4 ? argv[4] : "6", 1);
+    run_case(4, argc > 3 ? atoi(argv[3]) : 1, atoi(argv[1]), atoi(argv[2]), 1, 1);
     std::vector<unsigned long long> h(nw * 8);
     hipMemcpy(h.data(), g_lab_ts, nw * 64, hipMemcpyDeviceToHost);
-    unsigned long long t0 = ~0ull; for (int w = 0; w < nw; ++w) if (h[w * 8]) t0 = h[w * 8] < t0 ? h[w * 8] : t0;
-    printf("wave: start x-issued A-requested B-requested barrier A-consumed(last) end (cycles since the wave's start)\n");
-    for (int w = 0; w < nw; w += (w < 8 ? 1 : 397)) { if (!h[w * 8]) continue; printf("w%5d (+%6lld):", w, (long long)(h[w * 8] - t0)); for (int i = 0; i < 7; ++i) printf(" %7lld", h[w*8+i] ? (long long)(h[w * 8 + i] - h[w * 8]) : -1LL); printf("\n"); }
-    unsigned long long tmax = 0, smax = 0; for (int w = 0; w < nw; ++w) if (h[w * 8]) { if (h[w*8+6] > tmax) tmax = h[w*8+6]; if (h[w*8] > smax) smax = h[w*8]; }
-    printf("last wave start: +%lld cycles, last end: +%lld cycles\n", (long long)(smax - t0), (long long)(tmax - t0));
+    unsigned long long t0 = ~0ull; int live = 0;
+    for (int w = 0; w < nw; ++w) if (h[w * 8]) { t0 = h[w * 8] < t0 ? h[w * 8] : t0; ++live; }
+    const char* names[8] = {"wave start", "unit A requested", "x staged (stores issued)", "barrier passed", "unit B requested", "unit A consumed", "wave end", "arguments there"};
+    printf("%d waves; us since the first wave's start: min / median / p90 / max\n", live);
+    for (int i : {0, 7, 1, 2, 3, 4, 5, 6}) {
+      std::vector<double> v;
+      for (int w = 0; w < nw; ++w) if (h[w * 8] && h[w * 8 + i]) v.push_back((h[w * 8 + i] - t0) * 0.01);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      printf("  %-26s %6.2f %6.2f %6.2f %6.2f   (%zu waves)\n", names[i], v.front(), v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+    }
     return 0;
   }
 #endif
