@@ -25,24 +25,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-// Sum of the diagonal of a 16x16 MFMA accumulator tile, the same value in every lane.  D[i][j] sits in lane j + 16 (i / 4), register
-// i % 4, so the diagonal is register i of lane 20 r + i (r = 0..3): three DPP adds fold a quad's (reg0, reg1, reg2, reg3) of lanes
-// (0, 1, 2, 3) into its lane 0 — no per-lane selects —, the four quads that hold diagonal elements are read out and added.
-// Association: ((d0 + d1) + (d2 + d3)) per quad, (q0 + q1) + (q2 + q3) across — the order wave_sum() gives the masked tile.
-__device__ __forceinline__ float diag_sum(const f32x4& t) {
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
-  };
-  const float a = t[0] + dpp(t[1], std::integral_constant<int, 0x55>{});   // quad_perm [1,1,1,1]: lane 0 of the quad: reg0 + lane 1's reg1
-  const float b = t[2] + dpp(t[3], std::integral_constant<int, 0xFF>{});   // quad_perm [3,3,3,3]: lane 2: reg2 + lane 3's reg3
-  const float w = a + dpp(b, std::integral_constant<int, 0xAA>{});         // quad_perm [2,2,2,2]: lane 0: a + lane 2's b
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 20));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 40));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 60));
-  return (r0 + r1) + (r2 + r3);
-}
-
 __device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 
 // biased levels of slab S for the byte pairs (b0,b2) [word] / (b1,b3) [word >> 8] of one packed dword: the fp16 pair

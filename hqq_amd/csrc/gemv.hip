@@ -132,11 +132,6 @@ struct LayerCtx {
   int N, row0, end;
 };
 
-// select between VALUES (arguments by value).  `c ? x : y` on two lvalues is itself an lvalue: the compiler selects the ADDRESS and
-// loads through it — a dependent scalar load (kernel-argument struct) or a scratch access (local struct) per select.
-template <class T>
-__device__ __forceinline__ T pick(bool c, T x, T y) { return c ? x : y; }
-
 __device__ __forceinline__ LayerCtx select_layer(const GvIn& a, int prow) {
   LayerCtx c{a.Wq[0], a.scale[0], a.zero[0], a.N[0], 0, a.prow_end[0]};
 #pragma unroll
@@ -170,10 +165,6 @@ __device__ __forceinline__ OutCtx select_out(const GvIn& a, const GvOut& o, int 
   return OutCtx{o.bias[li], o.y[li], N, row0};
 }
 
-// raw buffer descriptor over a whole allocation: base pointer, stride 0, no bound (offsets stay below 4 GiB per layer: checked on the host)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
-}
 
 // one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
 template <int NBITS, int M, int S, int PER>

@@ -64,16 +64,16 @@ __device__ __forceinline__ G3Layer g3_select(const G3Args& a, int e) {
 #pragma unroll
   for (int i = 1; i < G3_MAXL; ++i) {
     const bool in = e >= a.e_end[i - 1];
-    c.Wq = in ? a.Wq[i] : c.Wq;
-    c.scale = in ? a.scale[i] : c.scale;
-    c.zero = in ? a.zero[i] : c.zero;
-    c.bias = in ? a.bias[i] : c.bias;
-    c.y = in ? a.y[i] : c.y;
-    c.N = in ? a.N[i] : c.N;
-    c.step = in ? a.step[i] : c.step;
-    c.e0 = in ? a.e_end[i - 1] : c.e0;
-    c.end = in ? a.e_end[i] : c.end;
-    c.li = in ? i : c.li;
+    c.Wq = pick(in, a.Wq[i], c.Wq);   // selects of VALUES (hqq_common.h): `in ? a.f[i] : c.f` selects the address and loads through it
+    c.scale = pick(in, a.scale[i], c.scale);
+    c.zero = pick(in, a.zero[i], c.zero);
+    c.bias = pick(in, a.bias[i], c.bias);
+    c.y = pick(in, a.y[i], c.y);
+    c.N = pick(in, a.N[i], c.N);
+    c.step = pick(in, a.step[i], c.step);
+    c.e0 = pick(in, a.e_end[i - 1], c.e0);
+    c.end = pick(in, a.e_end[i], c.end);
+    c.li = pick(in, i, c.li);
   }
   return c;
 }
@@ -111,7 +111,8 @@ __device__ __forceinline__ float g3_wave_sum(float v) {
 struct G3Unit {
   u32x4 w[G3_U];          // words 4i..4i+3 of group (16*unit + 4u + j)
   uint32_t sh[G3_U];      // bit position 27 - 3*slab of that group
-  uint16_t z, sc;         // lanes 0..15: zero / scale of group 16*unit + lane (raw fp16 bits)
+  uint32_t z, sc;         // lanes 0..15: zero / scale of group 16*unit + lane (raw fp16 bits, zero-extended: a uint16_t carried round
+                          // the loop is masked — and waited for — in front of the next unit's requests)
 };
 
 template <int M>
@@ -132,8 +133,16 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   int* start_tab = reinterpret_cast<int*>(smem + static_cast<size_t>(M) * kpad * 2);
   if (tid < G3_MAXL * 11) {
     const int l = tid / 11, t = tid - 11 * l;
-    const int st = (t * a.step[l] + G - 1) / G;          // (zero-padded rows at the end of the last slabs: clamp to N)
-    start_tab[l * 12 + t] = (t == 10 || st > a.N[l]) ? a.N[l] : st;
+    // (the layer's fields by selects over scalar loads: indexing the argument arrays with a per-lane l made two dependent VECTOR
+    //  loads from the kernel-argument segment — two memory round trips in front of everything else in the kernel)
+    int step_l = a.step[0], N_l = a.N[0];
+#pragma unroll
+    for (int i = 1; i < G3_MAXL; ++i) {
+      step_l = pick(l == i, a.step[i], step_l);
+      N_l = pick(l == i, a.N[i], N_l);
+    }
+    const int st = (t * step_l + G - 1) / G;             // (zero-padded rows at the end of the last slabs: clamp to N)
+    start_tab[l * 12 + t] = (t == 10 || st > N_l) ? N_l : st;
   }
   // ---- stage x (natural k order) ----
   for (int v = tid; v < M * (kpad >> 3); v += G3_WAVES * 64) {
@@ -144,7 +153,11 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   }
 
   // r0 = first group row of output row `row`; groups past G (last unit of a row) re-read group 0 and meet zero x
+  // (buffer loads: the layer's base pointer in a wave-uniform descriptor + one 32-bit byte offset per lane — no 64-bit VALU address
+  //  arithmetic and fewer address temporaries, which the register allocator otherwise parks in the previous unit's load destinations,
+  //  forcing a wait for that unit's data in front of the next requests)
   auto issue = [&](G3Unit& un, const G3Layer& ly, int row, int unit) {
+    const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(ly.Wq), rz = buffer_rsrc(ly.zero), rs = buffer_rsrc(ly.scale);
     int n = g3_row_of(row - ly.e0, xcd, start_tab + ly.li * 12);
     n = n < 0 ? 0 : n;                                 // an entry without a row: same loads on row 0, nothing stored
     const int r0 = n * G;
@@ -158,20 +171,22 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
       const int s = s0 + (r >= bound ? 1 : 0);         // a row spans at most two slabs (G <= step)
       const int p = r - s * ly.step;
       un.sh[u] = 27 - 3 * s;
-      un.w[u] = *reinterpret_cast<const u32x4*>(ly.Wq + static_cast<int64_t>(p) * 64 + li * 4);
+      un.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, p * 256 + li * 16, 0, 0);
     }
     int gm = unit * 16 + (lane & 15);
     gm = gm < G ? gm : 0;
-    un.z = __builtin_bit_cast(uint16_t, ly.zero[static_cast<int64_t>(r0) + gm]);
-    un.sc = __builtin_bit_cast(uint16_t, ly.scale[static_cast<int64_t>(r0) + gm]);
+    un.z = __builtin_amdgcn_raw_buffer_load_b16(rz, (r0 + gm) * 2, 0, 0);
+    un.sc = __builtin_amdgcn_raw_buffer_load_b16(rs, (r0 + gm) * 2, 0, 0);
   };
 
   int row = (blockIdx.x >> 3) * G3_WAVES + wave;         // entry index in this XCD's stream (not an output row)
   int unit = 0;
-  G3Layer ly = g3_select(a, row < total ? row : total - 1);
+  const bool live0 = row < total;
+  row = live0 ? row : total - 1;                         // waves without an entry request the last one (uniform load counts) and leave
+  G3Layer ly = g3_select(a, row);
   G3Unit ua, ub;
   __syncthreads();                                       // x and the start tables are in LDS
-  if (row < total) issue(ua, ly, row, 0);
+  issue(ua, ly, row, 0);
 
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
@@ -195,8 +210,8 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
     }
   };
 
-  auto consume = [&](const G3Unit& cur, const G3Layer& oly, int orow, int unit) {
-    const uint32_t mine = static_cast<uint32_t>(cur.z) | (static_cast<uint32_t>(cur.sc) << 16);
+  auto consume = [&](const G3Unit& cur, int orow, int unit) {
+    const uint32_t mine = cur.z | (cur.sc << 16);
 #pragma unroll
     for (int u = 0; u < G3_U; u += 2) {
       // loads u and u+1 -> one MFMA: this lane's k-octet = 4 values of group (4u+j) and 4 of group (4u+4+j)
@@ -215,15 +230,14 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
         acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[m], 0, 0, 0);
       }
     }
-    if (unit == nunits - 1) {   // row finished
+    if (unit == nunits - 1) {   // row finished (its layer is looked up again: the issuing side may have moved on)
+      const G3Layer oly = g3_select(a, orow);
       const int n = g3_row_of(orow - oly.e0, xcd, start_tab + oly.li * 12);
       float mine_out = 0.f;
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        const int i = (lane & 15) - 4 * (lane >> 4);
-        const float part = i == 0 ? acc[m][0] : i == 1 ? acc[m][1] : i == 2 ? acc[m][2] : i == 3 ? acc[m][3] : 0.f;
+        const float v = diag_sum(acc[m]);   // hqq_common.h: same association as the masked wave sum it replaces
         acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float v = g3_wave_sum(part);
         mine_out = lane == m ? v : mine_out;
       }
       if (lane < M && n >= 0) {
@@ -242,24 +256,24 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
     }
   };
 
-  G3Layer la = ly;
-  if (row < total) {
-    for (;;) {
+  // one loop shape, ONE exit at the bottom: a unit past the wave's last is still requested (the last entry again) and not consumed,
+  // so every consume has exactly one unit's loads behind it and nothing waits in front of a request (gemv.hip has the story)
+  if (live0) {
+    bool more;
+    do {
       int r1 = row, u1 = unit;
       advance(r1, u1, ly);
-      if (r1 >= total) { consume(ua, la, row, unit); break; }
-      const G3Layer lb = ly;
-      issue(ub, lb, r1, u1);
-      consume(ua, la, row, unit);
+      const bool live1 = r1 < total;
+      issue(ub, ly, live1 ? r1 : row, live1 ? u1 : unit);
+      consume(ua, row, unit);
       int r2 = r1, u2 = u1;
       advance(r2, u2, ly);
-      if (r2 >= total) { consume(ub, lb, r1, u1); break; }
-      la = ly;
-      issue(ua, la, r2, u2);
-      consume(ub, lb, r1, u1);
+      more = r2 < total;   // (r1 >= total implies r2 >= total)
+      issue(ua, ly, more ? r2 : (live1 ? r1 : row), more ? u2 : unit);
+      if (live1) consume(ub, r1, u1);
       row = r2;
       unit = u2;
-    }
+    } while (more);
   }
 }
 

@@ -43,7 +43,9 @@ struct S3Args {
   int N[S3_MAXL];
   int step[S3_MAXL];        // ceil(N * G / 10)
   int task_end[S3_MAXL];    // end (exclusive) of layer i's tasks in the concatenated task space
-  int tmod[S3_MAXL][10];    // (t * step) mod G: where in its output row slab t's packed row 0 starts
+  int smod[S3_MAXL];        // step mod G: slab t's packed row 0 starts at group (t * step) mod G of its output row — built up slab by
+                            // slab with one add and one wrap in SGPRs (a table [layer][slab] indexed by the run-time layer cost one
+                            // dependent scalar load per slab and task)
   const half_t* x;
   float* part;              // [task][10][2][M]
   int K, G, total_tasks, n_layers;
@@ -53,21 +55,21 @@ struct S3Layer {   // wave-uniform
   const int32_t* Wq;
   const half_t* scale;
   const half_t* zero;
-  int N, step, task0, li;
+  int N, step, task0, smod;
 };
 
 __device__ __forceinline__ S3Layer s3_select(const S3Args& a, int task) {
-  S3Layer c{a.Wq[0], a.scale[0], a.zero[0], a.N[0], a.step[0], 0, 0};
+  S3Layer c{a.Wq[0], a.scale[0], a.zero[0], a.N[0], a.step[0], 0, a.smod[0]};
 #pragma unroll
   for (int i = 1; i < S3_MAXL; ++i) {
     const bool in = task >= a.task_end[i - 1];
-    c.Wq = in ? a.Wq[i] : c.Wq;
-    c.scale = in ? a.scale[i] : c.scale;
-    c.zero = in ? a.zero[i] : c.zero;
-    c.N = in ? a.N[i] : c.N;
-    c.step = in ? a.step[i] : c.step;
-    c.task0 = in ? a.task_end[i - 1] : c.task0;
-    c.li = in ? i : c.li;
+    c.Wq = pick(in, a.Wq[i], c.Wq);   // selects of VALUES (hqq_common.h): `in ? a.f[i] : c.f` selects the address and loads through it
+    c.scale = pick(in, a.scale[i], c.scale);
+    c.zero = pick(in, a.zero[i], c.zero);
+    c.N = pick(in, a.N[i], c.N);
+    c.step = pick(in, a.step[i], c.step);
+    c.task0 = pick(in, a.task_end[i - 1], c.task0);
+    c.smod = pick(in, a.smod[i], c.smod);
   }
   return c;
 }
@@ -101,7 +103,8 @@ __device__ __forceinline__ constexpr uint32_t s3_sel(int cls) {
 
 struct S3Unit {
   u32x4 w[4];             // load i: words 4c .. 4c + 3 of packed row p0 + 4 i + o
-  uint16_t z[3], sc[3];   // load q: zero / scale of (slab 4 q + o, packed row p0 + c)
+  uint32_t z[3], sc[3];   // load q: zero / scale of (slab 4 q + o, packed row p0 + c); 32-bit holders of the zero-extended 2-byte loads
+                          // (a uint16_t carried round the loop is masked — and waited for — in front of the next task's requests)
 };
 
 template <int M, bool SUB>
@@ -116,14 +119,18 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   const int total = a.total_tasks;
   const int nwaves = gridDim.x * S3_WAVES;
 
+  // buffer loads: the layer's base pointer in a wave-uniform descriptor + one 32-bit byte offset per lane (no 64-bit VALU address
+  // arithmetic, fewer address temporaries: with global loads the register allocator reused the previous task's load destinations
+  // for them and the compiler had to wait for that task's data in front of the next task's requests)
   auto issue = [&](S3Unit& un, const S3Layer& ly, int task) {
     const int p0 = (task - ly.task0) * S3_ROWS;
     const int R = ly.N * G;
+    const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(ly.Wq), rz = buffer_rsrc(ly.zero), rs = buffer_rsrc(ly.scale);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int p = p0 + 4 * i + o;
       p = p < ly.step ? p : ly.step - 1;   // rows past the tensor (last task): re-read the last row, weighted by zero below
-      un.w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ly.Wq + static_cast<int64_t>(p) * 64 + c * 4));
+      un.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, p * 256 + c * 16, 0, 2 /* nt */);
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -131,15 +138,15 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
       const int r = p + t * ly.step;
       const bool ok = t < 10 && p < ly.step && r < R;
       const int idx = ok ? r : 0;
-      un.z[q] = __builtin_bit_cast(uint16_t, ly.zero[idx]);
-      un.sc[q] = __builtin_bit_cast(uint16_t, ly.scale[idx]);
+      un.z[q] = __builtin_amdgcn_raw_buffer_load_b16(rz, idx * 2, 0, 0);
+      un.sc[q] = __builtin_amdgcn_raw_buffer_load_b16(rs, idx * 2, 0, 0);
     }
   };
 
   int task = blockIdx.x * S3_WAVES + wave;
   S3Layer la = s3_select(a, task < total ? task : total - 1);
   S3Unit ua, ub;
-  if (task < total) issue(ua, la, task);
+  issue(ua, la, task < total ? task : total - 1);   // (waves without a task request the last one: uniform load counts; they leave after the barrier)
 
   // ---- x (first 16 groups repeated behind K) ----
   for (int v = tid; v < M * (KP >> 3); v += S3_WAVES * 64) {
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
     for (int q = 0; q < 3; ++q) {
       const int t = 4 * q + o, p = p0 + c;
       const bool ok = t < 10 && p < ly.step && p + t * ly.step < R;
-      zs[q] = ok ? (static_cast<uint32_t>(un.z[q]) | (static_cast<uint32_t>(un.sc[q]) << 16)) : 0u;
+      zs[q] = ok ? (un.z[q] | (un.sc[q] << 16)) : 0u;
       if constexpr (SUB) {   // three-op rebuild (decode_common.h): (z, s) -> (z 2^-J, s 2^J), J = 9 - e(slab); exact by hqq_hip_meta_check
         const int J = 9 - s3_field_e(t < 10 ? t : 0);
         const half2_t f = {__builtin_bit_cast(half_t, static_cast<uint16_t>((15 - J) << 10)), __builtin_bit_cast(half_t, static_cast<uint16_t>((15 + J) << 10))};   // (2^-J, 2^J)
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) pk[cls][i][h] = __builtin_amdgcn_perm(un.w[i][2 * h + 1], un.w[i][2 * h], s3_sel(cls));
     float* dst = a.part + static_cast<int64_t>(task) * (10 * 2 * M);
+    int tmod = 0;   // (T * step) mod G for the slab in hand
 
     auto slab = [&](auto tc) {
       constexpr int T = decltype(tc)::value;
@@ -190,8 +198,10 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
       constexpr float inv = 1.0f / static_cast<float>(1 << e);
       const half2_t k1 = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
       const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
-      int g0 = p0g + a.tmod[ly.li][T];   // group (inside its output row) of the task's first packed row in this slab
+      int g0 = p0g + tmod;   // group (inside its output row) of the task's first packed row in this slab
       g0 = g0 >= G ? g0 - G : g0;
+      tmod += ly.smod;       // slabs are visited in ascending order
+      tmod = tmod >= G ? tmod - G : tmod;
       const int bd = G - g0;             // first local row of the NEXT output row (>= 16: none in this task)
       const uint32_t xa = xlane + static_cast<uint32_t>(g0) * 128u;
       uint32_t mine[4];
@@ -264,20 +274,22 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   };
 
   // every issue() emits the same ten loads (past the end: the last task again, never consumed), so the waits the compiler
-  // derives are exact counts
-  for (;;) {
+  // derives are exact counts; one loop shape with ONE exit at the bottom (an exit from the middle runs through the loop latch
+  // once the control flow is structurised, and the compiler then drains vmcnt in front of the next request: gemv.hip)
+  bool more;
+  do {
     const int t1 = task + nwaves;
-    const S3Layer lb = s3_select(a, t1 < total ? t1 : total - 1);
-    issue(ub, lb, t1 < total ? t1 : total - 1);
+    const bool live1 = t1 < total;
+    const S3Layer lb = s3_select(a, live1 ? t1 : total - 1);
+    issue(ub, lb, live1 ? t1 : total - 1);
     consume(ua, la, task);
-    if (t1 >= total) break;
     const int t2 = t1 + nwaves;
-    la = s3_select(a, t2 < total ? t2 : total - 1);
-    issue(ua, la, t2 < total ? t2 : total - 1);
-    consume(ub, lb, t1);
-    if (t2 >= total) break;
+    more = t2 < total;
+    la = s3_select(a, more ? t2 : total - 1);
+    issue(ua, la, more ? t2 : total - 1);
+    if (live1) consume(ub, lb, t1);
     task = t2;
-  }
+  } while (more);
 }
 
 // y[m][n] = sum of row n's partials: ascending slab, ascending task — a fixed order.  A row has G / 16 + 1 contributions per slab
@@ -386,13 +398,13 @@ int gemv3s_run(int n_layers, const void* x, const void* const* Wq, const void* c
     tasks += (a.step[i] + S3_ROWS - 1) / S3_ROWS;
     if (tasks > INT32_MAX / 128) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
     a.task_end[i] = static_cast<int>(tasks);
-    for (int t = 0; t < 10; ++t) a.tmod[i][t] = static_cast<int>((static_cast<int64_t>(t) * a.step[i]) % G);
+    a.smod[i] = static_cast<int>(a.step[i] % G);
     max_n = N[i] > max_n ? N[i] : max_n;
   }
   for (int i = n_layers; i < S3_MAXL; ++i) {
     a.Wq[i] = a.Wq[n_layers - 1]; a.scale[i] = a.scale[n_layers - 1]; a.zero[i] = a.zero[n_layers - 1]; a.bias[i] = a.bias[n_layers - 1];
     a.y[i] = a.y[n_layers - 1]; a.N[i] = a.N[n_layers - 1]; a.step[i] = a.step[n_layers - 1]; a.task_end[i] = a.task_end[n_layers - 1];
-    for (int t = 0; t < 10; ++t) a.tmod[i][t] = a.tmod[n_layers - 1][t];
+    a.smod[i] = a.smod[n_layers - 1];
   }
   a.x = static_cast<const half_t*>(x);
   a.K = static_cast<int>(K);

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+
 #include "../../include/hqq_hip.h"
 
 namespace hqq {
@@ -30,6 +32,34 @@ static inline int per_of(int nbits) {
 }
 
 // ---- bf16 <-> f32, round-to-nearest-even (device) -------------------------------------------------
+// select between VALUES (arguments by value).  `c ? x : y` on two lvalues is itself an lvalue: the compiler selects the ADDRESS and
+// loads through it — a dependent scalar load (kernel-argument struct) or a scratch access (local struct) per select.
+template <class T>
+__device__ __forceinline__ T pick(bool c, T x, T y) { return c ? x : y; }
+
+// raw buffer descriptor over a whole allocation: base pointer, stride 0, no bound (offsets stay below 4 GiB per layer: checked on the host)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+
+// Sum of the diagonal of a 16x16 MFMA accumulator tile, the same value in every lane.  D[i][j] sits in lane j + 16 (i / 4), register
+// i % 4, so the diagonal is register i of lane 20 r + i (r = 0..3): three DPP adds fold a quad's (reg0, reg1, reg2, reg3) of lanes
+// (0, 1, 2, 3) into its lane 0 — no per-lane selects —, the four quads that hold diagonal elements are read out and added.
+// Association: ((d0 + d1) + (d2 + d3)) per quad, (q0 + q1) + (q2 + q3) across — the order wave_sum() gives the masked tile.
+__device__ __forceinline__ float diag_sum(const f32x4& t) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  const float a = t[0] + dpp(t[1], std::integral_constant<int, 0x55>{});   // quad_perm [1,1,1,1]: lane 0 of the quad: reg0 + lane 1's reg1
+  const float b = t[2] + dpp(t[3], std::integral_constant<int, 0xFF>{});   // quad_perm [3,3,3,3]: lane 2: reg2 + lane 3's reg3
+  const float w = a + dpp(b, std::integral_constant<int, 0xAA>{});         // quad_perm [2,2,2,2]: lane 0: a + lane 2's b
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 20));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 40));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), 60));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   uint32_t x = __float_as_uint(f);
