@@ -296,13 +296,14 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
 
   // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
   // them: the wait for one unit is then an exact s_waitcnt vmcnt(<loads of the following unit>), never vmcnt(0).
-  // A dead unit (past the wave's last one) reads the first bytes of the wave's last row in every lane: one cache line.
+  // A dead unit (past the wave's last one) reads the first bytes of the layer in every lane: one cache line, the same for every
+  // wave of the launch (it stays in L2).
   // Buffer loads: wave-uniform descriptor (the layer's base pointer) + scalar row offset + one 32-bit lane offset — no 64-bit
   // VALU address arithmetic (global loads with a per-lane group index cost ~12 VALU instructions per unit in 64-bit adds and
   // multiplies, a tenth of this kernel's VALU work).  Offsets are bytes < 4 GiB per layer (checked on the host).
   auto issue = [&](Unit<PER, GS64>& un, const LayerCtx& c, int prow, int unit, bool live) {
-    const int p = prow - c.row0;                               // packed row inside the layer
-    const int rows_per_slab = c.N / PER;
+    const int p = live ? prow - c.row0 : 0;                    // packed row inside the layer
+    const int rows_per_slab = live ? c.N / PER : 0;
     const int Glive = live ? G : 0, Klive = live ? K : 0;      // scalar selects: a dead unit's lanes all fall back to offset 0
     const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(c.Wq), rz = buffer_rsrc(c.zero), rs = buffer_rsrc(c.scale);
     // meta first: the consumer needs it before the first weight vector (loads return in issue order)

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   // (buffer loads: the layer's base pointer in a wave-uniform descriptor + one 32-bit byte offset per lane — no 64-bit VALU address
   //  arithmetic and fewer address temporaries, which the register allocator otherwise parks in the previous unit's load destinations,
   //  forcing a wait for that unit's data in front of the next requests)
-  auto issue = [&](G3Unit& un, const G3Layer& ly, int row, int unit) {
+  auto issue = [&](G3Unit& un, const G3Layer& ly, int row, int unit, bool live) {
     const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(ly.Wq), rz = buffer_rsrc(ly.zero), rs = buffer_rsrc(ly.scale);
     int n = g3_row_of(row - ly.e0, xcd, start_tab + ly.li * 12);
     n = n < 0 ? 0 : n;                                 // an entry without a row: same loads on row 0, nothing stored
@@ -171,12 +171,12 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
       const int s = s0 + (r >= bound ? 1 : 0);         // a row spans at most two slabs (G <= step)
       const int p = r - s * ly.step;
       un.sh[u] = 27 - 3 * s;
-      un.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, p * 256 + li * 16, 0, 0);
+      un.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, live ? p * 256 + li * 16 : 0, 0, 0);   // dead unit: one line, the same for every wave
     }
     int gm = unit * 16 + (lane & 15);
     gm = gm < G ? gm : 0;
-    un.z = __builtin_amdgcn_raw_buffer_load_b16(rz, (r0 + gm) * 2, 0, 0);
-    un.sc = __builtin_amdgcn_raw_buffer_load_b16(rs, (r0 + gm) * 2, 0, 0);
+    un.z = __builtin_amdgcn_raw_buffer_load_b16(rz, live ? (r0 + gm) * 2 : 0, 0, 0);
+    un.sc = __builtin_amdgcn_raw_buffer_load_b16(rs, live ? (r0 + gm) * 2 : 0, 0, 0);
   };
 
   int row = (blockIdx.x >> 3) * G3_WAVES + wave;         // entry index in this XCD's stream (not an output row)
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
   G3Layer ly = g3_select(a, row);
   G3Unit ua, ub;
   __syncthreads();                                       // x and the start tables are in LDS
-  issue(ua, ly, row, 0);
+  issue(ua, ly, row, 0, live0);
 
   uint32_t magic;
   asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
     }
   };
 
-  // one loop shape, ONE exit at the bottom: a unit past the wave's last is still requested (the last entry again) and not consumed,
+  // one loop shape, ONE exit at the bottom: a unit past the wave's last is still requested (one cache line) and not consumed,
   // so every consume has exactly one unit's loads behind it and nothing waits in front of a request (gemv.hip has the story)
   if (live0) {
     bool more;
@@ -264,12 +264,12 @@ __global__ __launch_bounds__(G3_WAVES * 64) void gemv3_f16_kernel(const G3Args a
       int r1 = row, u1 = unit;
       advance(r1, u1, ly);
       const bool live1 = r1 < total;
-      issue(ub, ly, live1 ? r1 : row, live1 ? u1 : unit);
+      issue(ub, ly, live1 ? r1 : row, live1 ? u1 : unit, live1);
       consume(ua, row, unit);
       int r2 = r1, u2 = u1;
       advance(r2, u2, ly);
       more = r2 < total;   // (r1 >= total implies r2 >= total)
-      issue(ua, ly, more ? r2 : (live1 ? r1 : row), more ? u2 : unit);
+      issue(ua, ly, more ? r2 : (live1 ? r1 : row), more ? u2 : unit, more);
       if (live1) consume(ub, r1, u1);
       row = r2;
       unit = u2;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   // buffer loads: the layer's base pointer in a wave-uniform descriptor + one 32-bit byte offset per lane (no 64-bit VALU address
   // arithmetic, fewer address temporaries: with global loads the register allocator reused the previous task's load destinations
   // for them and the compiler had to wait for that task's data in front of the next task's requests)
-  auto issue = [&](S3Unit& un, const S3Layer& ly, int task) {
+  auto issue = [&](S3Unit& un, const S3Layer& ly, int task, bool live) {
     const int p0 = (task - ly.task0) * S3_ROWS;
     const int R = ly.N * G;
     const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(ly.Wq), rz = buffer_rsrc(ly.zero), rs = buffer_rsrc(ly.scale);
@@ -130,14 +130,14 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
     for (int i = 0; i < 4; ++i) {
       int p = p0 + 4 * i + o;
       p = p < ly.step ? p : ly.step - 1;   // rows past the tensor (last task): re-read the last row, weighted by zero below
-      un.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, p * 256 + c * 16, 0, 2 /* nt */);
+      un.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, live ? p * 256 + c * 16 : 0, 0, 2 /* nt */);   // dead task: one line for every wave
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int t = 4 * q + o, p = p0 + c;
       const int r = p + t * ly.step;
       const bool ok = t < 10 && p < ly.step && r < R;
-      const int idx = ok ? r : 0;
+      const int idx = ok && live ? r : 0;
       un.z[q] = __builtin_amdgcn_raw_buffer_load_b16(rz, idx * 2, 0, 0);
       un.sc[q] = __builtin_amdgcn_raw_buffer_load_b16(rs, idx * 2, 0, 0);
     }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
   int task = blockIdx.x * S3_WAVES + wave;
   S3Layer la = s3_select(a, task < total ? task : total - 1);
   S3Unit ua, ub;
-  issue(ua, la, task < total ? task : total - 1);   // (waves without a task request the last one: uniform load counts; they leave after the barrier)
+  issue(ua, la, task < total ? task : total - 1, task < total);   // (waves without a task: uniform load counts; they leave after the barrier)
 
   // ---- x (first 16 groups repeated behind K) ----
   for (int v = tid; v < M * (KP >> 3); v += S3_WAVES * 64) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
     slab(std::integral_constant<int, 9>{});
   };
 
-  // every issue() emits the same ten loads (past the end: the last task again, never consumed), so the waits the compiler
+  // every issue() emits the same ten loads (past the end: one cache line, never consumed), so the waits the compiler
   // derives are exact counts; one loop shape with ONE exit at the bottom (an exit from the middle runs through the loop latch
   // once the control flow is structurised, and the compiler then drains vmcnt in front of the next request: gemv.hip)
   bool more;
@@ -281,12 +281,12 @@ __global__ __launch_bounds__(S3_WAVES * 64) void gemv3s_kernel(const S3Args a) {
     const int t1 = task + nwaves;
     const bool live1 = t1 < total;
     const S3Layer lb = s3_select(a, live1 ? t1 : total - 1);
-    issue(ub, lb, live1 ? t1 : total - 1);
+    issue(ub, lb, live1 ? t1 : total - 1, live1);
     consume(ua, la, task);
     const int t2 = t1 + nwaves;
     more = t2 < total;
     la = s3_select(a, more ? t2 : total - 1);
-    issue(ua, la, more ? t2 : total - 1);
+    issue(ua, la, more ? t2 : total - 1, more);
     if (live1) consume(ub, lb, t1);
     task = t2;
   } while (more);
