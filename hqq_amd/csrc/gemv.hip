@@ -82,11 +82,12 @@ struct GvArgs {
 #endif
 };
 
-// What the kernel receives: two argument structs.  GvIn — everything the streaming loop reads — is fetched by one batch of scalar
-// loads at the top and lives in SGPRs; GvOut — where a finished row goes — is read with an indexed scalar load when a row ends
-// (once per row, scalar cache) instead of occupying 16 more SGPRs for the whole kernel (with them the loop spilled SGPRs into VGPR
-// lanes: ~25 v_readlane per row).  Two structs because one indexed access makes the compiler treat the whole struct as memory and
-// stage its loads behind each other.
+// What the kernel receives.  GvIn — everything the streaming loop reads — travels as plain scalar kernel parameters (GV_IN_PARAMS
+// below; the struct is rebuilt from them inside the kernel), is fetched by one batch of scalar loads at the top and lives in SGPRs.
+// GvOut — where a finished row goes — stays a struct and is read with an indexed scalar load when a row ends (once per row, scalar
+// cache) instead of occupying 16 more SGPRs for the whole kernel (with them the loop spilled SGPRs into VGPR lanes: ~25 v_readlane
+// per row).  Kept apart because one indexed access makes the compiler treat a whole argument struct as memory and stage its loads
+// behind each other.
 struct GvIn {
   const uint8_t* Wq[GV_MAXL];
   const half_t* scale[GV_MAXL];
