@@ -171,6 +171,53 @@ class _MatmulNoCache(torch.autograd.Function):
         return grad_input, None, grad_bias
 
 
+# the reference's public names for the autograd functions of the path (quantize.py:289-385; used by HQQLinear itself and by
+# code written against it, e.g. the PEFT wrappers).  Compute stays in the HIP kernels behind `dequantize` / `matmul`.
+HQQMatmulNoCacheMul = _MatmulNoCache
+
+
+class HQQMatmulNoCacheDeq(torch.autograd.Function):
+    """y = x @ dequantize().t() (+ bias), the weight re-dequantised in backward instead of cached (quantize.py:289-319)"""
+    @staticmethod
+    def forward(x, dequantize, bias):
+        out = torch.matmul(x, dequantize().t())
+        if bias is not None:
+            out += bias
+        return out
+
+    @staticmethod
+    def setup_context(ctx, inputs, outputs):
+        x, dequantize, bias = inputs
+        ctx.save_for_backward(x, bias)
+        ctx.dequantize = dequantize
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, bias = ctx.saved_tensors
+        grad_input = torch.matmul(grad_output, ctx.dequantize()) if ctx.needs_input_grad[0] else None
+        grad_bias = grad_output.reshape(-1, grad_output.shape[-1]).sum(0) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return grad_input, None, grad_bias
+
+
+class HQQMatmulCachedDeq(torch.autograd.Function):
+    """same product with the dequantised weight kept for backward: faster, one fp16 copy of W more (quantize.py:356-385)"""
+    @staticmethod
+    def forward(ctx, x, hqq_layer, bias):
+        weight_tmp = hqq_layer.dequantize()
+        out = torch.matmul(x, weight_tmp.t())
+        if bias is not None:
+            out += bias
+        ctx.save_for_backward(x, bias, weight_tmp)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, bias, weight_tmp = ctx.saved_tensors
+        grad_input = torch.matmul(grad_output, weight_tmp) if ctx.needs_input_grad[0] else None
+        grad_bias = grad_output.reshape(-1, grad_output.shape[-1]).sum(0) if (bias is not None and ctx.needs_input_grad[2]) else None
+        return grad_input, None, grad_bias
+
+
 class HQQLinear(nn.Module):
     backend = HQQBackend.HIP   # class-wide default (the reference's is PYTORCH, quantize.py:389)
 

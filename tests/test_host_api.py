@@ -140,3 +140,11 @@ def test_decode_coverage_predicates_mirror_the_header():
     assert not ops.skinny_covers(f16, 32, 4096, 4096 + 64, 64, 4) and not ops.skinny_covers(f16, 32, 4096, 256, 64, 4)
     assert not ops.skinny_covers(f16, 32, 4096, 4096, 128, 4) and not ops.skinny_covers(f16, 32, 4096, 4096, 64, 3)
     assert not ops.skinny_covers(f16, 32, 4095, 4096, 64, 4)      # N must be a multiple of the values per byte
+
+
+def test_autograd_function_names_of_the_reference_exist():
+    """quantize.py:289-385: the three autograd functions are public names other code imports"""
+    import torch
+    from hqq_amd.core import quantize as q
+    for name in ("HQQMatmulNoCacheDeq", "HQQMatmulNoCacheMul", "HQQMatmulCachedDeq"):
+        assert issubclass(getattr(q, name), torch.autograd.Function)

@@ -92,6 +92,26 @@ def test_state_dict_round_trip_and_float_view(ops):
     assert torch.equal(c(x), a(x)) and torch.equal(c.dequantize(), a.dequantize())
 
 
+def test_reference_autograd_function_names(ops):
+    """HQQMatmulNoCacheMul / HQQMatmulNoCacheDeq / HQQMatmulCachedDeq (quantize.py:289-385): same outputs and input gradients as
+    x @ dequantize().t() + bias differentiated by torch, 2-D and 3-D inputs"""
+    from hqq_amd.core.quantize import HQQMatmulCachedDeq, HQQMatmulNoCacheDeq, HQQMatmulNoCacheMul
+    lin = torch.nn.Linear(512, 256, bias=True)
+    layer = HQQLinear(lin, BaseQuantizeConfig(nbits=4, group_size=64), compute_dtype=torch.float16, device="cuda")
+    W = layer.dequantize()
+    for shape in ((5, 512), (2, 3, 512)):
+        x0 = torch.randn(*shape, device="cuda", dtype=torch.float16)
+        xr = x0.clone().requires_grad_(True)
+        yr = torch.matmul(xr, W.t()) + layer.bias
+        yr.float().square().sum().backward()
+        for fn, arg in ((HQQMatmulNoCacheMul, layer.matmul), (HQQMatmulNoCacheDeq, layer.dequantize), (HQQMatmulCachedDeq, layer)):
+            x = x0.clone().requires_grad_(True)
+            y = fn.apply(x, arg, layer.bias)
+            y.float().square().sum().backward()
+            assert y.shape == yr.shape and torch.allclose(y.float(), yr.float(), rtol=2e-3, atol=2e-3), fn.__name__
+            assert torch.allclose(x.grad.float(), xr.grad.float(), rtol=1e-2, atol=1e-2), fn.__name__
+
+
 def test_backward_wrt_input_redequantises(ops):
     lin = _cfg1_linear()
     layer = HQQLinear(lin, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
