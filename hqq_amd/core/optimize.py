@@ -31,5 +31,23 @@ def optimize_weights_proximal_legacy(tensor: Tensor, scale: Tensor, zero: Tensor
     return W_q.to(torch.float32 if tensor.dtype not in (torch.float16, torch.bfloat16, torch.float32) else tensor.dtype).to(tensor.device), scale.to(tensor.device), zero_new.to(tensor.device)
 
 
+def optimize_weights_proximal_legacy_step(W_f: Tensor, scale: Tensor, zero: Tensor, min_max: list, beta: float, lp_norm: float, axis: int) -> tuple:
+    """optimize.py:201-206, one half-quadratic step: returns (W_r, W_q, new zero, scale).  The new zero-point — the only reduction of
+    the step — comes from the HIP solver run for one iteration (ATen's CPU float32 summation order, bit for bit); W_q and W_r are the
+    step's elementwise expressions evaluated on the device (round / clamp / subtract / divide: one IEEE operation each, no contraction)."""
+    if W_f.dim() != 2 or axis not in (0, 1):
+        raise ValueError("hqq_amd: optimize_weights_proximal_legacy_step takes the 2-D grouped view and axis 0 or 1")
+    if min_max[0] != 0:
+        raise NotImplementedError("hqq_amd: levels start at 0 (min_max[0] == 0), as Quantizer.quantize sets them")
+    if not W_f.is_cuda:
+        raise RuntimeError("hqq_amd: optimize_weights_proximal_legacy_step has no CPU path (tensor on %s)" % W_f.device)
+    scale_f, zero_f = scale.to(W_f.device).float(), zero.to(W_f.device).float()
+    Wf = W_f.float()
+    W_q = torch.round(Wf * scale_f + zero_f).clamp_(min_max[0], min_max[1])
+    W_r = (W_q - zero_f) / scale_f
+    _, zero_new = ops.optimize(W_f, scale_f, zero_f, int(min_max[1]), axis=axis, iters=1, beta=float(beta), lp_norm=float(lp_norm))
+    return W_r, W_q, zero_new, scale
+
+
 # the reference's aliases (optimize.py:259)
 optimize_weights_proximal = optimize_weights_proximal_legacy

@@ -62,3 +62,10 @@ def decode_safetensor_type(data, data_type):
         except KeyError:
             raise ValueError(f"unknown dtype string in state_dict: {text!r}") from None
     raise TypeError(f"cannot decode to {data_type}")
+
+
+def zero_pad_row(tensor: torch.Tensor, num_rows: int, dtype: Union[torch.dtype, None] = None) -> torch.Tensor:
+    """hqq/core/utils.py:22-32: `tensor` on top of a zero matrix of `num_rows` rows (the 3-bit packer pads its rows to a multiple of ten with it)"""
+    out = torch.zeros([num_rows, tensor.shape[1]], device=tensor.device, dtype=tensor.dtype if (dtype is None) else dtype)
+    out[: len(tensor)] = tensor
+    return out

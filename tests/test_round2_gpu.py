@@ -525,6 +525,32 @@ def test_optimize_weights_proximal_on_its_own(ops, name, axis):
     assert torch.equal(scale2.cpu(), scale) and np.array_equal((1.0 / scale).numpy().view(np.uint32), g["scale_f32"].reshape(scale.shape).view(np.uint32))
 
 
+@pytest.mark.parametrize("name,axis", [("quant_4b_192x256", 1), ("quant_2b_64x2048_normal", 1), ("quant_axis0_4b_128x256", 0)])
+def test_one_proximal_step_on_its_own(ops, name, axis):
+    """optimize_weights_proximal_legacy_step (optimize.py:201-206) by hand: W_r, W_q and the new zero-point bit for bit what the
+    reference's op sequence gives in float32 on the CPU (evaluated here with the same torch ops)"""
+    from hqq_amd.core.optimize import optimize_weights_proximal_legacy_step, shrink_lp_op
+    g = load_golden(name)
+    nbits, gs = int(g["nbits"]), int(g["gs"])
+    W = torch.from_numpy(g["W"]).float()
+    Wg = W.reshape(-1, gs) if axis == 1 else W.reshape(gs, -1)
+    _min, _max = Wg.min(axis=axis, keepdim=True)[0], Wg.max(axis=axis, keepdim=True)[0]
+    max_v = round(2 ** nbits - 1)
+    denom = _max - _min
+    scale = max_v / denom
+    scale = torch.where(denom.abs() <= 1e-4, torch.full_like(scale, 1.0), scale).clamp(max=2e4)
+    zero = -_min * scale
+    if nbits == 4:
+        zero = torch.round(zero)
+    W_q = torch.round(Wg * scale + zero).clamp_(0, max_v)
+    W_r = (W_q - zero) / scale
+    W_e = shrink_lp_op(Wg - W_r, 10.0, 0.7)
+    zero_ref = torch.mean(W_q - (Wg - W_e) * scale, axis=axis, keepdim=True)
+    got_r, got_q, got_z, got_s = optimize_weights_proximal_legacy_step(Wg.cuda(), scale.cuda(), zero.cuda(), [0, max_v], 10.0, 0.7, axis)
+    assert torch.equal(got_q.cpu(), W_q) and torch.equal(got_r.cpu().view(torch.int32), W_r.view(torch.int32))
+    assert torch.equal(got_z.cpu().view(torch.int32), zero_ref.view(torch.int32)) and torch.equal(got_s.cpu(), scale)
+
+
 def test_hqqlinear_per_channel_group_size_none(ops, oracle):
     """group_size=None (one group per output row, quantize.py:434-439): the generic-group-size solver, bit-exact against the oracle,
     and a forward that agrees with dequantize() — whatever kernel or composition serves that group size"""
