@@ -148,3 +148,25 @@ def test_autograd_function_names_of_the_reference_exist():
     from hqq_amd.core import quantize as q
     for name in ("HQQMatmulNoCacheDeq", "HQQMatmulNoCacheMul", "HQQMatmulCachedDeq"):
         assert issubclass(getattr(q, name), torch.autograd.Function)
+
+
+def test_patching_helpers_of_the_reference():
+    """hqq/utils/patching.py:38-109: autoset_quant_config, patch_add_weight_param, patch_lora_inference (host logic, no GPU)"""
+    import types
+    import torch
+    from hqq_amd.utils.patching import autoset_quant_config, patch_add_weight_param, patch_lora_inference
+    lay = types.SimpleNamespace(quant_config=None, meta={"nbits": 4, "group_size": 64, "axis": 1, "quant_scale": False, "quant_zero": False})
+    assert autoset_quant_config(lay) is lay and lay.quant_config["weight_quant_params"]["nbits"] == 4
+    assert lay.quant_config["weight_quant_params"]["group_size"] == 64 and lay.quant_config["weight_quant_params"]["axis"] == 1
+    assert autoset_quant_config(lay, {"x": 1}).quant_config == {"x": 1}
+    m = torch.nn.Module()
+    m.device = "cpu"
+    patch_add_weight_param(m, {"device": "cpu", "dtype": torch.float16})
+    assert m.weight.shape == (1,) and not m.weight.requires_grad
+    m2 = torch.nn.Module()
+    patch_add_weight_param(m2, {"device": "cpu", "dtype": torch.float16})
+    assert m2.weight.dtype == torch.float16
+    lora = types.SimpleNamespace(lora_A=torch.randn(8, 2), lora_B=torch.randn(2, 4), scaling=0.5, linear_layer=object())
+    patch_lora_inference(lora)
+    x = torch.randn(3, 8)
+    assert torch.allclose(lora.forward_lora(x), (x @ lora.lora_A @ lora.lora_B) * 0.5)

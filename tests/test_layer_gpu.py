@@ -122,6 +122,20 @@ def test_backward_wrt_input_redequantises(ops):
     torch.testing.assert_close(x.grad, want, rtol=2e-3, atol=2e-2)
 
 
+def test_prepare_for_inference_default_binds_the_inference_forward(ops):
+    """backend="default" (patching.py:128-136): every HQQLinear gets the instance-bound inference forward — here the fused HIP one —
+    same output bits as the class-wide forward, no autograd graph"""
+    from hqq_amd.utils.patching import prepare_for_inference
+    torch.manual_seed(5)
+    model = torch.nn.Sequential(HQQLinear(torch.nn.Linear(256, 128, bias=True), BaseQuantizeConfig(nbits=4, group_size=64), compute_dtype=torch.float16, device="cuda"))
+    x = torch.randn(3, 256, device="cuda", dtype=torch.float16)
+    want = model(x)
+    prepare_for_inference(model, backend="default")
+    assert "forward" in vars(model[0]) and model[0].quant_config is not None
+    got = model(x.clone().requires_grad_(True))
+    assert torch.equal(got, want) and not got.requires_grad
+
+
 def test_prepare_for_inference_swaps_layers(ops):
     from hqq_amd.backends.hip import HQQLinearHIP
     from hqq_amd.utils.patching import prepare_for_inference
