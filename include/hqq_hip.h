@@ -215,7 +215,8 @@ int hqq_hip_quantize_axis0(const void* W, int w_dtype, int64_t numel, int64_t gr
  * CALLER's scale and zero instead of the group's min / max.  W viewed as [numel / group_size, group_size] (axis 1: a group per row) or
  * [group_size, numel / group_size] (axis 0: a group per column); scale_in / zero_in one float32 per group (scale as the quantiser uses it,
  * NOT inverted).  levels_out: the final W_q = clamp(rint(W * scale + zero), 0, max_v) as uint8 in W's view; zero_out: the solved zero per
- * group (scale is returned unchanged by the reference).  workspace: hqq_hip_quantize_workspace_bytes(numel, group_size, iters) + 4 bytes
+ * group (scale is returned unchanged by the reference).  iters = 1 is one optimize_weights_proximal_legacy_step (optimize.py:201-206):
+ * zero_out is then that step's new zero-point.  workspace: hqq_hip_quantize_workspace_bytes(numel, group_size, iters) + 4 bytes
  * per group. */
 int hqq_hip_optimize(const void* W, int w_dtype, int64_t numel, int64_t group_size, int axis, int max_v, const float* scale_in, const float* zero_in,
                      int iters, float beta, float lp_norm, void* levels_out, float* zero_out, int32_t* info_out,
