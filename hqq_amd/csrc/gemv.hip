@@ -114,16 +114,30 @@ static_assert(GV_MAXL == 4, "the scalar parameter list below spells four layers 
 #define GV_IN_TS_PACK
 #define GV_IN_TS_ARG(in)
 #endif
+#ifdef GV_LAB_PRELOAD
+// lab (tools/gemv_lab.hip, built with -mllvm -amdgpu-kernarg-preload-count=16): what a wave of layer 0 needs for its x loads and its first
+// unit's requests leads the parameter list — 14 dwords, as many as the hardware preloads into SGPRs at wave launch — so that those
+// requests do not wait for the scalar loads of the rest
+#define GV_IN_PARAMS                                                                                                                    \
+  const half_t *x_, int K_, int G_, int total_, int pe0, int N0, int ksplit_, const uint8_t *Wq0, const half_t *sc0, const half_t *ze0, \
+      int gs_, int red_off_, const uint8_t *Wq1, const uint8_t *Wq2, const uint8_t *Wq3, const half_t *sc1, const half_t *sc2,          \
+      const half_t *sc3, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N1, int N2, int N3, int pe1, int pe2, int pe3 GV_IN_TS_PARAM
+#define GV_IN_ARGS(in)                                                                                                                       \
+  (in).x, (in).K, (in).G, (in).total_prow, (in).prow_end[0], (in).N[0], (in).ksplit, (in).Wq[0], (in).scale[0], (in).zero[0], (in).gs,        \
+      (in).red_off, (in).Wq[1], (in).Wq[2], (in).Wq[3], (in).scale[1], (in).scale[2], (in).scale[3], (in).zero[1], (in).zero[2], (in).zero[3], \
+      (in).N[1], (in).N[2], (in).N[3], (in).prow_end[1], (in).prow_end[2], (in).prow_end[3] GV_IN_TS_ARG(in)
+#else
 #define GV_IN_PARAMS                                                                                                                       \
   const uint8_t *Wq0, const uint8_t *Wq1, const uint8_t *Wq2, const uint8_t *Wq3, const half_t *sc0, const half_t *sc1, const half_t *sc2, \
       const half_t *sc3, const half_t *ze0, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N0, int N1, int N2, int N3,       \
       int pe0, int pe1, int pe2, int pe3, const half_t *x_, int K_, int gs_, int G_, int total_, int red_off_, int ksplit_ GV_IN_TS_PARAM
-#define GV_IN_PACK \
-  GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ GV_IN_TS_PACK }
 #define GV_IN_ARGS(in)                                                                                                                       \
   (in).Wq[0], (in).Wq[1], (in).Wq[2], (in).Wq[3], (in).scale[0], (in).scale[1], (in).scale[2], (in).scale[3], (in).zero[0], (in).zero[1],    \
       (in).zero[2], (in).zero[3], (in).N[0], (in).N[1], (in).N[2], (in).N[3], (in).prow_end[0], (in).prow_end[1], (in).prow_end[2],           \
       (in).prow_end[3], (in).x, (in).K, (in).gs, (in).G, (in).total_prow, (in).red_off, (in).ksplit GV_IN_TS_ARG(in)
+#endif
+#define GV_IN_PACK \
+  GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ GV_IN_TS_PACK }
 
 // the layer a wave is currently streaming (all wave-uniform -> SGPRs)
 struct LayerCtx {
@@ -269,8 +283,12 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   const GvIn a = GV_IN_PACK;
   // all of them in ONE batch of scalar loads before anything else (the asm only needs them present: left alone the compiler fetched
   // x and K first, requested x, and then fetched the rest — a second cold scalar-cache miss in front of the first weight request)
-  asm volatile("" ::"s"(Wq0), "s"(Wq1), "s"(Wq2), "s"(Wq3), "s"(sc0), "s"(sc1), "s"(sc2), "s"(sc3), "s"(ze0), "s"(ze1), "s"(ze2), "s"(ze3), "s"(N0), "s"(N1),
-               "s"(N2), "s"(N3), "s"(pe0), "s"(pe1), "s"(pe2), "s"(pe3), "s"(x_), "s"(K_), "s"(gs_), "s"(G_), "s"(total_), "s"(ksplit_), "s"(gridDim.x));
+#define GV_PIN_ARGS                                                                                                                           \
+  asm volatile("" ::"s"(Wq0), "s"(Wq1), "s"(Wq2), "s"(Wq3), "s"(sc0), "s"(sc1), "s"(sc2), "s"(sc3), "s"(ze0), "s"(ze1), "s"(ze2), "s"(ze3), "s"(N0), \
+               "s"(N1), "s"(N2), "s"(N3), "s"(pe0), "s"(pe1), "s"(pe2), "s"(pe3), "s"(x_), "s"(K_), "s"(gs_), "s"(G_), "s"(total_), "s"(ksplit_), "s"(gridDim.x))
+#ifndef GV_LAB_PRELOAD
+  GV_PIN_ARGS;
+#endif
   static_assert(EXACT || !BF16, "bf16 is served by the exact-weights path only");
   static_assert(!SUB || (EXACT && !BF16), "the subnormal-field sequence is an fp16 exact-weights variant");
   constexpr int PER = 8 / NBITS;
@@ -392,10 +410,21 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
   const bool live0 = prow < total;
   prow = live0 ? prow : total - 1;
+#ifdef GV_LAB_PRELOAD
+  LayerCtx lc{a.Wq[0], a.scale[0], a.zero[0], a.N[0], 0, a.prow_end[0]};   // preloaded: a wave of layer 0 requests without waiting for the rest
+  if (prow >= a.prow_end[0]) {
+    asm volatile("");   // (keeps this a branch: converted to selects it would wait for every argument on both paths)
+    lc = select_layer(a, prow);
+  }
+#else
   LayerCtx lc = select_layer(a, prow);
+#endif
   Unit<PER, GS64> ua, ub;
   issue(ua, lc, prow, unit, live0);
   GV_TS(1)
+#ifdef GV_LAB_PRELOAD
+  GV_PIN_ARGS;
+#endif
 
   store_chunk(0, tid, xv0, xv1);
 #pragma unroll
