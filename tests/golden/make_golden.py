@@ -23,6 +23,8 @@ Fixture families
   quant_tensorwise_<tag>.npz Quantizer.quantize(channel_wise=False): one scale / zero for the whole tensor, packed in its own shape
   quant_axis0_<tag>.npz      Quantizer.quantize(axis=0) (groups down the rows of the [gs, numel/gs] view) + HQQLinear(axis=0)
                              dequantize / forward for fp16
+  step_<tag>.npz             optimize_weights_proximal_legacy_step (optimize.py:201-206) on a grouped tensor with a given start
+                             (scale, zero): W_r, W_q and the new zero-point of ONE solver step
   refsd_cfg1_4b.npz          the reference's own HQQLinear.state_dict() (encoded, quantize.py:617-680) of the configs[0]
                              layer at 4 bits, fp16 — the wire format hqq_amd.HQQLinear.load_state_dict must accept
 """
@@ -274,6 +276,26 @@ def main():
     Wt = torch.randn(160, 256) * 0.05
     for nbits in (8, 4, 3, 2, 1):
         tensorwise_case(f"quant_tensorwise_{nbits}b_160x256", Wt, nbits, nbits == 4)
+
+    # ---------------- one solver step on its own: optimize_weights_proximal_legacy_step (optimize.py:201-206) ----------------
+    from hqq.core.optimize import optimize_weights_proximal_legacy_step
+
+    def step_case(tag, Wg, nbits, axis):
+        max_v = round(2 ** nbits - 1)
+        _min, _max = Wg.min(axis=axis, keepdim=True)[0], Wg.max(axis=axis, keepdim=True)[0]
+        scale = (max_v / (_max - _min)).clamp(max=2e4)   # (the start Quantizer.quantize gives the solver, quantize.py:118-134)
+        zero = -_min * scale
+        if nbits == 4:
+            zero = torch.round(zero)
+        W_r, W_q, zero_out, scale_out = optimize_weights_proximal_legacy_step(Wg.clone(), scale.clone(), zero.clone(), [0, max_v], 1e1, 0.7, axis)
+        assert torch.equal(scale_out, scale)
+        save(tag, W=Wg.numpy(), scale_in=scale.numpy(), zero_in=zero.numpy(), axis=np.array(axis), max_v=np.array(max_v), beta=np.array(1e1),
+             lp_norm=np.array(0.7), W_r=W_r.numpy(), W_q=W_q.numpy().astype(np.uint8), zero_out=zero_out.numpy())
+
+    torch.manual_seed(17)
+    step_case("step_4b_axis1_384x64", torch.randn(384, 64) * 0.03, 4, 1)
+    step_case("step_2b_axis1_128x64", torch.randn(128, 64) * 0.5 + 0.1, 2, 1)
+    step_case("step_4b_axis0_64x512", torch.randn(64, 512) * 0.03, 4, 0)
 
     # ---------------- the reference's state_dict (wire format) of the configs[0] layer ----------------
     torch.manual_seed(0)

@@ -169,3 +169,22 @@ def test_aten_outer_sum_order(oracle):
         xn = np.ascontiguousarray(x.numpy())
         got = np.array([L.hqq_oracle_col_sum_f32(xn[:, j:].ctypes.data_as(ctypes.c_void_p), C, n, j, C) for j in range(C)], np.float32)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (n, C)
+
+
+@pytest.mark.parametrize("name", ["step_4b_axis1_384x64", "step_2b_axis1_128x64", "step_4b_axis0_64x512"])
+def test_one_solver_step_formula_matches_reference(name):
+    """optimize_weights_proximal_legacy_step (optimize.py:201-206) as the reference computed it (tests/golden/step_*.npz) against the
+    op sequence the GPU test `test_one_proximal_step_on_its_own` evaluates with torch on the CPU — which pins that test's expectation
+    (and hqq_amd.core.optimize.shrink_lp_op, host code) to the reference itself: W_r, W_q and the new zero-point bit for bit"""
+    import torch
+    from hqq_amd.core.optimize import shrink_lp_op
+    g = load_golden(name)
+    W, scale, zero = torch.from_numpy(g["W"]), torch.from_numpy(g["scale_in"]), torch.from_numpy(g["zero_in"])
+    axis, max_v, beta, lp = int(g["axis"]), int(g["max_v"]), float(g["beta"]), float(g["lp_norm"])
+    W_q = torch.round(W * scale + zero).clamp_(0, max_v)
+    W_r = (W_q - zero) / scale
+    W_e = shrink_lp_op(W - W_r, beta, lp)
+    zero_new = torch.mean(W_q - (W - W_e) * scale, axis=axis, keepdim=True)
+    assert np.array_equal(W_q.numpy().astype(np.uint8), g["W_q"])
+    assert np.array_equal(W_r.numpy().view(np.uint32), g["W_r"].view(np.uint32))
+    assert np.array_equal(zero_new.numpy().view(np.uint32), g["zero_out"].view(np.uint32))
