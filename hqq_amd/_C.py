@@ -28,6 +28,7 @@ SYMBOLS = {
     "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
+    "hqq_hip_gemv_chained": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _vp, _vp]),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_forward_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemm_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
@@ -47,7 +48,7 @@ SYMBOLS = {
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -120,6 +120,49 @@ struct SlabExact {
     if constexpr (S + 1 < PER) SlabExact<NBITS, M, S + 1, PER, SUB>::run(w, zs, b0, b1, acc, magic);
   }
 };
+// The rebuild half of SlabExact on its own: the lane's 16 weights of every slab as MFMA A operands (out[s][0] = k 0..7 of the
+// lane's chunk, out[s][1] = k 8..15), nothing contracted yet.  gemv_chain.hip rebuilds a launch's first units while the activation
+// row they will meet is still being produced by the previous launch.  Same operations in the same order as SlabExact: same bits.
+template <int NBITS, int S, int PER, bool SUB>
+struct SlabRebuild {
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], h8_t (&out)[PER][2], uint32_t magic) {
+    constexpr int sh = NBITS * (PER - 1 - S);
+    const half2_t pr = as_h2(zs[S]);
+    const half2_t zz = {pr.x, pr.x}, ss = {pr.y, pr.y};
+    half2_t q[8];
+    uint32_t o[8];
+    if constexpr (SUB) {
+      constexpr uint32_t m1 = ((NBITS == 8) ? 0xFFu : ((1u << NBITS) - 1u)) << sh;
+      constexpr uint32_t m = m1 | (m1 << 16);
+      const half2_t lift = {static_cast<half_t>(32768.0f), static_cast<half_t>(32768.0f)};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        q[2 * d] = as_h2(w[d] & m);
+        q[2 * d + 1] = as_h2((w[d] >> 8) & m);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], lift, -zz);   // rounding 1 (zz = z * 2^-J)
+    } else {
+      constexpr float inv = 1.0f / static_cast<float>(1 << sh);
+      const half2_t k1 = {static_cast<half_t>(inv), static_cast<half_t>(inv)};
+      const half2_t k2 = {static_cast<half_t>(-1024.0f * inv), static_cast<half_t>(-1024.0f * inv)};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        q[2 * d] = biased_levels<NBITS, S>(w[d], magic);
+        q[2 * d + 1] = biased_levels<NBITS, S>(w[d] >> 8, magic);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = __builtin_elementwise_fma(q[i], k1, k2);   // exact integer level
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = q[i] - zz;                                  // rounding 1
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = __builtin_bit_cast(uint32_t, q[i] * ss);    // rounding 2 (SUB: ss = s * 2^J)
+    out[S][0] = __builtin_bit_cast(h8_t, u32x4{o[0], o[1], o[2], o[3]});
+    out[S][1] = __builtin_bit_cast(h8_t, u32x4{o[4], o[5], o[6], o[7]});
+    if constexpr (S + 1 < PER) SlabRebuild<NBITS, S + 1, PER, SUB>::run(w, zs, out, magic);
+  }
+};
 // (z, s) of slab `slab` as fetched -> (z * 2^-J, s * 2^J): one packed multiply on the fetching lane, before the hand-round
 // (`slab` is a constant after unrolling)
 template <int NBITS>

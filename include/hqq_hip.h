@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 2
+#define HQQ_HIP_ABI_VERSION 3
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -132,6 +132,41 @@ int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* con
                          const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
                          int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Chained decode launches (ABI 3): hqq_hip_gemv_grouped as a LINK of a chain of dependent launches that overlap.
+ * In a decode step launch s + 1 reads what launch s wrote (q|k|v -> o -> gate|up -> down -> next block: the loop around
+ * HQQLinear.forward, hqq/utils/generation_hf.py:117-540; forward itself: quantize.py:880-898).  Stream order makes that safe and
+ * costs a kernel boundary + prologue + pipeline fill per launch (~3.4 us against 3.6 us of weight streaming at the 7B shapes).
+ * A chained launch does everything that does not need x BEFORE x exists — it requests its first packed units and rebuilds them to
+ * fp16 MFMA operands in registers — then waits IN the kernel for its predecessor's arrival counters, reads x and contracts.  The
+ * caller puts consecutive links on TWO streams (even / odd) so that link s + 1 starts while link s streams; link s + 2 follows
+ * link s in stream order, so at most two links are alive, and a link places at most half of what a compute unit admits: both are
+ * fully resident whatever the dispatch order (a waiting workgroup never keeps a producing one off the chip).
+ * Same arithmetic, same summation order, same bits as hqq_hip_gemv_grouped.  Covered: fp16, nbits in {8,4,2}, group_size 64,
+ * 1 <= M <= 4, exact weights (opts 0 or HQQ_OPT_META_SCALABLE), K % 64 == 0; else HQQ_ERR_UNSUPPORTED.
+ *   link->wait          the predecessor's arrival counters (HQQ_CHAIN_COUNTER_BYTES, 128-byte aligned), or NULL: x is complete when
+ *                       the launch starts (the first link of a step; plain stream order)
+ *   link->wait_arrivals what the predecessor's call returned in *arrivals
+ *   link->signal        this launch's arrival counters, or NULL: no later launch waits for it
+ *   link->status        one uint32, shared by the chain: a wait that gives up after spin_limit polls writes 1 + its workgroup index
+ *                       there and runs on WITHOUT waiting (outputs undefined, reported, never a hang).  0 = every hand-off completed.
+ *   link->spin_limit    polls before giving up (0 = 65536, roughly 50 ms)
+ * The caller zeroes every counter block and the status word before the first link of a step (one memset node under graph capture)
+ * and keeps outputs that a later link reads untouched until the chain has finished.  *arrivals receives the number of arrivals this
+ * launch will add to link->signal.
+ * ------------------------------------------------------------------------------------------- */
+#define HQQ_CHAIN_COUNTER_BYTES 4096
+typedef struct hqq_hip_chain_link {
+  const void* wait;
+  void* signal;
+  void* status;
+  uint32_t wait_arrivals;
+  uint32_t spin_limit;
+} hqq_hip_chain_link;
+int hqq_hip_gemv_chained(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
+                         const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
+                         int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, const hqq_hip_chain_link* link,
+                         uint32_t* arrivals, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * The persistent decode engine: one launch walks a whole list of DEPENDENT stages, one activation row (bs = 1).
  * A stage is what one hqq_hip_gemv_grouped call computes — up to HQQ_GEMV_MAX_GROUP layers reading the same x[1,K] — and stage
