@@ -35,9 +35,17 @@ class HQQLinearHIP(nn.Module):
         self.register_buffer("scale", m["scale"].reshape(-1).contiguous(), persistent=True)
         self.register_buffer("zero", m["zero"].reshape(-1).contiguous(), persistent=True)
         self.bias = None if hqq_layer.bias is None else hqq_layer.bias.to(device=W_q.device, dtype=self.compute_dtype)
-        # checked once, here: may the exact weight rebuild use its three-op form on this layer's (zero, scale)?  (include/hqq_hip.h)
-        self.opts = ops.OPT_META_SCALABLE if (self.compute_dtype == torch.float16 and self.nbits in (8, 4, 2, 1) and
+        self.refresh_opts()
+
+    def refresh_opts(self) -> None:
+        """May the exact weight rebuild use its three-op form on this layer's (zero, scale)?  (include/hqq_hip.h, hqq_hip_meta_check.)
+        Checked when the layer is built and again whenever a state dict is loaded into it; call it after editing `scale` / `zero` in place."""
+        self.opts = ops.OPT_META_SCALABLE if (self.compute_dtype == torch.float16 and self.nbits in (8, 4, 2, 1) and self.scale.is_cuda and
                                                ops.meta_scalable(self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits)) else 0
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.refresh_opts()   # scale / zero are persistent buffers: a loaded checkpoint may not satisfy what the old values did
 
     @staticmethod
     def check(hqq_layer: HQQLinear) -> bool:
@@ -72,7 +80,7 @@ class HQQLinearHIP(nn.Module):
                 out += self.bias
             return out
         return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, self.nbits,
-                           opts=self.opts)
+                           opts=ops.layer_opts(self.opts))
 
 
 def patch_hqq_to_hip(layer, patch_params=None):
@@ -119,7 +127,8 @@ class _GroupedMember(nn.Module):
             return self.layer(x)
         layers = [m.layer for m in g.members]
         outs = ops.gemv_grouped(x, [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers], self.in_features,
-                                layers[0].group_size, layers[0].nbits, opts=g.opts)
+                                layers[0].group_size, layers[0].nbits,
+                                opts=ops.layer_opts(ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0))
         g.x, g.version, g.outs = x, ver, list(outs)
         out, g.outs[self._index] = g.outs[self._index], None
         return out

@@ -99,8 +99,11 @@ class Quantizer:
         if meta["view_as_float"]:
             W_q = W_q.view(meta["unpack_view_dtype"])
         N, K = meta["shape"]
-        if meta["scale"].numel() == 1 and meta["zero"].numel() == 1 and (N if meta["axis"] == 1 else K) > 1 and not meta["group_size"]:
-            # channel_wise=False: one scale / zero for the tensor, packed in its own shape — every row is a group with the same constants
+        gs_eff = meta["group_size"] if meta["group_size"] else (K if meta["axis"] == 1 else N)
+        if meta["scale"].numel() == 1 and meta["zero"].numel() == 1 and (N * K) // gs_eff > 1:
+            # channel_wise=False: one scale / zero for the tensor, levels packed in the tensor's own shape — every row is a group with the
+            # same constants.  Recognised by the meta itself (one constant pair for more than one group), whatever group_size the caller
+            # left in it: Quantizer.quantize(channel_wise=False) stores the argument's default, 64 (the reference broadcasts the 0-d pair)
             return ops.dequantize(W_q, meta["scale"].reshape(1).expand(N).contiguous(), meta["zero"].reshape(1).expand(N).contiguous(),
                                   N, K, K, Quantizer._packing_bits[meta["packing"]], 1)
         gs = meta["group_size"] if meta["group_size"] else (K if meta["axis"] == 1 else N)
@@ -456,7 +459,7 @@ class HQQLinear(nn.Module):
             N, K = m["shape"]
             W_q = self.W_q.view(m["unpack_view_dtype"]) if m["view_as_float"] else self.W_q
             return ops.forward(x, W_q, m["scale"], m["zero"], bias, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]],
-                               opts=getattr(self, "_hip_opts", 0))
+                               opts=ops.layer_opts(getattr(self, "_hip_opts", 0)))
         out = self.matmul(x, transpose=transpose)
         if bias is not None:
             out += bias

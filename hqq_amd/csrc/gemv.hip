@@ -495,12 +495,8 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   const int tiles = a.ksplit ? a.total_prow : (a.total_prow + GV_WAVES - 1) / GV_WAVES;
   const int grid = tiles < cap ? tiles : cap;
   if (lds > 64 * 1024) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GV_LDS_MAX);
-      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-      raised = true;
-    }
+    static LdsRaised raised;   // per instantiation (and device)
+    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), GV_LDS_MAX, "hqq_hip_gemv")) return rc;
   }
   GvIn in;
   GvOut out;

@@ -290,12 +290,8 @@ static int g3_launch(const G3Args& a, hipStream_t st) {
   const int cap = (n_cus * per_cu) & ~7;
   auto kern = gemv3_f16_kernel<M>;
   if (lds > 64 * 1024) {
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-      raised = true;
-    }
+    static LdsRaised raised;
+    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), 144 * 1024, "hqq_hip_gemv")) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(tiles < cap ? tiles : cap), dim3(G3_WAVES * 64), lds, st, a);
   return check_launch("hqq_hip_gemv(3-bit)");

@@ -351,12 +351,8 @@ static int s3_launch(S3Args& a, int max_n, void* ws, size_t ws_bytes, hipStream_
   const int cap = n_cus * per_cu;
   auto kern = gemv3s_kernel<M, SUB>;
   if (lds > 64 * 1024) {
-    static bool raised = false;
-    if (!raised) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-      raised = true;
-    }
+    static LdsRaised raised;
+    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), 144 * 1024, "hqq_hip_gemv")) return rc;
   }
   hipLaunchKernelGGL(kern, dim3(wgs < cap ? wgs : cap), dim3(S3_WAVES * 64), lds, st, a);
   int rc = check_launch("hqq_hip_gemv(3-bit)");

@@ -398,15 +398,9 @@ static int launch_chain(const GvArgs& args, GvChain ch, uint32_t* arrivals, hipS
   const size_t lds = a.red_off + 16;
   if (lds > static_cast<size_t>(GV_LDS_MAX)) { set_error("hqq_hip_gemv_chained: K=%d too long to stage %d rows of x in LDS", a.K, M); return HQQ_ERR_UNSUPPORTED; }
   auto kern = gemv_chain_kernel<NBITS, M, SUB, NPRE>;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   if (lds > 64 * 1024) {
-    static bool raised[64] = {};   // per instantiation and device
-    if (dev < 0 || dev >= 64 || !raised[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GV_LDS_MAX);
-      if (e != hipSuccess) { set_error("hqq_hip_gemv_chained: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-      if (dev >= 0 && dev < 64) raised[dev] = true;
-    }
+    static LdsRaised raised;   // per instantiation (and device)
+    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), GV_LDS_MAX, "hqq_hip_gemv_chained")) return rc;
   }
   // Two links are co-resident: place at most half of what a CU admits of this kernel (registers, LDS).  Cached per instantiation for the
   // LDS size last asked about (a host query, no stream operation).

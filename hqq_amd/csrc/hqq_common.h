@@ -25,6 +25,19 @@ int check_launch(const char* what);
 // stream capture in the caller) left there, so that check_launch() reports this call's launch only
 static inline void clear_stale_error() { (void)hipGetLastError(); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) takes effect on the CURRENT device only: one flag per device and call site (a
+// process-wide flag left the second GPU of a process without the raised limit: its first launch above 64 KiB of LDS failed)
+struct LdsRaised { bool done[64] = {}; };
+static inline int raise_lds_limit(LdsRaised& st, const void* kern, int bytes, const char* who) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+  if (dev >= 0 && dev < 64 && st.done[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) { set_error("%s: cannot raise the dynamic LDS limit: %s", who, hipGetErrorString(e)); return static_cast<int>(e); }
+  if (dev >= 0 && dev < 64) st.done[dev] = true;
+  return 0;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static inline int per_of(int nbits) {

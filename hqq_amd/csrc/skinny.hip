@@ -611,12 +611,8 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
   case MT: {                                                                                                  \
     auto kern = skinny_f16_kernel<NBITS, MT, BF16, SUB>;                                                          \
     if (lds > 64 * 1024) {                                                                                    \
-      static bool raised = false;                                                                             \
-      if (!raised) {                                                                                          \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
-        if (e != hipSuccess) { set_error("hqq_hip_gemv: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e)); return static_cast<int>(e); } \
-        raised = true;                                                                                        \
-      }                                                                                                       \
+      static LdsRaised raised;                                                                                \
+      if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), 128 * 1024, "hqq_hip_gemv")) return rc; \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                        \
     break;                                                                                                    \

@@ -65,7 +65,9 @@ def _p(t):
 
 
 def set_gemv_mode(mode: int) -> None:
-    """GEMV_EXACT (default): reference-identical weights on the MFMA path; GEMV_FACTORED: fp32-factored dot2 path."""
+    """GEMV_EXACT (default): reference-identical weights on the MFMA path; GEMV_FACTORED: fp32-factored dot2 path.  Applies to raw
+    ops.* calls that pass no `opts` and to every layer forward (HQQLinear with HQQBackend.HIP, HQQLinearHIP, grouped projections),
+    which combine it with their own meta-dependent bits through layer_opts()."""
     global _default_opts
     if mode not in (GEMV_EXACT, GEMV_FACTORED):
         raise ValueError(f"hqq_amd: unknown gemv mode {mode}")
@@ -80,6 +82,12 @@ def _opts(opts) -> int:
     return _default_opts if opts is None else int(opts)
 
 
+def layer_opts(meta_opts: int) -> int:
+    """Option bits for a LAYER's forward: its own meta-dependent bits (0 / OPT_META_SCALABLE), unless set_gemv_mode(GEMV_FACTORED) is in
+    force — then the factored arithmetic for every layer (the three-op bit belongs to the exact rebuild and is dropped)."""
+    return OPT_FACTORED if (_default_opts & OPT_FACTORED) else int(meta_opts)
+
+
 # ---- caller-owned workspace of the split-K / slab-sharing decode launches (include/hqq_hip.h "Workspace") --------------------
 # One zero-initialised buffer per device, sized for the largest launch seen so far.  Growing allocates a NEW buffer and keeps
 # the old ones alive: a hipGraph captured earlier has the old address baked in and must stay valid (never free what a graph
@@ -89,11 +97,35 @@ _ws_retired: list = []
 _WS_MIN = 8 << 20
 
 
+_ws_last_stream: dict = {}
+
+
+def _ws_serialise(key: int) -> None:
+    """The device's workspace is ONE buffer (arrival counters + parked partial sums) and the C ABI forbids sharing it between calls that
+    may run concurrently: a call from another stream than the previous workspace user first waits for everything that stream has
+    enqueued.  (Outside stream capture; inside a capture the launches of one capture are ordered by the capture itself unless the
+    caller forks streams — then give each branch its own buffer through the C ABI.)"""
+    cur = torch.cuda.current_stream(key)
+    last = _ws_last_stream.get(key)
+    if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+        cur.wait_stream(last)
+    _ws_last_stream[key] = cur
+
+
+def release_retired_workspaces() -> int:
+    """Free the workspace buffers that growth retired.  Only when no captured hipGraph still replays launches that were captured with
+    them (the caller knows; the library cannot).  Returns the bytes released."""
+    n = sum(t.numel() for t in _ws_retired)
+    _ws_retired.clear()
+    return n
+
+
 def reserve_workspace(device, nbytes: int) -> Tensor:
     """make sure the device's decode workspace holds `nbytes`; call it before capturing a graph whose launches need one"""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     cur = _ws_cur.get(key)
+    _ws_serialise(key)
     if cur is not None and cur.numel() >= nbytes:
         return cur
     if torch.cuda.is_current_stream_capturing():
@@ -169,6 +201,9 @@ def dequantize(W_q: Tensor, scale: Tensor, zero: Tensor, N: int, K: int, group_s
     _dev(W_q, scale, zero)
     if scale.dtype != zero.dtype:
         raise TypeError("hqq_amd: scale and zero must share the compute dtype")
+    groups = (N * K) // int(group_size)
+    if scale.numel() != groups or zero.numel() != groups:   # the kernel reads N * K / group_size constants through raw pointers
+        raise ValueError(f"hqq_amd: dequantize needs {groups} scale / zero values (N * K / group_size), got {scale.numel()} / {zero.numel()}")
     out = torch.empty((N, K), dtype=scale.dtype, device=W_q.device)
     with torch.cuda.device(W_q.device):
         rc = _C.lib().hqq_hip_dequantize(nbits, _p(W_q.contiguous()), _p(scale.contiguous()), _p(zero.contiguous()), _p(out),
