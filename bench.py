@@ -602,6 +602,7 @@ def main():
         # the other hot path: Quantizer.quantize = solver + packing, one HIP launch chain per layer
         try:
             qres = []
+            sv = _solver_valu()
             for nm, N_, K_ in (("4096x4096", 4096, 4096), ("11008x4096", 11008, 4096), ("4096x11008", 4096, 11008)):
                 Wsrc = (torch.randn(N_, K_, device=dev, generator=gx) * 0.02).half()
                 ops.quantize(Wsrc, nbits=nbits, group_size=64, round_zero=(nbits == 4))
@@ -616,7 +617,16 @@ def main():
                 its = int(info[0].item())
                 qres.append({"layer": nm, "ms": round(ms, 3), "iters_run": its, "G_element_iters_per_s": round(N_ * K_ * 20 / (ms * 1e-3) / 1e9, 1),
                              "hbm_floor_ms": round((2 + nbits / 8) * N_ * K_ / (HBM_PEAK_GBS * 1e9) * 1e3, 4)})
-            out["quantize"] = {"layers": qres, "note": "Quantizer.quantize (20 proximal iterations computed, stop index applied as the reference does) + bit-packing, fp16 weights in HBM; "
+                if sv:   # the bound, stated: VALU issue (tools/solver_valu_count.py reads the instruction count off the ISA of this build)
+                    qres[-1]["valu_frac"] = round(qres[-1]["G_element_iters_per_s"] / sv["peak_G_element_iters_per_s"], 4)
+            out["quantize"] = {"layers": qres,
+                               "roofline": None if not sv else {"bound": "valu", "unit": "G element-iterations/s", "peak": sv["peak_G_element_iters_per_s"],
+                                                                "valu_instr_per_element_iteration": sv["valu_instr_per_element_iteration"],
+                                                                "issue_cycles_per_element_iteration": sv["issue_cycles_per_element_iteration"],
+                                                                "note": "peak = 1024 SIMDs x 2.4 GHz / issue cycles per element-iteration of solve_kernel's fast path (4 cycles per VALU "
+                                                                        "wave-instruction, 16 for the v_rcp_f32 of the IEEE division; profiles/solver_valu.json); achieved = N K 20 / time of the "
+                                                                        "whole Quantizer.quantize call (solver + error reduction + final levels + packing)"},
+                               "note": "Quantizer.quantize (20 proximal iterations computed, stop index applied as the reference does) + bit-packing, fp16 weights in HBM; "
                                "bound: VALU (float32 division, rounding, clamp, sign, the ATen-ordered row sum; the double-precision pow of the shrinkage is evaluated only in waves "
                                "where it can matter), hbm_floor = one read of W + one write of W_q"}
         except Exception as e:
@@ -640,6 +650,89 @@ def main():
                     legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
             except Exception as e:
                 legs.append({"name": "7b-stack bs=128", "error": repr(e)})
+        # int3 / int2 (BASELINE.json configs[3]): the same stack quantised at the other bit widths by the HIP solver, one token, stream-ordered launches
+        if nbits == 4:
+            for nb in (3, 2):
+                try:
+                    blks = [{name: make_layer(ops, name, N, K, nb, dev, seed=50000 * nb + 16 * b + i, random_codes=a.random_codes, cd=cd)
+                             for i, (name, N, K) in enumerate(BLOCK)} for b in range(nblocks)]
+
+                    def step_nb(blks=blks, nb=nb):
+                        for blk in blks:
+                            for grp in EXCHANGE_GROUPS:
+                                Ls = [blk[name] for name in grp]
+                                o_ = ops.OPT_META_SCALABLE if (a.gemv_mode == "exact" and all(L.opts & ops.OPT_META_SCALABLE for L in Ls)) else 0
+                                ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nb, outs=out_local[grp], opts=o_)
+                    leg(f"7b-stack bs=1 int{nb} (128 stream-ordered launches)", step_nb, nblocks * sum(gemv_bytes(N, K, nb, 1) for _, N, K in BLOCK), 1,
+                        nblocks * len(EXCHANGE_GROUPS), _decode_kernel_name(nb, 1, a.dtype, a.gemv_mode))
+                    del blks
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    legs.append({"name": f"7b-stack bs=1 int{nb}", "error": repr(e)})
+        # prefill (BASELINE.json configs[2], one chunk of 8192 of its 65,536 tokens): one block's seven linears, fused MFMA dequant-GEMM vs the composition
+        if nbits in (8, 4, 2):
+            try:
+                Mp = 8192
+                xsp = {K: torch.randn(Mp, K, device=dev, generator=gx).to(cd) for K in xs}
+                yp = {N_: torch.empty(Mp, N_, device=dev, dtype=cd) for N_ in sorted({L.N for L in blocks[0].values()})}
+                flops_p = 2.0 * Mp * sum(N * K for _, N, K in BLOCK)
+
+                def block_prefill(fused):
+                    for L in blocks[0].values():
+                        ops.forward(xsp[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=yp[L.N], fused=fused, opts=group_opts([L]))
+                for nm, fused, kern in ((f"prefill: one 7B block, M={Mp}, fused MFMA dequant-GEMM (gemm_pipe.hip)", True, "hqq::gemm_pipe_f16_kernel"),
+                                        (f"prefill: one 7B block, M={Mp}, dequantise kernel + library GEMM (the composition)", False, "hqq::dequantize + hipBLASLt")):
+                    leg(nm, lambda f=fused: block_prefill(f), sum(gemv_bytes(N, K, nbits, Mp) for _, N, K in BLOCK), Mp, len(BLOCK), kern)
+                    legs[-1]["bound"] = "mfma"
+                    legs[-1]["tflops"] = round(flops_p / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
+                    legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+                    legs[-1].pop("roofline_frac", None)
+                del xsp, yp
+                torch.cuda.empty_cache()
+            except Exception as e:
+                legs.append({"name": "prefill 8192", "error": repr(e)})
+        # end to end (the reference's headline metric is tok/s of the generate loop, hqq/utils/generation_hf.py:117-540,
+        # Readme.md:153): a random-initialised Llama-2-7B-shaped HF model, every decoder linear quantised by the HIP solver, patched to the
+        # fused kernels (q|k|v and gate|up grouped), greedy decode with a static KV cache, one captured hipGraph per token
+        if nbits == 4 and os.environ.get("HQQ_BENCH_E2E", "1") != "0":
+            try:
+                from transformers import LlamaConfig, LlamaForCausalLM
+                from hqq_amd.backends.hip import group_llama_projections
+                from hqq_amd.core.quantize import BaseQuantizeConfig
+                from hqq_amd.utils.generation import GraphedGreedyDecoder
+                from hqq_amd.utils.model import quantize_model
+                from hqq_amd.utils.patching import prepare_for_inference
+                del blocks[:]
+                torch.cuda.empty_cache()
+                t0 = time.perf_counter()
+                lcfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=N_BLOCKS_7B, num_attention_heads=32, num_key_value_heads=32,
+                                   vocab_size=32000, max_position_embeddings=2048)
+                dflt = torch.get_default_dtype()
+                torch.set_default_dtype(torch.float16)
+                try:
+                    with torch.device(dev):
+                        model = LlamaForCausalLM(lcfg).eval()
+                finally:
+                    torch.set_default_dtype(dflt)
+                quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device=str(dev))
+                prepare_for_inference(model, backend="hip")
+                ngrp = group_llama_projections(model)
+                torch.cuda.synchronize()
+                t_build = time.perf_counter() - t0
+                dec = GraphedGreedyDecoder(model, max_cache_len=256)
+                ids = torch.randint(0, 32000, (1, 16), device=dev, generator=gx)
+                r = dec.benchmark(ids, new_tokens=64, warmup=8)
+                lin_ms = sec_per_step * 1e3
+                out["end_to_end"] = {"tok_s": round(r["tok_s"], 2), "ms_per_token": round(r["ms_per_token"], 4), "new_tokens": r["new_tokens"], "prompt_tokens": r["prompt_tokens"],
+                                     "linear_stack_ms": round(lin_ms, 4), "linear_stack_share": round(lin_ms / r["ms_per_token"], 3), "build_s": round(t_build, 1),
+                                     "model": "random-init Llama-2-7B-shaped LlamaForCausalLM (32 blocks, hidden 4096, intermediate 11008, vocab 32000, fp16), every decoder linear int4 gs=64 "
+                                              f"via hqq_amd.utils.model.quantize_model (HIP solver), prepare_for_inference(backend='hip'), {ngrp} grouped q|k|v / gate|up launches",
+                                     "loop": "hqq_amd.utils.generation.GraphedGreedyDecoder: static KV cache, one captured hipGraph per token (attention, norms, rotary, lm_head are torch's "
+                                             "kernels inside the graph), argmax fed back on the device"}
+                del model, dec
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["end_to_end"] = {"error": repr(e)}
         out["legs"] = legs
 
     if rank == 0:
@@ -658,6 +751,15 @@ def _decode_kernel_name(nbits, M, dtype, mode):
         return f"hqq::skinny_f16_kernel<{nbits}, {(M + 15) // 16}, {'bf16' if dtype == 'bf16' else 'f16'}>"
     arith = "factored" if mode == "factored" else ("exact, three-op rebuild" if mode == "exact" and dtype == "f16" else "exact")
     return f"hqq::gemv_f16_kernel<{nbits}, {M}, gs64, {arith}, {'bf16' if dtype == 'bf16' else 'f16'}>"
+
+
+def _solver_valu():
+    """instruction census of the solver's fast path (profiles/solver_valu.json, written by tools/solver_valu_count.py from the ISA); None if absent"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "solver_valu.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def _pmc_traffic(nbits):

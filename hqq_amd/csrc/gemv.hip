@@ -126,8 +126,11 @@ struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the r
   }
 };
 
-template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false>
-__global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, const GvOut o) {
+// WPG: waves per workgroup.  4 (x 4 workgroups per CU) everywhere, except single layers of at most one packed row per wave of an
+// 8 x 2 grid (o / down of a 7B block: 2048 packed rows), where 8 (x 2 per CU) measured -7 % per launch (fewer workgroups to dispatch and
+// half as many copies of x staged per CU; grouped launches lose 11 % with it: profiles/r03_ab_w8x2.txt)
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false, int WPG = GV_WAVES>
+__global__ __launch_bounds__(WPG * 64) void gemv_f16_kernel(GV_IN_PARAMS, const GvOut o) {
   // (GvIn arrives as plain scalar parameters: values, not memory — passed as a struct the compiler turned selects of its loaded
   //  pointers into loads of selected addresses and staged the loads behind each other: dependent scalar-load latencies in front of
   //  the first weight request)
@@ -160,8 +163,8 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   const int nunits = (nsteps + GV_U - 1) / GV_U;
   const int planes_per_m = nsteps * 2 * 64;
   const bool ksplit = a.ksplit != 0;                   // workgroup-uniform
-  const int stride = ksplit ? gridDim.x : gridDim.x * GV_WAVES;
-  const int ustep = ksplit ? GV_WAVES : 1, ubase = ksplit ? wave : 0;
+  const int stride = ksplit ? gridDim.x : gridDim.x * WPG;
+  const int ustep = ksplit ? WPG : 1, ubase = ksplit ? wave : 0;
   const int total = a.total_prow;
 
   // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   load_chunk(0, tid, xv0, xv1);
   __builtin_amdgcn_sched_barrier(0);   // x in front of the weights: loads return in request order, and the staging barrier waits for x only
 
-  int prow = ksplit ? blockIdx.x : blockIdx.x * GV_WAVES + wave;
+  int prow = ksplit ? blockIdx.x : blockIdx.x * WPG + wave;
   int unit = ubase;
   // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
   const bool live0 = prow < total;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   store_chunk(0, tid, xv0, xv1);
 #pragma unroll
   for (int m = 0; m < M; ++m)
-    for (int j = tid + (m == 0 ? GV_WAVES * 64 : 0); j < chunks_per_m; j += GV_WAVES * 64) {
+    for (int j = tid + (m == 0 ? WPG * 64 : 0); j < chunks_per_m; j += WPG * 64) {
       load_chunk(m, j, xv0, xv1);
       store_chunk(m, j, xv0, xv1);
     }
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
         if (wave == 0 && lane < M * PER) {
           mine = red[lane];
 #pragma unroll
-          for (int w = 1; w < GV_WAVES; ++w) mine += red[w * (M * PER) + lane];
+          for (int w = 1; w < WPG; ++w) mine += red[w * (M * PER) + lane];
         }
         __syncthreads();
         if (wave != 0) return;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_f16_kernel(GV_IN_PARAMS, c
   }
 #ifdef GV_LAB_TS
   GV_TS(6)
-  if (lane == 0 && a.ts) { const int wg = blockIdx.x * GV_WAVES + wave; for (int i = 0; i < 8; ++i) a.ts[wg * 8 + i] = t_[i]; }
+  if (lane == 0 && a.ts) { const int wg = blockIdx.x * WPG + wave; for (int i = 0; i < 8; ++i) a.ts[wg * 8 + i] = t_[i]; }
 #endif
 }
 
@@ -457,29 +460,35 @@ static int num_cus() {
   return g_num_cus;
 }
 
-template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false>
+template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false, int WPG = GV_WAVES>
 static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
+  constexpr int WG_PER_CU = GV_WG_PER_CU * GV_WAVES / WPG;   // the same 16 waves per CU
+  if constexpr (WPG == GV_WAVES && M == 1 && GS64 && EXACT && !BF16 && (NBITS == 8 || NBITS == 4 || NBITS == 2)) {
+    // a single layer with at most one packed row per wave of the wide grid, whose rows span at least one unit per wave: 8 waves x 2 per CU
+    if (args.prow_end[0] == args.total_prow && args.total_prow <= num_cus() * 8 && args.total_prow * 2 > num_cus() * 8 && args.K >= GV_UNIT)
+      return launch_gemv_f16<NBITS, M, GS64, EXACT, BF16, SUB, 8>(args, st);
+  }
   constexpr int PER = 8 / NBITS;
   GvArgs a = args;
   const int nsteps = (a.K + GV_KSTEP - 1) / GV_KSTEP;
   const int nunits = (nsteps + GV_U - 1) / GV_U;
   const size_t xs_bytes = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
   a.red_off = static_cast<int>((xs_bytes + 15) & ~static_cast<size_t>(15));
-  const size_t lds = a.red_off + sizeof(float) * GV_WAVES * M * PER;                  // + K-split reduction buffer
-  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16, SUB>;
+  const size_t lds = a.red_off + sizeof(float) * WPG * M * PER;                  // + K-split reduction buffer
+  auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>;
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
-  per_cu = per_cu > GV_WG_PER_CU ? GV_WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
+  per_cu = per_cu > WG_PER_CU ? WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   {
     // registers bound the residency too (M = 4 exact needs 152 VGPRs: three workgroups per CU, not four): a persistent grid larger
     // than what is resident runs its surplus workgroups as a second round behind the first
     static int by_regs = 0;   // per instantiation
     if (by_regs == 0) {
       hipFuncAttributes fa;
-      by_regs = GV_WG_PER_CU;
+      by_regs = WG_PER_CU;
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess && fa.numRegs > 0) {
         const int regs = (fa.numRegs + 7) & ~7;                 // allocation granule
         const int waves_per_simd = 512 / regs;                  // unified VGPR/AGPR file of 512 per SIMD lane
-        by_regs = waves_per_simd * 4 / GV_WAVES;                // GV_WAVES waves per workgroup over 4 SIMDs
+        by_regs = waves_per_simd * 4 / WPG;                     // WPG waves per workgroup over 4 SIMDs
         by_regs = by_regs < 1 ? 1 : by_regs;
       } else {
         (void)hipGetLastError();
@@ -491,8 +500,8 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   // few rows x long K (e.g. the 1024 x 28672 shard of a 70B down-projection): one row per wave would leave most of the chip idle
   // and each wave with 2-4 KiB in flight; let the workgroup's waves share a row instead
   // (the choice depends on the layer shape only, never on M: a row's result does not change with the batch it is computed in)
-  a.ksplit = (nunits >= GV_WAVES && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * GV_WG_PER_CU * GV_WAVES) ? 1 : 0;
-  const int tiles = a.ksplit ? a.total_prow : (a.total_prow + GV_WAVES - 1) / GV_WAVES;
+  a.ksplit = (nunits >= WPG && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * WG_PER_CU * WPG) ? 1 : 0;
+  const int tiles = a.ksplit ? a.total_prow : (a.total_prow + WPG - 1) / WPG;
   const int grid = tiles < cap ? tiles : cap;
   if (lds > 64 * 1024) {
     static LdsRaised raised;   // per instantiation (and device)
@@ -508,7 +517,7 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
 #ifdef GV_LAB_TS
   in.ts = a.ts;
 #endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(GV_WAVES * 64), lds, st, GV_IN_ARGS(in), out);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out);
   return check_launch("hqq_hip_gemv");
 }
 

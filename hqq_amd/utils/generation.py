@@ -60,3 +60,30 @@ class GraphedGreedyDecoder:
             self.pos += 1
             toks.append(self.tok.clone())
         return torch.cat([ids] + toks, dim=1)
+
+    @torch.no_grad()
+    def benchmark(self, input_ids: Tensor, new_tokens: int = 64, warmup: int = 8) -> dict:
+        """end-to-end decode rate: prefill `input_ids`, capture the decode step, then time `new_tokens` replays of it (HIP events on
+        the current stream; the argmax feeds the next step on the device, the host only replays).  Returns tok/s and ms per token."""
+        assert input_ids.shape[0] == 1
+        T = input_ids.shape[1]
+        assert T + warmup + new_tokens + 4 <= self.max_cache_len
+        self.generate(input_ids, 3, use_graph=True)          # prefill + eager step + captured step (leaves self.graph, self.tok, self.pos)
+        assert self.graph is not None
+
+        def step():
+            self.graph.replay()
+            self.tok.copy_(self.next_tok)
+            self.pos += 1
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(new_tokens):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / new_tokens
+        return {"ms_per_token": ms, "tok_s": 1e3 / ms, "new_tokens": new_tokens, "prompt_tokens": T}
+

@@ -85,3 +85,40 @@ def test_graphed_greedy_decoder_matches_generate():
     graphed = dec.generate(ids, 12, use_graph=True)
     assert dec.graph is not None
     assert torch.equal(eager, want) and torch.equal(graphed, want)
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_quantize_model_matches_the_reference_fixture(nbits):
+    """SURVEY.md §8 f2 pinned to the reference: the 2-block toy Llama of tests/golden/make_model_golden.py, quantised THERE by the
+    reference's AutoHQQHFModel.quantize_model (hqq/models/base.py:266-401, CPU, float32) and HERE by hqq_amd.utils.model.quantize_model
+    on the GPU — the same linears are replaced (lm_head left alone) and every layer's packed W_q, zero and scale hash to the reference's."""
+    import hashlib
+    import numpy as np
+    from conftest import load_golden
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQLinear
+    from hqq_amd.utils.model import quantize_model
+
+    def sha(t):
+        return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest().encode()
+
+    g = load_golden(f"model_llama2blk_{nbits}b")
+    names = bytes(g["names"]).decode().split("\n")
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=512, max_position_embeddings=128)
+    model = LlamaForCausalLM(cfg).float().eval()
+    for n in names:
+        if sha(model.get_submodule(n).weight.detach().numpy()) != g[f"src__{n}"].tobytes():
+            pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    model = model.cuda()
+    quantize_model(model, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=torch.float32, device="cuda")
+    got = [n for n, m in model.named_modules() if isinstance(m, HQQLinear)]
+    assert got == names, "the set (and order) of replaced linears differs from the reference's"
+    assert [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)] == bytes(g["untouched"]).decode().split("\n")
+    for n in names:
+        m = model.get_submodule(n)
+        assert list(m.meta["shape"]) == list(g[f"shape__{n}"])
+        assert sha(m.W_q.data.cpu().numpy()) == g[f"Wq__{n}"].tobytes(), f"{n}: packed W_q differs from the reference"
+        assert sha(m.meta["zero"].float().cpu().numpy()) == g[f"zero__{n}"].tobytes(), f"{n}: zero differs from the reference"
+        assert sha(m.meta["scale"].float().cpu().numpy()) == g[f"scale__{n}"].tobytes(), f"{n}: scale differs from the reference"
