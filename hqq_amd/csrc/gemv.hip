@@ -1,5 +1,5 @@
 // gemv.hip — the decode kernel: fused unpack -> dequantize -> GEMV for HQQLinear.forward with a few activation rows, gfx950,
-// and the C entry points of the decode path (hqq_hip_gemv / hqq_hip_gemv_grouped / hqq_hip_set_gemv_mode), which also route to
+// and the C entry points of the decode path (hqq_hip_gemv / hqq_hip_gemv_grouped), which also route to
 // gemv3.hip (3-bit containers) and gemv_mfma.hip (5..16 rows).
 //
 // Replaces, for axis=1 layers, the reference's per-call chain
@@ -24,7 +24,7 @@
 //           and handed to the consuming lanes with ds_bpermute (group_size 64; other group sizes fetch per lane)
 //   layers  kernel arguments are structure-of-arrays; the current layer is picked with scalar selects and lives in SGPRs
 //
-// Arithmetic, two modes (template parameter EXACT; hqq_hip_set_gemv_mode):
+// Arithmetic, two modes (template parameter EXACT; per-call option bit HQQ_OPT_FACTORED):
 //  EXACT (default)  every weight pair is rebuilt exactly as Quantizer.dequantize does it — (w & mask) | 0x6400 -> v_pk_fma (exact
 //           level) -> v_pk_add(-zero) -> v_pk_mul(scale): two fp16 roundings, bit-identical to hqq_hip_dequantize / the reference
 //           — and contracted on the matrix core: all 64 lanes hold the SAME output row, lane (i = l & 15, o = l >> 4) supplies

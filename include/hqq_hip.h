@@ -228,8 +228,8 @@ int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale,
  *   Wq_out     packed weights, layout of hqq_hip_pack
  *   scale_out  [N*K/gs] float32 = 1/scale (quantize.py:154) ; zero_out [N*K/gs] float32
  *   info_out   int32[2] on the device: {iterations run, stop iteration index}  (may be NULL)
- * The solver runs in float32 — the reference's CPU precision (optimize.py:231); results equal the
- * reference's CPU path (see DESIGN.md for the two documented rounding caveats).
+ * The solver runs in float32 — the reference's CPU precision (optimize.py:231); packed levels, zero and scale equal the
+ * reference's CPU path bit for bit (the reference's GPU path solves in fp16 and differs from its own CPU result).
  * ------------------------------------------------------------------------------------------- */
 size_t hqq_hip_quantize_workspace_bytes(int64_t numel, int64_t group_size, int iters);
 int hqq_hip_quantize(const void* W, int w_dtype, int64_t numel, int64_t group_size, int max_v, int pack_bits,
