@@ -18,6 +18,9 @@ constexpr int GV_KSTEP = 1024;            // k covered by one wave load instruct
 #endif
 constexpr int GV_U = GV_U_LOADS;          // load instructions per unit
 constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
+#ifndef GV_RING_UNITS
+#define GV_RING_UNITS 0   // > 0: bs = 1 launches use the ring kernel with this many 1-KiB units in flight (lab switch; 0: the ping-pong kernel everywhere — measured faster, see gemv_ring_kernel)
+#endif
 constexpr int GV_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int GV_LDS_MAX = 144 * 1024;    // x staging budget per workgroup
 constexpr int GV_EXACT_ROWWISE_MAX_M = 4;  // EXACT mode: 2*per MFMAs per x row and KiB; beyond this the tile kernel (gemv_mfma.hip) takes over
