@@ -370,11 +370,36 @@ def main():
 
     per_slab = 1 if nbits == 3 else 8 // nbits
 
+    # One activation row (the decode headline): slab s of a layer's full output row is the rank-major concatenation of every rank's run s
+    # (hqq_amd.shard.gather_columns), so per-slab all-gathers land the outputs STRAIGHT in the reference's column order — one coalesced
+    # collective per exchange point where the backend can (RCCL: one grouped launch), no un-permute kernels.  Probed once below; a backend
+    # that cannot falls back to the shard-wide gather + un-permute.
+    xmode = {"coalesced": False}
+
+    def exchange_rows1(grp, coalesce):
+        cm = getattr(dist, "_coalescing_manager", None) if coalesce else None
+
+        def issue():
+            for j, n in enumerate(grp):
+                nl = dimN[n]
+                N_, n1 = world * nl, nl // per_slab
+                src, dst = out_local[grp][j].reshape(-1), out_full[grp][j].reshape(-1)
+                for s_ in range(per_slab):
+                    dist.all_gather_into_tensor(dst[s_ * (N_ // per_slab):(s_ + 1) * (N_ // per_slab)], src[s_ * n1:(s_ + 1) * n1])
+        if cm is not None:
+            with cm(device=dev):
+                issue()
+        else:
+            issue()
+
     def exchange(grp):
         """all-gather the group's shard outputs, then restore the reference's column order: rank r's packed-row block holds,
         per slab s, output columns s * N/per + [r * n', (r + 1) * n'), n' = N / (per * P)  (hqq_amd.shard.unpermute,
         the function tests/test_shard.py checks against whole layers, writing into a preallocated buffer here)"""
         from hqq_amd import shard
+        if M == 1 and xmode.get("rows1"):
+            exchange_rows1(grp, xmode["coalesced"])
+            return
         dist.all_gather_into_tensor(out_gath[grp], out_flat[grp])
         tot = sum(dimN[n] for n in grp)
         g = out_gath[grp].view(world, M * tot)
@@ -446,6 +471,24 @@ def main():
                 sopts.append(group_opts(Ls))
         return ops.LaunchChain(stages, nbits, opts=sopts)
 
+    xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")   # auto: coalesced per-slab gathers on RCCL, else the shard-wide gather; rows1: force per-slab (one by one off RCCL); gather: legacy
+    if world > 1 and M == 1 and xenv != "gather":
+        # probe the per-slab exchange once, eagerly, on every rank.  Only the COALESCED form (one launch per exchange point) is worth having:
+        # issued one by one it is `per` times as many collectives as the shard-wide gather
+        for coalesce in ((True,) if dist.get_backend() == "nccl" else ((False,) if xenv == "rows1" else ())):
+            try:
+                for grp in EXCHANGE_GROUPS:
+                    exchange_rows1(grp, coalesce)
+                torch.cuda.synchronize()
+                ok = torch.ones(1, device=dev)
+            except Exception as e:   # noqa: BLE001
+                if rank == 0:
+                    print(f"[bench] per-slab exchange (coalesce={coalesce}) not available: {type(e).__name__}: {e}", file=sys.stderr)
+                ok = torch.zeros(1, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank must agree on the mode
+            if float(ok) > 0:
+                xmode["rows1"], xmode["coalesced"] = True, coalesce
+                break
     use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0" and (world == 1 or dist.get_backend() == "nccl")
     engine = a.engine and decode and world == 1 and M == 1 and a.dtype == "f16" and nbits in (8, 4, 2) and a.gemv_mode != "factored"
     chained = a.chain and not engine and decode and world == 1 and M <= 4 and a.dtype == "f16" and nbits in (8, 4, 2) and a.gemv_mode != "factored" and S == 1
@@ -505,7 +548,13 @@ def main():
         if world > 1:   # the exchange alone (same graph structure without the GEMV launches)
             xrun, _ = _graphed(lambda: step(only_exchange=True), use_graph, rank)
             xs_, _ = _timed(xrun, max(5, a.steps // 2), 3, dist, dev)
-            out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5), "all_gathers_per_step": stages_per_step,
+            rows1 = bool(M == 1 and xmode.get("rows1"))
+            n_slab_gathers = nblocks * len(BLOCK) * per_slab
+            out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5),
+                               "mode": ("per-slab all-gathers straight into the reference's column order" + (", one coalesced RCCL launch per exchange point" if xmode["coalesced"] else ", issued one by one")) if rows1 else "one all-gather of the shard outputs per exchange point + un-permute copies",
+                               "collective_launches_per_step": (stages_per_step if xmode["coalesced"] else n_slab_gathers) if rows1 else stages_per_step,
+                               "all_gathers_per_step": n_slab_gathers if rows1 else stages_per_step,
+                               "unpermute_kernels_per_step": 0 if rows1 else nblocks * len(BLOCK),
                                "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK),
                                "note": "all-gather + un-permute of every exchange point, timed without the GEMV launches"}
             if strong and not a.no_single_gpu_reference:

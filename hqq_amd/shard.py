@@ -53,6 +53,34 @@ def unpermute(y_gathered: Tensor, N: int, nbits: int, world: int) -> Tensor:
     return y_gathered.reshape(P, M, per, n1).permute(1, 2, 0, 3).reshape(M, N)
 
 
+def gather_columns(y_loc: Tensor, out_full: Tensor, N: int, nbits: int, group=None, coalesce: bool = True) -> Tensor:
+    """All-gather ONE activation row straight into the reference's column order — no un-permute afterwards.
+
+    y_loc [1, N/P] is this rank's output in its local order (slab-major: `per` runs of n' = N/(per*P) columns); out_full [1, N].  Slab s of
+    the full row, columns [s*N/per, (s+1)*N/per), is the rank-major concatenation of every rank's run s — exactly what an all-gather of
+    that run into that slice produces.  So one all-gather per slab, issued as ONE coalesced collective where the backend can (RCCL: a
+    single grouped launch), replaces the gather of the whole shard + a permuting copy kernel.  One row only: with M > 1 rows a slab's
+    columns are strided in memory (use the shard-wide gather + `unpermute` there)."""
+    import torch.distributed as dist
+    if y_loc.numel() * dist.get_world_size(group) != N or out_full.numel() != N:
+        raise ValueError("hqq_amd: gather_columns takes one activation row: y_loc [1, N/P], out_full [1, N]")
+    per = 1 if nbits == 3 else ops.PER[nbits]
+    world = dist.get_world_size(group)
+    n1 = N // (per * world)
+    src, dst = y_loc.reshape(-1), out_full.reshape(-1)
+
+    def issue():
+        for s_ in range(per):
+            dist.all_gather_into_tensor(dst[s_ * (N // per):(s_ + 1) * (N // per)], src[s_ * n1:(s_ + 1) * n1], group=group)
+    cm = getattr(dist, "_coalescing_manager", None) if (coalesce and per > 1) else None
+    if cm is not None and dist.get_backend(group) == "nccl":
+        with cm(group=group, device=y_loc.device):
+            issue()
+    else:   # (gloo and friends: the same gathers one by one)
+        issue()
+    return out_full
+
+
 class ShardedHQQForward:
     """One rank's share of a column-sharded layer.  forward(x) = local fused forward + one all-gather over the process
     group (RCCL on GPUs; any torch.distributed backend works, the CPU tests use gloo with a stand-in local op)."""
@@ -69,6 +97,9 @@ class ShardedHQQForward:
     def forward(self, x: Tensor) -> Tensor:
         y_loc = self._local(x).reshape(-1, self.n_loc).contiguous()
         M = y_loc.shape[0]
+        if M == 1:   # decode: straight into the reference's column order, no un-permute
+            full = torch.empty((1, self.N), dtype=y_loc.dtype, device=y_loc.device)
+            return gather_columns(y_loc, full, self.N, self.nbits, self.group).reshape(*x.shape[:-1], self.N)
         out = torch.empty((self.world * M, self.n_loc), dtype=y_loc.dtype, device=y_loc.device)   # rank-major concatenation
         self.dist.all_gather_into_tensor(out, y_loc, group=self.group)
         return unpermute(out.view(self.world, M, self.n_loc), self.N, self.nbits, self.world).reshape(*x.shape[:-1], self.N)

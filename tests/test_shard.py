@@ -83,6 +83,9 @@ def _worker(rank, world, port, nbits, q):
         sh = shard.ShardedHQQForward(Wq, scale, zero, bias, N, K, gs, nbits, local_forward=local)
         y = sh(x)
         ok = torch.allclose(y, x @ Wfull.t() + bias, atol=1e-5) and sh.n_loc == N // world and tuple(y.shape) == (M, N)
+        # one activation row: per-slab gathers straight into the reference's column order (shard.gather_columns), no un-permute
+        y1 = sh(x[:1])
+        ok = ok and tuple(y1.shape) == (1, N) and torch.allclose(y1, x[:1] @ Wfull.t() + bias, atol=1e-5)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

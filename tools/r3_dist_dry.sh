@@ -1,0 +1,9 @@
+#!/bin/bash
+# 2-rank dry run of the N > 1 bench path on ONE GPU (gloo carries the exchange; both ranks launch kernels on GPU 0): plumbing, not a measurement
+mkdir -p gpurun_out/r3
+export HQQ_BENCH_ONE_GPU=1 HQQ_BENCH_BACKEND=gloo HQQ_BENCH_EXCHANGE=rows1
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --blocks 2 --steps 3 --warmup 1 --random-codes --no-single-gpu-reference > gpurun_out/r3/dist_dry.json 2> gpurun_out/r3/dist_dry.err
+echo rc=$?; tail -n 3 gpurun_out/r3/dist_dry.err; python -c "
+import json; d=json.loads(open('gpurun_out/r3/dist_dry.json').read().strip().split('\n')[-1]); print(d['ms_per_step'], d['config']['parallelism'][:60]); print(d['exchange'])"
+HQQ_BENCH_EXCHANGE=gather timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --blocks 2 --steps 3 --warmup 1 --random-codes --no-single-gpu-reference 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step']); print(d['exchange'])"
