@@ -129,326 +129,25 @@ struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the r
 // WPG: waves per workgroup.  4 (x 4 workgroups per CU) everywhere, except single layers of at most one packed row per wave of an
 // 8 x 2 grid (o / down of a 7B block: 2048 packed rows), where 8 (x 2 per CU) measured -7 % per launch (fewer workgroups to dispatch and
 // half as many copies of x staged per CU; grouped launches lose 11 % with it: profiles/r03_ab_w8x2.txt)
-template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false, int WPG = GV_WAVES>
-__global__ __launch_bounds__(WPG * 64) void gemv_f16_kernel(GV_IN_PARAMS, const GvOut o) {
-  // (GvIn arrives as plain scalar parameters: values, not memory — passed as a struct the compiler turned selects of its loaded
-  //  pointers into loads of selected addresses and staged the loads behind each other: dependent scalar-load latencies in front of
-  //  the first weight request)
-  const GvIn a = GV_IN_PACK;
-  // all of them in ONE batch of scalar loads before anything else (the asm only needs them present: left alone the compiler fetched
-  // x and K first, requested x, and then fetched the rest — a second cold scalar-cache miss in front of the first weight request)
-#define GV_PIN_ARGS                                                                                                                           \
-  asm volatile("" ::"s"(Wq0), "s"(Wq1), "s"(Wq2), "s"(Wq3), "s"(sc0), "s"(sc1), "s"(sc2), "s"(sc3), "s"(ze0), "s"(ze1), "s"(ze2), "s"(ze3), "s"(N0), \
-               "s"(N1), "s"(N2), "s"(N3), "s"(pe0), "s"(pe1), "s"(pe2), "s"(pe3), "s"(x_), "s"(K_), "s"(gs_), "s"(G_), "s"(total_), "s"(ksplit_), "s"(gridDim.x))
-#ifndef GV_LAB_PRELOAD
-  GV_PIN_ARGS;
-#endif
-  static_assert(EXACT || !BF16, "bf16 is served by the exact-weights path only");
-  static_assert(!SUB || (EXACT && !BF16), "the subnormal-field sequence is an fp16 exact-weights variant");
-  constexpr int PER = 8 / NBITS;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
-
-#ifdef GV_LAB_TS
-  unsigned long long t_[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 100 MHz real-time counter: 10 ns ticks, comparable across CUs
-  t_[0] = __builtin_amdgcn_s_memrealtime();
-#define GV_TS(i) if (t_[i] == 0) t_[i] = __builtin_amdgcn_s_memrealtime();   // first occurrence
-#else
-#define GV_TS(i)
-#endif
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the row bookkeeping in SGPRs
-  const int K = a.K, gs = a.gs, G = a.G;
-  const int nsteps = (K + GV_KSTEP - 1) / GV_KSTEP;   // wave load instructions per row
-  const int nunits = (nsteps + GV_U - 1) / GV_U;
-  const int planes_per_m = nsteps * 2 * 64;
-  const bool ksplit = a.ksplit != 0;                   // workgroup-uniform
-  const int stride = ksplit ? gridDim.x : gridDim.x * WPG;
-  const int ustep = ksplit ? WPG : 1, ubase = ksplit ? wave : 0;
-  const int total = a.total_prow;
-
-  // Every call issues exactly GV_U weight loads + 2*PER (GS64) meta loads, valid or not, so that the compiler can count
-  // them: the wait for one unit is then an exact s_waitcnt vmcnt(<loads of the following unit>), never vmcnt(0).
-  // A dead unit (past the wave's last one) reads the first bytes of the layer in every lane: one cache line, the same for every
-  // wave of the launch (it stays in L2).
-  // Buffer loads: wave-uniform descriptor (the layer's base pointer) + scalar row offset + one 32-bit lane offset — no 64-bit
-  // VALU address arithmetic (global loads with a per-lane group index cost ~12 VALU instructions per unit in 64-bit adds and
-  // multiplies, a tenth of this kernel's VALU work).  Offsets are bytes < 4 GiB per layer (checked on the host).
-  auto issue = [&](Unit<PER, GS64>& un, const LayerCtx& c, int prow, int unit, bool live) {
-    const int p = live ? prow - c.row0 : 0;                    // packed row inside the layer
-    const int rows_per_slab = live ? c.N / PER : 0;
-    const int Glive = live ? G : 0, Klive = live ? K : 0;      // scalar selects: a dead unit's lanes all fall back to offset 0
-    const __amdgpu_buffer_rsrc_t rw = buffer_rsrc(c.Wq), rz = buffer_rsrc(c.zero), rs = buffer_rsrc(c.scale);
-    // meta first: the consumer needs it before the first weight vector (loads return in issue order)
-    if constexpr (GS64) {
-      int g = unit * (GV_UNIT / 64) + lane;
-      g = g < Glive ? g : 0;
-#pragma unroll
-      for (int s = 0; s < PER; ++s) {
-        const uint32_t row_off = static_cast<uint32_t>(p + s * rows_per_slab) * static_cast<uint32_t>(G) * 2u;   // wave-uniform
-        un.z[s] = __builtin_amdgcn_raw_buffer_load_b16(rz, g * 2, row_off, 0);
-        un.sc[s] = __builtin_amdgcn_raw_buffer_load_b16(rs, g * 2, row_off, 0);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < GV_U; ++u) {
-        int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
-        k0 = k0 < Klive ? k0 : 0;
-        const int goff = (k0 / gs) * 2;
-#pragma unroll
-        for (int s = 0; s < PER; ++s) {
-          const uint32_t row_off = static_cast<uint32_t>(p + s * rows_per_slab) * static_cast<uint32_t>(G) * 2u;
-          un.z[u * PER + s] = __builtin_amdgcn_raw_buffer_load_b16(rz, goff, row_off, 0);
-          un.sc[u * PER + s] = __builtin_amdgcn_raw_buffer_load_b16(rs, goff, row_off, 0);
-        }
-      }
-    }
-    const uint32_t wrow_off = static_cast<uint32_t>(p) * static_cast<uint32_t>(K);
-#pragma unroll
-    for (int u = 0; u < GV_U; ++u) {
-      // lanes past K (last step of a row) and whole steps past the row re-read the row start: their x is zero in LDS
-      // (and its chunk sum), so they add exactly 0
-      int k0 = unit * GV_UNIT + u * GV_KSTEP + lane * 16;
-      k0 = k0 < Klive ? k0 : 0;
-      un.w[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, k0, wrow_off, 2 /* nt: streamed once */);
-    }
-  };
-
-  // next unit of this wave: same row, or the wave's next row (re-selecting the layer when the row leaves it)
-  auto advance = [&](int& p, int& u, LayerCtx& c) {
-    u += ustep;
-    if (u >= nunits) {
-      u = ubase;
-      p += stride;
-      if (p >= c.end && p < total) c = select_layer(a, p);
-    }
-  };
-
-  // ---- prologue: the workgroup's first pass of x loads goes out first, then the first unit of this wave's first row, then x is
-  //      written to LDS.  (Measured and rejected, tools/gemv_lab.hip: the first unit in front of the x loads — loads return in
-  //      request order, the staging barrier then waits for the weights too: +5 % per launch; the first TWO units in front of the
-  //      staging — the second is requested 0.5 us earlier, but the burst only queues in the memory system, every wave's first unit
-  //      arrives later and so does the barrier: +5-8 %.) ----
-  float* xsum_lds = reinterpret_cast<float*>(smem + static_cast<size_t>(M) * planes_per_m * 16);   // [M][nsteps][64], FACTORED only
-  const int chunks_per_m = nsteps * 64;          // 16-k lane chunks per row of x, padded to whole steps
-  // (m, j) = (row of x, 16-k chunk j = step * 64 + lane); no division on the way to the first loads
-  // buffer loads bounded by the row (K % 16 == 0): chunks past K come back as zeros from the hardware's range check — no branch
-  // and no zero-initialised registers on the way to the first requests
-  auto load_chunk = [&](int m, int j, u32x4& v0, u32x4& v1) {
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.x + static_cast<int64_t>(m) * K), 0, K * 2, 0x00020000);
-    v0 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32, 0, 0);
-    v1 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32 + 16, 0, 0);
-  };
-  auto store_chunk = [&](int m, int j, const u32x4& v0, const u32x4& v1) {
-    if (j >= chunks_per_m) return;
-    const int it = j >> 6, ln = j & 63;
-    xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
-    xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
-    if constexpr (!EXACT) {
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const half2_t h0 = as_h2(v0[i]), h1 = as_h2(v1[i]);
-        sum += (static_cast<float>(h0.x) + static_cast<float>(h0.y)) + (static_cast<float>(h1.x) + static_cast<float>(h1.y));
-      }
-      xsum_lds[m * chunks_per_m + j] = sum;
-    }
-  };
-  GV_TS(7)
-  u32x4 xv0, xv1;
-  load_chunk(0, tid, xv0, xv1);
-  __builtin_amdgcn_sched_barrier(0);   // x in front of the weights: loads return in request order, and the staging barrier waits for x only
-
-  int prow = ksplit ? blockIdx.x : blockIdx.x * WPG + wave;
-  int unit = ubase;
-  // waves with no row at all (tiny layers) still run the prologue on row total-1 so that the load counts stay uniform
-  const bool live0 = prow < total;
-  prow = live0 ? prow : total - 1;
-#ifdef GV_LAB_PRELOAD
-  LayerCtx lc{a.Wq[0], a.scale[0], a.zero[0], a.N[0], 0, a.prow_end[0]};   // preloaded: a wave of layer 0 requests without waiting for the rest
-  if (prow >= a.prow_end[0]) {
-    asm volatile("");   // (keeps this a branch: converted to selects it would wait for every argument on both paths)
-    lc = select_layer(a, prow);
-  }
-#else
-  LayerCtx lc = select_layer(a, prow);
-#endif
-  Unit<PER, GS64> ua, ub;
-  issue(ua, lc, prow, unit, live0);
-  GV_TS(1)
-#ifdef GV_LAB_PRELOAD
-  GV_PIN_ARGS;
-#endif
-
-  store_chunk(0, tid, xv0, xv1);
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-    for (int j = tid + (m == 0 ? WPG * 64 : 0); j < chunks_per_m; j += WPG * 64) {
-      load_chunk(m, j, xv0, xv1);
-      store_chunk(m, j, xv0, xv1);
-    }
-  GV_TS(2)
-  __syncthreads();
-  GV_TS(3)
-
-  // FACTORED: one fp32 partial per (x row, slab); EXACT: one 16x16 MFMA tile (4 VGPRs) per (x row, slab)
-  using acc_t = std::conditional_t<EXACT, f32x4, float>;
-  acc_t acc[M][PER];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int s = 0; s < PER; ++s) {
-      if constexpr (EXACT) acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-      else acc[m][s] = 0.f;
-    }
-  uint32_t magic;
-  asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));   // opaque to the optimiser: stays in a VGPR
-
-  // (the issuing side may already have moved to the next layer: a finished row looks its layer up again)
-  auto consume = [&](const Unit<PER, GS64>& cur, int prow, int unit) {
-    if constexpr (EXACT) {
-#pragma unroll
-      for (int u = 0; u < GV_U; ++u) {
-        const int step = unit * GV_U + u;
-        uint32_t zs[PER];
-#pragma unroll
-        for (int s = 0; s < PER; ++s) {
-          if constexpr (GS64) {
-            uint32_t mine = cur.z[s] | (cur.sc[s] << 16);
-            if constexpr (SUB) mine = scale_meta_sub<NBITS>(mine, s);
-            zs[s] = __builtin_amdgcn_ds_bpermute((u * 16 + (lane >> 2)) << 2, mine);
-          } else {
-            zs[s] = cur.z[u * PER + s] | (cur.sc[u * PER + s] << 16);
-            if constexpr (SUB) zs[s] = scale_meta_sub<NBITS>(zs[s], s);
-          }
-        }
-        if (step < nsteps) {
-          // lanes past K see zero x (padded in LDS) and a finite re-read weight: they add exactly 0
-          using frag_t = std::conditional_t<BF16, bf16x8_t, h8_t>;
-          frag_t b0[M], b1[M];
-#pragma unroll
-          for (int m = 0; m < M; ++m) {
-            b0[m] = __builtin_bit_cast(frag_t, xs[m * planes_per_m + (step * 2 + 0) * 64 + lane]);
-            b1[m] = __builtin_bit_cast(frag_t, xs[m * planes_per_m + (step * 2 + 1) * 64 + lane]);
-          }
-          if constexpr (BF16) SlabExactBF16<NBITS, M, 0, PER>::run(cur.w[u], zs, b0, b1, acc, magic);
-          else SlabExact<NBITS, M, 0, PER, SUB>::run(cur.w[u], zs, b0, b1, acc, magic);
-        }
-      }
-    } else {
-    float c1o[PER], c2o[PER];   // GS64: constants of the group this lane fetched (unit's first group + lane)
-    if constexpr (GS64) GroupConst<NBITS, 0, PER>::run(cur.z, cur.sc, c1o, c2o);
-#pragma unroll
-    for (int u = 0; u < GV_U; ++u) {
-      const int step = unit * GV_U + u;
-      float c1[PER], c2[PER];
-      if constexpr (GS64) {
-        const int src = (u * 16 + (lane >> 2)) << 2;   // the lane that fetched this lane's group
-#pragma unroll
-        for (int s = 0; s < PER; ++s) {
-          c1[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c1o[s])));
-          c2[s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c2o[s])));
-        }
-      } else {
-        GroupConst<NBITS, 0, PER>::run(cur.z + u * PER, cur.sc + u * PER, c1, c2);
-      }
-      if (step < nsteps) {
-        half2_t xr[M][8];
-        float xsum[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const u32x4 p0 = xs[m * planes_per_m + (step * 2 + 0) * 64 + lane];
-          const u32x4 p1 = xs[m * planes_per_m + (step * 2 + 1) * 64 + lane];
-          xsum[m] = xsum_lds[(m * nsteps + step) * 64 + lane];
-          xr[m][0] = as_h2(p0.x); xr[m][1] = as_h2(p0.y); xr[m][2] = as_h2(p0.z); xr[m][3] = as_h2(p0.w);
-          xr[m][4] = as_h2(p1.x); xr[m][5] = as_h2(p1.y); xr[m][6] = as_h2(p1.z); xr[m][7] = as_h2(p1.w);
-        }
-        // lanes past K see zero x and zero xsum (padded in LDS) and finite constants: they add exactly 0
-        SlabLoop<NBITS, M, 0, PER>::run(cur.w[u], c1, c2, xr, xsum, acc, magic);
-      }
-    }
-    }
-    // ---- row finished: one wave reduction per output row; lane (m * PER + s) writes its value ----
-    if (unit + ustep >= nunits) {
-      const OutCtx oc = select_out(a, o, prow);
-      const int p = prow - oc.row0;
-      const int rows_per_slab = oc.N / PER;
-      float mine = 0.f;
-#pragma unroll
-      for (int m = 0; m < M; ++m)
-#pragma unroll
-        for (int s = 0; s < PER; ++s) {
-          float v;
-          if constexpr (EXACT) {
-            v = diag_sum(acc[m][s]);   // D[i][i] only (decode_common.h)
-            acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-          } else {
-            v = wave_sum(acc[m][s]);
-            acc[m][s] = 0.f;
-          }
-          mine = (lane == m * PER + s) ? v : mine;
-        }
-      if (ksplit) {   // the row's K range was shared by the workgroup's waves: add their partial sums (fixed order) in wave 0
-        float* red = reinterpret_cast<float*>(smem + a.red_off);
-        if (lane < M * PER) red[wave * (M * PER) + lane] = mine;
-        __syncthreads();
-        if (wave == 0 && lane < M * PER) {
-          mine = red[lane];
-#pragma unroll
-          for (int w = 1; w < WPG; ++w) mine += red[w * (M * PER) + lane];
-        }
-        __syncthreads();
-        if (wave != 0) return;
-      }
-      if (lane < M * PER) {
-        const int m = lane / PER, s = lane - m * PER;
-        const int n = p + s * rows_per_slab;
-        // `out += bias` on the rounded matmul result (quantize.py:896-897): two roundings in the compute dtype
-        if constexpr (BF16) {
-          uint16_t o = f32_to_bf16(mine);
-          if (oc.bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(reinterpret_cast<const uint16_t*>(oc.bias)[n]));
-          reinterpret_cast<uint16_t*>(oc.y)[static_cast<int64_t>(m) * oc.N + n] = o;
-        } else {
-          half_t o = static_cast<half_t>(mine);
-          if (oc.bias) o = o + oc.bias[n];
-          oc.y[static_cast<int64_t>(m) * oc.N + n] = o;
-        }
-      }
-    }
-  };
-
-  // ---- ping-pong over the wave's units: request unit i+1, then consume unit i; no register copies.  Every iteration has the same
-  //      shape and the loop ONE exit, at the bottom: a unit past the wave's last one is still "requested" (one cache line, see
-  //      issue()) and simply not consumed.  So each consume has exactly one unit's loads behind it on every path: its wait is
-  //      s_waitcnt vmcnt(<that unit>), and nothing waits in front of a request.  (Until round 2 the last unit had its own path —
-  //      consume, then leave from the middle of the loop.  The structurised control flow ran that exit through the loop latch; at the
-  //      loop header the other register set then looked freshly requested on one incoming edge and the compiler drained vmcnt to 0
-  //      in front of every second request, and in front of the others it waited for the previous unit's meta loads to mask their
-  //      16-bit phis: about ONE unit in flight per wave instead of two.) ----
-  if (live0) {
-    bool more;
-    do {
-      int p1 = prow, u1 = unit;
-      advance(p1, u1, lc);
-      const bool live1 = p1 < total;
-      issue(ub, lc, live1 ? p1 : prow, u1, live1);
-      GV_TS(4)
-      consume(ua, prow, unit);
-      GV_TS(5)
-      int p2 = p1, u2 = u1;
-      advance(p2, u2, lc);
-      more = p2 < total;   // (p1 >= total implies p2 >= total)
-      issue(ua, lc, more ? p2 : (live1 ? p1 : prow), u2, more);
-      if (live1) consume(ub, p1, u1);
-      prow = p2;
-      unit = u2;
-    } while (more);
-  }
-#ifdef GV_LAB_TS
-  GV_TS(6)
-  if (lane == 0 && a.ts) { const int wg = blockIdx.x * WPG + wave; for (int i = 0; i < 8; ++i) a.ts[wg * 8 + i] = t_[i]; }
-#endif
-}
+#define GV_KERNEL_NAME gemv_f16_kernel
+#define GV_KERNEL_EARLY_B 0
+#define GV_KERNEL_XPASS2 0
+#include "gemv_kernel.inc"
+#undef GV_KERNEL_NAME
+#undef GV_KERNEL_XPASS2
+#define GV_KERNEL_NAME gemv_f16_xp2_kernel
+#define GV_KERNEL_XPASS2 1
+#include "gemv_kernel.inc"
+#undef GV_KERNEL_NAME
+#undef GV_KERNEL_XPASS2
+#undef GV_KERNEL_EARLY_B
+#define GV_KERNEL_NAME gemv_f16_wide_kernel
+#define GV_KERNEL_EARLY_B 1
+#define GV_KERNEL_XPASS2 0
+#include "gemv_kernel.inc"
+#undef GV_KERNEL_NAME
+#undef GV_KERNEL_EARLY_B
+#undef GV_KERNEL_XPASS2
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The ring variant of the streaming loop (round 3; a LAB SWITCH, off by default: GV_RING_UNITS): units of ONE KiB (one 16-byte load per
@@ -747,13 +446,22 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
     if (!(nunits >= WPG && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * WG_PER_CU * WPG))
       return launch_gemv_ring<NBITS, M, SUB, WPG>(args, st);
   }
+#ifndef GV_WIDE_EARLY_B
+#define GV_WIDE_EARLY_B 0   // lab switch: measured +12 % on a 4096 x 4096 layer, +4 % on 4096 x 11008 (the burst delays the x loads and the barrier, as in grouped launches)
+#endif
   auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>;
+  if constexpr (WPG == 8 && GV_WIDE_EARLY_B) kern = gemv_f16_wide_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>;
+  // a row of x longer than one pass of the workgroup's threads (the 11008-wide down projection): the variant that requests the first two
+  // passes together (4096 x 11008: 8.3 -> 8.0 us; compiled as its own kernel so that the others keep their code, gemv_kernel.inc)
+  int variant = 0;   // which compilation of the kernel text this launch uses (per-kernel caches below)
+  if constexpr (EXACT && !BF16 && GS64) { if (nsteps * 64 > WPG * 64) { kern = gemv_f16_xp2_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>; variant = 1; } }
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
   per_cu = per_cu > WG_PER_CU ? WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
   {
     // registers bound the residency too (M = 4 exact needs 152 VGPRs: three workgroups per CU, not four): a persistent grid larger
     // than what is resident runs its surplus workgroups as a second round behind the first
-    static int by_regs = 0;   // per instantiation
+    static int by_regs_v[2] = {0, 0};   // per instantiation and kernel variant
+    int& by_regs = by_regs_v[variant];
     if (by_regs == 0) {
       hipFuncAttributes fa;
       by_regs = WG_PER_CU;
@@ -776,8 +484,8 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   const int tiles = a.ksplit ? a.total_prow : (a.total_prow + WPG - 1) / WPG;
   const int grid = tiles < cap ? tiles : cap;
   if (lds > 64 * 1024) {
-    static LdsRaised raised;   // per instantiation (and device)
-    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), GV_LDS_MAX, "hqq_hip_gemv")) return rc;
+    static LdsRaised raised[2];   // per instantiation, kernel variant (and device)
+    if (const int rc = raise_lds_limit(raised[variant], reinterpret_cast<const void*>(kern), GV_LDS_MAX, "hqq_hip_gemv")) return rc;
   }
   GvIn in;
   GvOut out;
