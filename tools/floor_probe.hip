@@ -125,18 +125,41 @@ int main() {
            name, ms, per_block * nblocks / (ms * 1e-3) / 1e9, alg_bytes / (ms * 1e-3) / 8e12, ms * 1e3 / (4 * nblocks));
     hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(st);
   };
-  for (int rep = 0; rep < 2; ++rep) {
-  run("4x4, 2 units x 2 KiB, stream only", stream_kernel<false, 2, 2>, 256, 4, 0);
-  run("4x4, 3 units x 1 KiB, stream only", stream_kernel<false, 3, 1>, 256, 4, 0);
+  run("4x4, 2 units x 2 KiB, stream only (the GEMV's shape)", stream_kernel<false, 2, 2>, 256, 4, 0);
+  run("4x4, 3 units x 1 KiB, stream only (best found)", stream_kernel<false, 3, 1>, 256, 4, 0);
   run("4x4, 2 x 2 KiB + x staging + 64 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 2, 64, 4>, 256, 4, 8704);
-  run("4x4, 3 x 2 KiB + x staging + 64 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 3, 2, 64, 4>, 256, 4, 8704);
-  run("4x4, 2 x 1 KiB + x staging + 64 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 1, 64, 4>, 256, 4, 8704);
   run("4x4, 3 x 1 KiB + x staging + 64 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 3, 1, 64, 2>, 256, 4, 8704);
-  run("4x4, 4 x 1 KiB + x staging + 64 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 4, 1, 64, 2>, 256, 4, 8704);
-  run("4x4, 3 x 1 KiB + x staging + 48 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 3, 1, 48, 2>, 256, 4, 8704);
-  run("4x4, 2 x 2 KiB + x staging + 48 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 2, 48, 4>, 256, 4, 8704);
-  run("4x4, 2 x 2 KiB + x staging + 32 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 2, 32, 4>, 256, 4, 8704);
-  run("4x4, 3 x 1 KiB + x staging + 32 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 3, 1, 32, 2>, 256, 4, 8704);
+  // ---- the metric's literal shape: one 4096 x 4096 int4 layer per launch (8.39 MB packed, 9.45 MB algorithmic), 32 dependent launches ----
+  {
+    const int rows = 2048, row_bytes = 4096, chain = 32;
+    auto run1 = [&](const char* name, auto kern, int threads, int wg_per_cu) {
+      hipStream_t st; hipStreamCreate(&st);
+      hipGraph_t g; hipGraphExec_t ge;
+      hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+      const int nw = threads / 64;
+      for (int i = 0; i < chain; ++i) {
+        const int tiles = (rows + nw - 1) / nw, cap = 256 * wg_per_cu, grid = tiles < cap ? tiles : cap;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, st, (const uint8_t*)(buf + static_cast<size_t>(i) * rows * row_bytes * 4), rows, row_bytes, (const _Float16*)x, y);
+      }
+      hipStreamEndCapture(st, &g);
+      hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      for (int w = 0; w < 5; ++w) hipGraphLaunch(ge, st);
+      hipStreamSynchronize(st);
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      hipEventRecord(e0, st);
+      const int reps = 50;
+      for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, st);
+      hipEventRecord(e1, st); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms * 1e3 / (reps * chain);
+      printf("one 4096x4096 layer per launch, %-40s %.2f us per launch   %.3f of 8 TB/s (9,453,568 algorithmic bytes)\n", name, us, 9453568.0 / (us * 1e-6) / 8e12);
+      hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(st);
+    };
+    run1("8 waves x 2/CU, 2 units x 2 KiB, stream only", stream_kernel<false, 2, 2>, 512, 2);
+    run1("4 x 4, 2 units x 2 KiB, stream only", stream_kernel<false, 2, 2>, 256, 4);
+    run1("8 x 2, 4 units x 1 KiB, stream only", stream_kernel<false, 4, 1>, 512, 2);
+    run1("4 x 4, 4 units x 1 KiB, stream only", stream_kernel<false, 4, 1>, 256, 4);
+    run1("16 x 1, 2 units x 2 KiB, stream only", stream_kernel<false, 2, 2>, 1024, 1);
   }
   return 0;
 }
