@@ -1,4 +1,6 @@
 """CPU tests of the host-side mirror of the reference interface: no kernel is launched here."""
+import os
+
 import pytest
 
 torch = pytest.importorskip("torch")
@@ -170,3 +172,31 @@ def test_patching_helpers_of_the_reference():
     patch_lora_inference(lora)
     x = torch.randn(3, 8)
     assert torch.allclose(lora.forward_lora(x), (x @ lora.lora_A @ lora.lora_B) * 0.5)
+
+
+def test_set_gemv_mode_combines_with_a_layers_own_option_bits():
+    """ops.layer_opts: a layer passes its meta-dependent bits (0 / OPT_META_SCALABLE) unless set_gemv_mode(GEMV_FACTORED) is in force — then the
+    factored arithmetic for every layer, and the three-op bit (an exact-rebuild variant) is dropped (advisor finding, round 2: the switch
+    used to be a silent no-op for layer forwards)"""
+    from hqq_amd import ops
+    assert ops.get_gemv_mode() == ops.GEMV_EXACT
+    assert ops.layer_opts(0) == 0 and ops.layer_opts(ops.OPT_META_SCALABLE) == ops.OPT_META_SCALABLE
+    try:
+        ops.set_gemv_mode(ops.GEMV_FACTORED)
+        assert ops.layer_opts(0) == ops.OPT_FACTORED and ops.layer_opts(ops.OPT_META_SCALABLE) == ops.OPT_FACTORED
+    finally:
+        ops.set_gemv_mode(ops.GEMV_EXACT)
+    assert ops.layer_opts(ops.OPT_META_SCALABLE) == ops.OPT_META_SCALABLE
+
+
+def test_chain_link_struct_matches_the_header():
+    """hqq_hip_chain_link (include/hqq_hip.h) as ctypes sees it: three pointers and two uint32 — 32 bytes, fields in the header's order"""
+    import ctypes
+    import re
+    from hqq_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hqq_hip.h")).read()
+    body = re.search(r"typedef struct hqq_hip_chain_link \{(.*?)\} hqq_hip_chain_link;", hdr, re.S).group(1)
+    names = re.findall(r"(\w+);", body)
+    assert names == ["wait", "signal", "status", "wait_arrivals", "spin_limit"]
+    assert [f[0] for f in ops._ChainLink._fields_] == names and ctypes.sizeof(ops._ChainLink) == 32
+    assert int(re.search(r"#define HQQ_CHAIN_COUNTER_BYTES (\d+)", hdr).group(1)) == ops.CHAIN_COUNTER_BYTES

@@ -88,6 +88,40 @@ __global__ __launch_bounds__(1024) void stream_kernel(const uint8_t* __restrict_
   }
 }
 
+// the same with perfect balance: wave w streams the contiguous KiB range [w * n / W, (w + 1) * n / W) of the launch, whatever the rows
+template <int NF, int UL>
+__global__ __launch_bounds__(1024) void flat_kernel(const uint8_t* __restrict__ base, int rows, int row_bytes, const _Float16* __restrict__ x, _Float16* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6, W = gridDim.x * nw, w = blockIdx.x * nw + wave;
+  const long long total = (static_cast<long long>(rows) * row_bytes) / (UL * 1024);   // units of the launch
+  const long long u0 = total * w / W, u1 = total * (w + 1) / W;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+  u32x4 ring[NF][UL];
+  long long cur = u0;
+  auto issue = [&](u32x4 (&v)[UL], long long u) {
+    const uint32_t off = static_cast<uint32_t>((u < u1 ? u : u0) * (UL * 1024));
+#pragma unroll
+    for (int h = 0; h < UL; ++h) v[h] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16 + h * 1024, off, 2);
+  };
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { issue(ring[f], cur); ++cur; }
+  float acc = 0.f;
+  long long done = u0;
+  while (done < u1) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (done < u1) {
+#pragma unroll
+        for (int h = 0; h < UL; ++h) acc += __uint_as_float(ring[f][h].x & 0x3F800000u) + __uint_as_float(ring[f][h].y & 0x3F800000u) + __uint_as_float(ring[f][h].z & 0x3F800000u) + __uint_as_float(ring[f][h].w & 0x3F800000u);
+      }
+      ++done;
+      issue(ring[f], cur); ++cur;
+    }
+  }
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) y[w] = static_cast<_Float16>(acc);
+}
+
 int main() {
   struct L { int rows, row_bytes; };   // packed rows x bytes per packed row (int4: K bytes per packed row, 2 output rows each)
   const L blk[4] = {{6144, 4096}, {2048, 4096}, {11008, 4096}, {2048, 11008}};   // q|k|v, o, gate|up, down
@@ -127,6 +161,9 @@ int main() {
   };
   run("4x4, 2 units x 2 KiB, stream only (the GEMV's shape)", stream_kernel<false, 2, 2>, 256, 4, 0);
   run("4x4, 3 units x 1 KiB, stream only (best found)", stream_kernel<false, 3, 1>, 256, 4, 0);
+  run("4x4, 2 units x 2 KiB, stream only, PERFECT BALANCE (equal bytes per wave)", flat_kernel<2, 2>, 256, 4, 0);
+  run("4x4, 3 units x 1 KiB, stream only, perfect balance", flat_kernel<3, 1>, 256, 4, 0);
+  run("4x4, 4 units x 1 KiB, stream only, perfect balance", flat_kernel<4, 1>, 256, 4, 0);
   run("4x4, 2 x 2 KiB + x staging + 64 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 2, 64, 4>, 256, 4, 8704);
   run("4x4, 3 x 1 KiB + x staging + 64 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 3, 1, 64, 2>, 256, 4, 8704);
   // ---- the metric's literal shape: one 4096 x 4096 int4 layer per launch (8.39 MB packed, 9.45 MB algorithmic), 32 dependent launches ----
