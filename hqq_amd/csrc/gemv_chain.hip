@@ -16,12 +16,18 @@
 // half of an average 7B launch, all of a 4096 x 4096 layer) either rebuilt or in flight, and the predecessor's boundary, prologue,
 // fill and tail have been spent under somebody else's stream.
 //
+// Measured (round 3): correct and bit-identical, the overlap works as described — and the 7B stack takes 1.28-1.35 ms
+// per token against 1.00-1.06 for the stream-ordered launches, because the in-kernel hand-off below costs 4-6 us where a kernel boundary
+// costs 3.4 (store acknowledgement, arrival, poll, x: each a trip across the fabric).  An opt-in entry point, not the default path.
+//
 // Protocol (MI355X_MICROARCH.md "inter-workgroup visibility", recipe R1: write-through payload, drained, then the flag)
 //   producer  every output is stored write-through (sc1); a wave that has stored its last row drains (s_waitcnt vmcnt(0)) and takes
 //             a ticket in LDS; the workgroup's last wave adds 1 to one of GC_SHARDS device-scope arrival counters (one 128-byte line each)
 //   consumer  wave 0 of the first 16 workgroups polls the counters relaxed (sc1 loads, s_sleep between polls) until their sum reaches the
-//             producer's workgroup count and raises 16 copies of a flag; wave 0 of every other workgroup polls one copy; the other waves sleep at an LDS-only barrier (their weight loads stay in flight); then all
-//             waves read x with sc1 loads (they bypass this CU's L1) into LDS
+//             producer's workgroup count and raises 16 copies of a flag; wave 0 of every other workgroup polls one copy (all 512
+//             workgroups polling the eight counter lines saturated those lines' memory channels: 7 us per hand-off); the other waves
+//             sleep at an LDS-only barrier (their weight loads stay in flight); then all waves read x with sc1 loads (they bypass
+//             this CU's L1) into LDS
 //   bounded   a poll loop gives up after `spin_limit` rounds, writes the status word and runs on without waiting (wrong results, reported;
 //             never a hang)
 //   residency at most two links are alive at any time (link s + 2 is stream-ordered behind link s), and a link places at most HALF of what
