@@ -281,6 +281,25 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   int p = (panel - ly.panel0) * SK_ROWS + rg * 16 + r;         // packed row inside the layer
   p = p < rows_per_slab ? p : rows_per_slab - 1;               // ragged last panel: duplicate the last row (masked at the store)
   const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * K + c * 16;
+  // Whole-line loads (SK_LINE_LOADS, two blocks per wave): a wave instruction that reads 16 rows x 64 B touches HALF of sixteen 128-byte
+  // lines, and the other halves come with the next instruction — measured on pure loads (tools/floor_probe.hip, profiles/r03_floor_probe5.txt)
+  // that pattern streams 26 % slower than contiguous KiBs, 8 rows x 128 B only 4.5 % slower.  So load L0 = rows 0-7 and L1 = rows 8-15 of
+  // the row group, both blocks each — lane (r8 = lane & 7, h = (lane >> 3) & 1, c): 16 bytes of block h — and put the MFMA layout (lane =
+  // row + 16 c, one block per register set) back with one DPP move per dword at consume time: block 0 = L0 in lanes 0-7 | L1 rotated by 8
+  // in lanes 8-15 of every 16-lane row, block 1 the other way round.
+  // Measured in THIS kernel (tools/r3_lab_skinny.sh, bit-identical results): no difference (10.4 / 13.1 / 14.4 / 17.7 us either way) — the
+  // skinny GEMM is bound by its per-chunk barrier and the bytes it keeps in flight, not by the request pattern.  Lab switch, off.
+#ifndef SK_LINE_LOADS
+#define SK_LINE_LOADS 0
+#endif
+  constexpr bool LINES = SK_LINE_LOADS && SK_BPW == 2;
+  const uint8_t* wline[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int pl = (panel - ly.panel0) * SK_ROWS + rg * 16 + 8 * u + (lane & 7);
+    pl = pl < rows_per_slab ? pl : rows_per_slab - 1;
+    wline[u] = ly.Wq + static_cast<int64_t>(pl) * K + ((lane >> 3) & 1) * 64 + c * 16;
+  }
   SK_TS();   // 1: kernel arguments read, layer selected
 
   // x: the 256 threads fill the chunk's 8 MT fragments in LDS order — piece q = tid + 256 i is lane (q & 63) of fragment
@@ -325,7 +344,8 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #pragma unroll
     for (int jl = 0; jl < SK_BPW; ++jl) {
       const int j = hf * SK_BPW + jl;
-      const u32x4* src = live ? reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(chunk) * SK_KC + j * 64) : reinterpret_cast<const u32x4*>(a.x);
+      const uint8_t* at = LINES ? wline[jl] + static_cast<int64_t>(chunk) * SK_KC + hf * 128 : wrow + static_cast<int64_t>(chunk) * SK_KC + j * 64;
+      const u32x4* src = live ? reinterpret_cast<const u32x4*>(at) : reinterpret_cast<const u32x4*>(a.x);
       un.w[jl] = __builtin_nontemporal_load(src);
     }
   };
@@ -338,7 +358,15 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto consume = [&](const SkUnit& cur, int buf, int chunk) {
+  auto consume = [&](const SkUnit& raw, int buf, int chunk) {
+    SkUnit cur = raw;
+    if constexpr (LINES) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {   // row_ror:8 (0x128), banks 2-3 = lanes 8-15 of a row, banks 0-1 = lanes 0-7
+        cur.w[0][d] = __builtin_amdgcn_update_dpp(raw.w[0][d], raw.w[1][d], 0x128, 0xF, 0xC, false);
+        cur.w[1][d] = __builtin_amdgcn_update_dpp(raw.w[1][d], raw.w[0][d], 0x128, 0xF, 0x3, false);
+      }
+    }
 #pragma unroll
     for (int jl = 0; jl < SK_BPW; ++jl) {
       const int j = hf * SK_BPW + jl;

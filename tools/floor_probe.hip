@@ -122,6 +122,42 @@ __global__ __launch_bounds__(1024) void flat_kernel(const uint8_t* __restrict__ 
   if (lane == 0) y[w] = static_cast<_Float16>(acc);
 }
 
+// access patterns of the tile kernels (skinny.hip, gemm_pipe.hip), perfect balance, 1 KiB per wave instruction:
+//   PAT 0: 1 KiB contiguous   PAT 1: 16 rows x 64 B (an MFMA A fragment's natural load)   PAT 2: 8 rows x 128 B (whole lines)
+template <int NF, int PAT>
+__global__ __launch_bounds__(1024) void panel_kernel(const uint8_t* __restrict__ base, int rows, int row_bytes, const _Float16* __restrict__ x, _Float16* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6, W = gridDim.x * nw, w = blockIdx.x * nw + wave;
+  const long long total = (static_cast<long long>(rows) * row_bytes) / 1024;
+  const long long u0 = total * w / W, u1 = total * (w + 1) / W;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+  const int upp = PAT == 1 ? row_bytes / 64 : row_bytes / 128;
+  const uint32_t lane_off = PAT == 0 ? lane * 16u : PAT == 1 ? static_cast<uint32_t>(lane & 15) * row_bytes + (lane >> 4) * 16u : static_cast<uint32_t>(lane & 7) * row_bytes + (lane >> 3) * 16u;
+  u32x4 ring[NF];
+  long long cur = u0;
+  auto issue = [&](u32x4& v, long long u) {
+    const long long uu = u < u1 ? u : u0;
+    uint32_t off;
+    if (PAT == 0) off = static_cast<uint32_t>(uu * 1024);
+    else { const uint32_t p = static_cast<uint32_t>(uu / upp), kb = static_cast<uint32_t>(uu % upp); off = p * (PAT == 1 ? 16u : 8u) * row_bytes + kb * (PAT == 1 ? 64u : 128u); }
+    v = __builtin_amdgcn_raw_buffer_load_b128(rw, lane_off, off, 2);
+  };
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { issue(ring[f], cur); ++cur; }
+  float acc = 0.f;
+  long long done = u0;
+  while (done < u1) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (done < u1) acc += __uint_as_float(ring[f].x & 0x3F800000u) + __uint_as_float(ring[f].y & 0x3F800000u) + __uint_as_float(ring[f].z & 0x3F800000u) + __uint_as_float(ring[f].w & 0x3F800000u);
+      ++done;
+      issue(ring[f], cur); ++cur;
+    }
+  }
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) y[w] = static_cast<_Float16>(acc);
+}
+
 int main() {
   struct L { int rows, row_bytes; };   // packed rows x bytes per packed row (int4: K bytes per packed row, 2 output rows each)
   const L blk[4] = {{6144, 4096}, {2048, 4096}, {11008, 4096}, {2048, 11008}};   // q|k|v, o, gate|up, down
@@ -166,6 +202,14 @@ int main() {
   run("4x4, 4 units x 1 KiB, stream only, perfect balance", flat_kernel<4, 1>, 256, 4, 0);
   run("4x4, 2 x 2 KiB + x staging + 64 pk ops per 16 B + 4 meta loads / unit", stream_kernel<true, 2, 2, 64, 4>, 256, 4, 8704);
   run("4x4, 3 x 1 KiB + x staging + 64 pk ops per 16 B + 2 meta loads / unit", stream_kernel<true, 3, 1, 64, 2>, 256, 4, 8704);
+  run("4x4, 4 x 1 KiB contiguous, perfect balance", panel_kernel<4, 0>, 256, 4, 0);
+  run("4x4, 4 x (16 rows x 64 B), perfect balance", panel_kernel<4, 1>, 256, 4, 0);
+  run("4x4, 4 x (8 rows x 128 B), perfect balance", panel_kernel<4, 2>, 256, 4, 0);
+  run("8x1, 8 x 1 KiB contiguous, perfect balance", panel_kernel<8, 0>, 512, 1, 0);
+  run("8x1, 8 x (16 rows x 64 B), perfect balance", panel_kernel<8, 1>, 512, 1, 0);
+  run("8x1, 8 x (8 rows x 128 B), perfect balance", panel_kernel<8, 2>, 512, 1, 0);
+  run("8x2, 4 x (16 rows x 64 B), perfect balance", panel_kernel<4, 1>, 512, 2, 0);
+  run("8x2, 4 x (8 rows x 128 B), perfect balance", panel_kernel<4, 2>, 512, 2, 0);
   // ---- the metric's literal shape: one 4096 x 4096 int4 layer per launch (8.39 MB packed, 9.45 MB algorithmic), 32 dependent launches ----
   {
     const int rows = 2048, row_bytes = 4096, chain = 32;
