@@ -397,6 +397,9 @@ def main():
         per slab s, output columns s * N/per + [r * n', (r + 1) * n'), n' = N / (per * P)  (hqq_amd.shard.unpermute,
         the function tests/test_shard.py checks against whole layers, writing into a preallocated buffer here)"""
         from hqq_amd import shard
+        if xmode.get("peer") is not None:   # one kernel: slices stored straight into every rank's full rows over peer memory
+            xmode["peer"].run(EXCHANGE_GROUPS.index(grp), out_local[grp])
+            return
         if M == 1 and xmode.get("rows1"):
             exchange_rows1(grp, xmode["coalesced"])
             return
@@ -471,8 +474,40 @@ def main():
                 sopts.append(group_opts(Ls))
         return ops.LaunchChain(stages, nbits, opts=sopts)
 
-    xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")   # auto: coalesced per-slab gathers on RCCL, else the shard-wide gather; rows1: force per-slab (one by one off RCCL); gather: legacy
-    if world > 1 and M == 1 and xenv != "gather":
+    # auto: peer-memory stores (csrc/exchange.hip) when they validate against the collective, else coalesced per-slab gathers on RCCL, else
+    # the shard-wide gather; peer / rows1 / gather force one
+    xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")
+    if world > 1 and M == 1 and strong and xenv in ("auto", "peer"):
+        # Build the peer arenas (collective), then VALIDATE three rounds of every exchange point against the collective on fresh random
+        # slices; every rank must agree, else the mode is dropped.  Waits are bounded: a peer that never delivers is reported, not hung on.
+        from hqq_amd import shard as _shard
+        ok, why = 1.0, ""
+        try:
+            px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in EXCHANGE_GROUPS], nbits, cd, dev)
+            gv = torch.Generator(device=dev).manual_seed(977 + rank)
+            for rnd in range(3):
+                for e, grp in enumerate(EXCHANGE_GROUPS):
+                    for t in out_local[grp]:
+                        t.copy_(torch.randn(t.shape, device=dev, generator=gv).to(cd))
+                    exchange(grp)                       # the collective (xmode holds no peer object yet) -> out_full
+                    px.run(e, out_local[grp])
+                    torch.cuda.synchronize()
+                    for j in range(len(grp)):
+                        if not torch.equal(px.full(e, j), out_full[grp][j]):
+                            ok, why = 0.0, f"rows differ from the collective's (round {rnd}, point {e}, layer {j})"
+            if px.status() != 0:
+                ok, why = 0.0, f"a wait gave up (status {px.status()})"
+        except Exception as e:   # noqa: BLE001
+            ok, why = 0.0, f"{type(e).__name__}: {e}"
+        okt = torch.tensor([ok], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if float(okt) > 0:
+            xmode["peer"] = px
+            for e, grp in enumerate(EXCHANGE_GROUPS):
+                out_full[grp] = [px.full(e, j) for j in range(len(grp))]
+        elif why:
+            print(f"[bench] rank {rank}: peer-memory exchange not used: {why}", file=sys.stderr)
+    if world > 1 and M == 1 and xenv not in ("gather", "peer") and xmode.get("peer") is None:
         # probe the per-slab exchange once, eagerly, on every rank.  Only the COALESCED form (one launch per exchange point) is worth having:
         # issued one by one it is `per` times as many collectives as the shard-wide gather
         for coalesce in ((True,) if dist.get_backend() == "nccl" else ((False,) if xenv == "rows1" else ())):
@@ -529,7 +564,7 @@ def main():
                                    (", hipGraph replay" if graphed else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
                        "global_batch": M,
                        "parallelism": "single-gpu" if world == 1 else
-                                      (f"output-column shard x{world} of fixed layers (strong scaling) + RCCL all-gather + un-permute per exchange point, in the timed region"
+                                      (f"output-column shard x{world} of fixed layers (strong scaling) + " + ("peer-memory exchange kernel (hqq_hip_exchange, xGMI stores)" if xmode.get("peer") is not None else "RCCL per-slab all-gathers (coalesced)" if xmode.get("rows1") else "RCCL all-gather + un-permute") + " per exchange point, in the timed region"
                                        if strong else f"column-shard x{world} + RCCL all-gather (weak: {world}x wider layers)"),
                        "gemv_mode": mode_name, "layers_with_three_op_rebuild": f"{n_scal}/{nblocks * len(BLOCK)}",
                        "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
@@ -549,14 +584,19 @@ def main():
             xrun, _ = _graphed(lambda: step(only_exchange=True), use_graph, rank)
             xs_, _ = _timed(xrun, max(5, a.steps // 2), 3, dist, dev)
             rows1 = bool(M == 1 and xmode.get("rows1"))
+            peer = xmode.get("peer") is not None
             n_slab_gathers = nblocks * len(BLOCK) * per_slab
             out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5),
-                               "mode": ("per-slab all-gathers straight into the reference's column order" + (", one coalesced RCCL launch per exchange point" if xmode["coalesced"] else ", issued one by one")) if rows1 else "one all-gather of the shard outputs per exchange point + un-permute copies",
-                               "collective_launches_per_step": (stages_per_step if xmode["coalesced"] else n_slab_gathers) if rows1 else stages_per_step,
-                               "all_gathers_per_step": n_slab_gathers if rows1 else stages_per_step,
-                               "unpermute_kernels_per_step": 0 if rows1 else nblocks * len(BLOCK),
+                               "mode": ("peer-memory stores (hqq_hip_exchange): one kernel per exchange point writes the rank's slices into every rank's full rows in the reference's column order and waits for the others' flags; validated against the collective at start-up"
+                                        if peer else
+                                        ("per-slab all-gathers straight into the reference's column order" + (", one coalesced RCCL launch per exchange point" if xmode["coalesced"] else ", issued one by one")) if rows1 else "one all-gather of the shard outputs per exchange point + un-permute copies"),
+                               "exchange_kernels_per_step": stages_per_step if peer else 0,
+                               "peer_status": xmode["peer"].status() if peer else None,
+                               "collective_launches_per_step": 0 if peer else ((stages_per_step if xmode["coalesced"] else n_slab_gathers) if rows1 else stages_per_step),
+                               "all_gathers_per_step": 0 if peer else (n_slab_gathers if rows1 else stages_per_step),
+                               "unpermute_kernels_per_step": 0 if (rows1 or peer) else nblocks * len(BLOCK),
                                "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK),
-                               "note": "all-gather + un-permute of every exchange point, timed without the GEMV launches"}
+                               "note": "the exchange of every exchange point, timed without the GEMV launches"}
             if strong and not a.no_single_gpu_reference:
                 # the SAME fixed stack on ONE GPU (rank 0 alone, the others wait): the single-GPU time a strong-scaling figure refers to
                 single = None

@@ -319,6 +319,34 @@ def gemv_chained(x: Tensor, layers, K: int, group_size: int, nbits: int, outs, o
     return int(arrivals.value)
 
 
+EXCHANGE_MAX_RANKS = 16
+
+
+def exchange(y_loc, N_loc, nbits: int, world: int, rank: int, full_ptrs, flag_ptrs, status_ptr: int, spin_limit: int = 0) -> None:
+    """One exchange point of a column-sharded decode step (csrc/exchange.hip, hqq_hip_exchange): this rank's [1, N_loc[j]] slices go
+    straight into every rank's full row of layer j, in the reference's column order; returns when enqueued (the kernel finishes once all
+    `world` ranks have delivered).  full_ptrs[p][j] / flag_ptrs[p]: raw device addresses (see hqq_amd.shard.PeerExchange, which owns them)."""
+    import ctypes
+    n = len(y_loc)
+    if not 1 <= n <= GEMV_MAX_GROUP:
+        raise ValueError(f"hqq_amd: an exchange point holds 1..{GEMV_MAX_GROUP} layers, got {n}")
+    if not 1 <= world <= EXCHANGE_MAX_RANKS or len(full_ptrs) != world or len(flag_ptrs) != world:
+        raise ValueError(f"hqq_amd: 1..{EXCHANGE_MAX_RANKS} ranks, one row set and one flag block per rank")
+    for t, nl in zip(y_loc, N_loc):
+        _dev(t)
+        if t.numel() != nl or not t.is_contiguous() or t.element_size() != 2:
+            raise ValueError("hqq_amd: exchange takes one dense 2-byte activation row per layer: y_loc[j] is [1, N_loc[j]]")
+    dt = _dt(y_loc[0].dtype)
+    VPn = ctypes.c_void_p * n
+    VPf = ctypes.c_void_p * (world * n)
+    VPw = ctypes.c_void_p * world
+    with torch.cuda.device(y_loc[0].device):
+        rc = _C.lib().hqq_hip_exchange(n, VPn(*[_p(t) for t in y_loc]), (ctypes.c_int64 * n)(*[int(v) for v in N_loc]), int(nbits), dt, int(world), int(rank),
+                                       VPf(*[int(full_ptrs[p][j]) for p in range(world) for j in range(n)]), VPw(*[int(v) for v in flag_ptrs]),
+                                       ctypes.c_void_p(int(status_ptr)), int(spin_limit), _stream())
+    _C.check(rc, "hqq_hip_exchange")
+
+
 class LaunchChain:
     """A list of dependent decode stages run as overlapped launches on two streams (csrc/gemv_chain.hip).
 

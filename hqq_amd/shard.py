@@ -105,3 +105,111 @@ class ShardedHQQForward:
         return unpermute(out.view(self.world, M, self.n_loc), self.N, self.nbits, self.world).reshape(*x.shape[:-1], self.N)
 
     __call__ = forward
+
+
+class PeerExchange:
+    """The exchange points of a column-sharded decode step over PEER MEMORY (csrc/exchange.hip, hqq_hip_exchange) instead of a
+    collective library: one small kernel per point stores this rank's slices straight into every rank's full rows — in the reference's
+    column order, so nothing is permuted afterwards — raises a flag per peer and waits for the others' flags.  One activation row.
+
+    points: one list per exchange point with the FULL widths N of the layers exchanged together (a decoder block:
+    [[Nq, Nk, Nv], [No], [Ngate, Nup], [Ndown]]).  Every rank builds the object with the same arguments; construction is collective
+    (the arenas' IPC handles are all-gathered over `group`).  Consecutive run() calls must alternate between at least two points
+    (the kernel's re-use rule); run() enforces it.
+
+        px = PeerExchange(points, nbits, torch.float16, device)
+        px.run(e, [y_q, y_k, y_v])      # y_*: this rank's [1, N/P] outputs of point e, local order
+        x_next = px.full(e, 0)          # [1, Nq], complete once the kernel has finished (stream order)
+    """
+
+    ALIGN = 256
+
+    def __init__(self, points, nbits: int, dtype, device, group=None, spin_limit: int = 0, _arenas=None, _rank=None, _world=None):
+        import torch.distributed as dist
+        self.nbits, self.dtype, self.device = int(nbits), dtype, torch.device(device)
+        if _arenas is None:
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = int(_world), int(_rank)
+        if not 1 <= self.world <= ops.EXCHANGE_MAX_RANKS:
+            raise ValueError(f"hqq_amd: PeerExchange serves 1..{ops.EXCHANGE_MAX_RANKS} ranks")
+        per = 1 if nbits == 3 else ops.PER[nbits]
+        self.points = [[int(n) for n in pt] for pt in points]
+        for pt in self.points:
+            if not 1 <= len(pt) <= ops.GEMV_MAX_GROUP:
+                raise ValueError(f"hqq_amd: an exchange point holds 1..{ops.GEMV_MAX_GROUP} layers")
+            for n in pt:
+                if n % (per * self.world):
+                    raise ValueError(f"hqq_amd: out_features={n} cannot be split over {self.world} ranks at {nbits} bits")
+        if len(self.points) < 2:
+            raise ValueError("hqq_amd: PeerExchange needs at least two exchange points (consecutive exchanges must alternate)")
+        # arena (identical layout on every rank): [flag blocks: one 128-byte line per point | status line | rows, 256-byte aligned]
+        self._flag_off = [128 * e for e in range(len(self.points))]
+        self._status_off = 128 * len(self.points)
+        off = self._status_off + 128
+        self._row_off = []
+        for pt in self.points:
+            offs = []
+            for n in pt:
+                off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                offs.append(off)
+                off += 2 * n
+            self._row_off.append(offs)
+        self.arena_bytes = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.spin_limit = int(spin_limit)
+        self._last = None
+        if _arenas is not None:      # single-process group (tests): the ranks' arenas are plain tensors of this process
+            self._arenas = list(_arenas)
+        else:
+            mine = torch.zeros(self.arena_bytes, dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
+            if self.world == 1:
+                self._arenas = [mine]
+            else:
+                from torch.multiprocessing.reductions import reduce_tensor
+                handles = [None] * self.world
+                dist.all_gather_object(handles, reduce_tensor(mine), group=group)
+                # (a process cannot open its own handle; peers' arenas are mapped into this process: stores to them travel over xGMI)
+                self._arenas = [mine if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
+                dist.barrier(group=group)   # every rank has mapped every arena before anyone stores into one
+        if any(a.numel() < self.arena_bytes for a in self._arenas):
+            raise ValueError("hqq_amd: PeerExchange arenas are smaller than the layout (ranks disagree about the points)")
+        self._base = [a.data_ptr() for a in self._arenas]
+        mine = self._arenas[self.rank]
+        elems = {torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}[dtype]
+        self._rows = [[mine[o:o + 2 * n].view(elems).view(1, n) for o, n in zip(offs, pt)] for offs, pt in zip(self._row_off, self.points)]
+
+    @classmethod
+    def local_group(cls, points, nbits: int, dtype, device, world: int, spin_limit: int = 0):
+        """`world` ranks inside ONE process (tests, dry runs): same kernels and layout, the arenas are ordinary tensors.  Run every
+        rank's exchange of a point on a stream of its own — each kernel waits for the others."""
+        arenas = [torch.zeros(cls._layout_bytes(points, world), dtype=torch.uint8, device=device) for _ in range(world)]
+        return [cls(points, nbits, dtype, device, spin_limit=spin_limit, _arenas=arenas, _rank=r, _world=world) for r in range(world)]
+
+    @classmethod
+    def _layout_bytes(cls, points, world: int) -> int:
+        off = 128 * len(points) + 128
+        for pt in points:
+            for n in pt:
+                off = (off + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN + 2 * int(n)
+        return (off + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
+    def full(self, e: int, j: int = 0) -> Tensor:
+        """this rank's full [1, N] row of layer j of point e (reference column order; complete after run(e, ...) in stream order)"""
+        return self._rows[e][j]
+
+    def status(self) -> int:
+        """0, or 1 + the rank whose flag a wait gave up on (then the rows of that exchange are undefined)"""
+        a = self._arenas[self.rank]
+        return int(a[self._status_off:self._status_off + 4].view(torch.int32).item())
+
+    def run(self, e: int, y_loc) -> None:
+        if self._last == e:
+            raise RuntimeError("hqq_amd: consecutive exchanges must alternate between at least two points (csrc/exchange.hip re-use rule)")
+        self._last = e
+        pt = self.points[e]
+        if len(y_loc) != len(pt):
+            raise ValueError(f"hqq_amd: exchange point {e} holds {len(pt)} layers, got {len(y_loc)}")
+        ops.exchange(list(y_loc), [n // self.world for n in pt], self.nbits, self.world, self.rank,
+                     [[b + o for o in self._row_off[e]] for b in self._base], [b + self._flag_off[e] for b in self._base],
+                     self._base[self.rank] + self._status_off, self.spin_limit)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 3
+#define HQQ_HIP_ABI_VERSION 4
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -167,6 +167,25 @@ int hqq_hip_gemv_chained(int nbits, int n_layers, const void* x, const void* con
                          const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
                          int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, const hqq_hip_chain_link* link,
                          uint32_t* arrivals, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * One exchange point of a column-sharded decode step (ABI 4; csrc/exchange.hip), one activation row, without a collective library.
+ * The reference has no multi-GPU path for HQQLinear.forward (quantize.py:880-898); the shard is SURVEY.md section 8e's: rank r holds the
+ * packed-row block r of every layer and computes, per slab s, the output columns s N/per + [r n', (r + 1) n'), n' = N / (per P).
+ * This call stores the rank's slices y_loc[j] ([1, N_loc[j]], local slab-major order) straight into EVERY rank's full row of layer j
+ * at those columns — peers' rows are device pointers the caller obtained with hipIpcOpenMemHandle (stores travel over xGMI) — raises
+ * this rank's flag in every rank's flag block, waits until all `world` flags of its own block are up and lowers them.  When the
+ * kernel has finished, this rank's full rows are complete and in the reference's column order; the next kernel in stream order may
+ * read them.  Capturable.  One launch, `world` workgroups.
+ *   full    [world * n_layers] pointers: full[p * n_layers + j] = rank p's [1, N_loc[j] * world] row of layer j (p == rank: local)
+ *   flags   [world] pointers: rank p's flag block of THIS point, `world` uint32 words, zero before the first use (p == rank: local)
+ *   status  one local uint32: a wait that gives up after spin_limit polls (0 = 4 Mi, seconds) writes 1 + the missing rank there
+ *           and returns — outputs undefined, reported, never a hang
+ * Re-use rule: consecutive exchanges on a stream must alternate between at least two points (flag block + rows); a decoder block
+ * has four.  Every rank must issue the same sequence of points.  dtype F16 / BF16; nbits picks `per` (3-bit shards: per = 1).
+ * ------------------------------------------------------------------------------------------- */
+#define HQQ_EXCHANGE_MAX_RANKS 16
+int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int nbits, int dtype, int world, int rank,
+                     void* const* full, void* const* flags, void* status, uint32_t spin_limit, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * The persistent decode engine: one launch walks a whole list of DEPENDENT stages, one activation row (bs = 1).
  * A stage is what one hqq_hip_gemv_grouped call computes — up to HQQ_GEMV_MAX_GROUP layers reading the same x[1,K] — and stage

@@ -55,6 +55,13 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 1) == 1 and L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 2) == 1
     assert L.hqq_hip_forward_prefers_fused(4, 1025, 4096, 4096, 64, 1) == 0 and L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 32, 1) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 32, 4096, 4096, 64, 1) == 1
+    # the peer-memory exchange validates its arguments before it launches anything
+    VP1, VP2 = (ctypes.c_void_p * 1)(16), (ctypes.c_void_p * 2)(16, 16)
+    st = ctypes.c_void_p(16)
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 1, 17, 0, VP2, VP2, st, 0, None) == -2     # more ranks than HQQ_EXCHANGE_MAX_RANKS
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(511), 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2      # 511 columns do not split into two slab runs
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 0, 2, 0, VP2, VP2, st, 0, None) == -3      # fp32 activations
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 1, 2, 2, VP2, VP2, st, 0, None) == -2      # rank 2 of 2
     # the decode plan: sizes and argument checks on the host
     assert L.hqq_hip_decode_plan_bytes(0) == 0 and L.hqq_hip_decode_plan_bytes(128) == 256 + 128 * 256 + 1280
 

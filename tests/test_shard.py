@@ -105,3 +105,21 @@ def test_sharded_forward_all_gather_gloo_world2(nbits):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def test_peer_exchange_layout_is_the_same_on_every_rank_and_rows_do_not_overlap():
+    """the arena layout is pure arithmetic on (points, world): every rank must derive the same offsets (peers address each other's rows
+    as base + offset), rows and flag lines must not overlap"""
+    from hqq_amd.shard import PeerExchange
+    points = [[8192, 1024, 1024], [8192], [28672, 28672], [8192]]
+    total = PeerExchange._layout_bytes(points, 8)
+    assert total % PeerExchange.ALIGN == 0 and total >= 128 * 5 + 2 * sum(sum(p) for p in points)
+    # replay the layout the constructor uses and check it against the total
+    off, spans = 128 * len(points) + 128, []
+    for pt in points:
+        for n in pt:
+            off = (off + 255) // 256 * 256
+            spans.append((off, off + 2 * n))
+            off += 2 * n
+    assert (off + 255) // 256 * 256 == total
+    assert all(a1 <= b0 for (a0, a1), (b0, b1) in zip(spans, spans[1:])) and spans[0][0] >= 128 * 5

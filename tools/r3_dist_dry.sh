@@ -7,3 +7,7 @@ echo rc=$?; tail -n 3 gpurun_out/r3/dist_dry.err; python -c "
 import json; d=json.loads(open('gpurun_out/r3/dist_dry.json').read().strip().split('\n')[-1]); print(d['ms_per_step'], d['config']['parallelism'][:60]); print(d['exchange'])"
 HQQ_BENCH_EXCHANGE=gather timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --blocks 2 --steps 3 --warmup 1 --random-codes --no-single-gpu-reference 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step']); print(d['exchange'])"
+# peer-memory exchange (csrc/exchange.hip): arenas mapped through IPC handles, validated against the gloo collective at start-up
+HQQ_BENCH_EXCHANGE=auto timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --blocks 4 --steps 5 --warmup 2 --random-codes --no-single-gpu-reference 2> gpurun_out/r3/dist_dry_peer.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['config']['parallelism']); print(d['exchange'])"
+tail -n 3 gpurun_out/r3/dist_dry_peer.err
