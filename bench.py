@@ -21,8 +21,11 @@ Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL).  Default 
 configs[4]: the Llama-2-70B linear shapes (q,o 8192x8192; k,v 1024x8192; gate,up 28672x8192; down 8192x28672),
 nbits=4, every layer's output columns sharded over the N ranks (packed-row blocks of the reference layout,
 hqq_amd/shard.py) — STRONG scaling of fixed layers: x is replicated, every exchange point (after q|k|v, o,
-gate|up, down) is one RCCL all-gather of the fp16 shard outputs over xGMI followed by the un-permute to the
-reference's column order, both inside the timed region; the all-gathers are also timed on their own.
+gate|up, down) completes the outputs in the reference's column order inside the timed region, and the exchange is
+also timed on its own.  At one activation row the exchange is, in order of preference: one small kernel storing the
+rank's slices into every rank's full rows over peer memory (csrc/exchange.hip; arenas mapped through IPC handles,
+validated against the collective at start-up), per-slab RCCL all-gathers in one coalesced launch, or the shard-wide
+all-gather + un-permute (HQQ_BENCH_EXCHANGE=peer|rows1|gather forces one; the JSON's `exchange` block says which ran).
 `--workload decode --gpus N` keeps round 1's weak-scaling variant (every rank streams a 7B-stack-sized shard).
 
 Prints ONE JSON line on rank 0.  `value` = algorithmic GB/s streamed by the whole job (SURVEY.md §8d bytes:

@@ -85,9 +85,12 @@ class ShardedHQQForward:
     """One rank's share of a column-sharded layer.  forward(x) = local fused forward + one all-gather over the process
     group (RCCL on GPUs; any torch.distributed backend works, the CPU tests use gloo with a stand-in local op)."""
 
-    def __init__(self, W_q, scale, zero, bias, N, K, group_size, nbits, group=None, local_forward=None):
+    def __init__(self, W_q, scale, zero, bias, N, K, group_size, nbits, group=None, local_forward=None, peer=None):
+        """peer: (PeerExchange, point) — at one activation row the outputs are then exchanged by that object's kernel (peer-memory stores,
+        csrc/exchange.hip) instead of a collective; the returned row is the exchange's buffer, valid until the point is used again"""
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        self.peer = peer
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.N, self.K, self.gs, self.nbits = N, K, group_size, nbits
@@ -97,6 +100,10 @@ class ShardedHQQForward:
     def forward(self, x: Tensor) -> Tensor:
         y_loc = self._local(x).reshape(-1, self.n_loc).contiguous()
         M = y_loc.shape[0]
+        if M == 1 and self.peer is not None:
+            px, e = self.peer
+            px.run(e, [y_loc])
+            return px.full(e, 0).reshape(*x.shape[:-1], self.N)
         if M == 1:   # decode: straight into the reference's column order, no un-permute
             full = torch.empty((1, self.N), dtype=y_loc.dtype, device=y_loc.device)
             return gather_columns(y_loc, full, self.N, self.nbits, self.group).reshape(*x.shape[:-1], self.N)

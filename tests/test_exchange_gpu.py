@@ -99,7 +99,24 @@ for rnd in range(25):
         px.run(e, mine)
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(px.full(e, j), f)) for j, f in enumerate(fulls))
-st = px.status()
+# the product path: two column-sharded layers whose decode outputs are exchanged by the kernel (hqq_amd.shard.ShardedHQQForward, peer=...)
+from hqq_amd import ops
+gw = torch.Generator().manual_seed(5)
+px2 = shard.PeerExchange([[1024], [512]], nbits, torch.float16, "cuda:0")
+layers = []
+for e, (N, K) in enumerate(((1024, 512), (512, 1024))):
+    W = (torch.randn(N, K, generator=gw) * 0.05).half().cuda()
+    Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=True)
+    s, z = s.half(), z.half()
+    layers.append((shard.ShardedHQQForward(Wq, s, z, None, N, K, 64, nbits, peer=(px2, e)), ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, 64, nbits)))
+for rnd in range(10):
+    for fwd, Wd in layers:
+        x = torch.randn(1, Wd.shape[1], generator=g).half().cuda()
+        y = fwd(x)
+        torch.cuda.synchronize()
+        if not torch.allclose(y.float(), x.float() @ Wd.float().t(), rtol=1e-3, atol=2e-3):
+            bad += 1
+st = px.status() + px2.status()
 dist.barrier()
 print(f"rank {rank}: mismatches {bad}, status {st}", flush=True)
 sys.exit(0 if (bad == 0 and st == 0) else 3)
