@@ -47,7 +47,27 @@
 #ifdef SK_LAB_TS
 extern unsigned long long* g_sk_lab_ts;
 #endif
+// This file is compiled twice (Makefile): the WIDE tile — 64-packed-row panels, four row groups x two block halves — and, with -DSK_NARROW,
+// the NARROW one — 32-row panels, two row groups x four blocks — for 4- / 2-bit launches of at most 2048 packed rows (one 4096-row int4 layer: o, down),
+// where the wide tile has 32 panels and must cut K eight ways to fill the chip.  Measured (profiles/r03_skinny_tiles_ks.txt, us per launch,
+// wide -> narrow with four K splits): o at 8 / 32 rows 10.3 -> 8.8 / 12.8 -> 10.3; down 13.8 -> 13.1 / 17.4 -> 16.4; the larger 4-bit
+// launches (q|k|v, gate|up) are faster on the wide tile (17.0 vs 17.6, 25.1 vs 30.7) and stay there.  2-bit launches (four slabs per byte:
+// twice the rebuild work per panel) are faster on the narrow tile at every 7B shape (o 17.7 -> 13.6, q|k|v 23.0 -> 16.3, gate|up 25.0 ->
+// 22.0, down 25.2 -> 16.9 at 32 rows): up to 8192 packed rows.  The choice depends on the shapes of the launch only, never on M, so a
+// row's bits do not depend on the batch it is computed in.
+#ifdef SK_NARROW
+#define SK_NS sk_narrow
+#ifndef SK_ROW_GROUPS
+#define SK_ROW_GROUPS 2
+#endif
+#ifndef SK_BLOCK_SPLIT
+#define SK_BLOCK_SPLIT 4
+#endif
+#else
+#define SK_NS sk_wide
+#endif
 namespace hqq {
+namespace SK_NS {
 
 constexpr int SK_MAXL = HQQ_GEMV_MAX_GROUP;
 #ifndef SK_BLOCK_SPLIT
@@ -601,7 +621,11 @@ static void sk_choose(int total_panels, int nchunks, int forced, int& ks, int& c
   const int cus = sk_num_cus();
   ks = (total_panels * 16 >= cus * 9 && nchunks <= SK_MAX_CPS) ? 1   // >= 0.56 workgroups per CU: one pass, no partials
                                                                : (cus + total_panels - 1) / total_panels;
+#ifndef SK_NARROW
   if (total_panels >= 48) { const int lim = nchunks / 8 > 1 ? nchunks / 8 : 1; ks = ks > lim ? lim : ks; }
+#else   // narrow tile (measured, profiles/r03_skinny_tiles_ks.txt): as many splits as fill the chip without a second round, >= 4 chunks each
+  if (ks > 1) { ks = cus / total_panels; const int lim = nchunks / 4 > 1 ? nchunks / 4 : 1; ks = ks > lim ? lim : ks; }
+#endif
   ks = ks > nchunks / 2 ? nchunks / 2 : ks;   // at least two chunks per workgroup
   ks = ks > 16 ? 16 : (ks < 1 ? 1 : ks);
   if (forced >= 1 && forced <= nchunks) ks = forced;
@@ -633,7 +657,10 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
     a.cnt = static_cast<int*>(ws);
     a.part = reinterpret_cast<float*>(static_cast<char*>(ws) + SK_CNT_BYTES);
   }
-  const size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
+  size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
+  // the partial tiles of a row group's upper waves meet in the same LDS once the loop is done: (SK_SPLIT - 1) tiles per row group and slab
+  const size_t red = static_cast<size_t>(SK_SPLIT - 1) * SK_RG * (8 / NBITS) * mt * 64 * sizeof(f32x4);
+  lds = lds > red ? lds : red;
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
 #define HQQ_SK_CASE(MT)                                                                                       \
   case MT: {                                                                                                  \
@@ -706,5 +733,42 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
     return nbits == 4 ? sk_launch<4, false, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, false, true>(a, opts, ws, ws_bytes, st);
   return nbits == 4 ? sk_launch<4, false>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false>(a, opts, ws, ws_bytes, st) : sk_launch<8, false>(a, opts, ws, ws_bytes, st);
 }
+
+}  // namespace SK_NS
+
+#ifndef SK_NARROW
+namespace sk_narrow {
+bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
+size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts);
+int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
+               hipStream_t st);
+}  // namespace sk_narrow
+
+// which tile serves a launch: shapes only (see the head of the file)
+#ifndef SK_NARROW_MAX_PROWS
+#define SK_NARROW_MAX_PROWS 2048
+#endif
+static bool sk_takes_narrow(int nbits, int n_layers, const int64_t* N, uint32_t opts) {
+  if ((opts & HQQ_OPT_SKINNY_WIDE) || nbits == 8) return false;   // (8-bit: one slab per byte — the narrow tile's constant staging has fewer lines than threads; not built)
+  const int per = 8 / nbits;
+  int64_t prows = 0;
+  for (int i = 0; i < n_layers; ++i) prows += N[i] / per;
+  return prows <= (nbits == 2 ? 4 : 1) * static_cast<int64_t>(SK_NARROW_MAX_PROWS);
+}
+bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers) {
+  return sk_wide::skinny_covers(nbits, M, K, group_size, N, n_layers);   // (the same conditions for both tiles)
+}
+size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts) {
+  return sk_takes_narrow(nbits, n_layers, N, opts) ? sk_narrow::skinny_workspace_bytes(nbits, n_layers, N, M, K, opts)
+                                                   : sk_wide::skinny_workspace_bytes(nbits, n_layers, N, M, K, opts);
+}
+int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
+               hipStream_t st) {
+  return sk_takes_narrow(nbits, n_layers, N, opts) ? sk_narrow::skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, ws, ws_bytes, st)
+                                                   : sk_wide::skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, ws, ws_bytes, st);
+}
+#endif
 
 }  // namespace hqq

@@ -22,7 +22,7 @@ SKINNY_MAX_M = 64   # HQQ_GEMV_MAX_M_SKINNY: fp16 / bf16, 8-/4-/2-bit, group_siz
 GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 # per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
-OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC, OPT_GEMM_NARROW, OPT_GEMM_WIDE, OPT_GEMM_NOHYBRID = 1, 2, 4, 8, 16, 32, 64, 128, 256
+OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC, OPT_GEMM_NARROW, OPT_GEMM_WIDE, OPT_GEMM_NOHYBRID, OPT_SKINNY_WIDE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 
 def OPT_SKINNY_KS(n: int) -> int:

@@ -112,7 +112,8 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_GEMM_NARROW  64u   /* pipelined fused GEMM: force 4 waves per workgroup (64 packed rows per tile) — tuning */
 #define HQQ_OPT_GEMM_WIDE   128u   /* pipelined fused GEMM: force 8 waves per workgroup (128 packed rows per tile) — tuning */
 #define HQQ_OPT_GEMM_NOHYBRID 256u  /* pipelined fused GEMM: never split only the last round of tiles (tuning) */
-#define HQQ_OPT_ALL (511u | (255u << 24))
+#define HQQ_OPT_SKINNY_WIDE 512u  /* 5..64 rows: force the 64-packed-row tile for launches the 32-row tile would serve (tests / tuning) */
+#define HQQ_OPT_ALL (1023u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.

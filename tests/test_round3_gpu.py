@@ -238,3 +238,37 @@ def test_workspace_users_on_two_streams_are_serialised(ops):
             outs.append(ops.gemv(x, Wq, s, z, None, N, K, 64, 4))
     torch.cuda.synchronize()
     assert all(torch.equal(o, want) for o in outs)
+
+
+# ------------------------------------------------------------------------------------------------
+# the skinny GEMM's two tiles (csrc/skinny.hip compiled twice): small 4-bit launches run on 32-row panels, HQQ_OPT_SKINNY_WIDE forces 64
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cd", ["f16", "bf16"])
+@pytest.mark.parametrize("nbits", [4, 2])
+@pytest.mark.parametrize("N,K,bias", [(4096, 4096, False), (4096, 11008, True), (1000, 1024, True), (68, 512, False), (2048, 2048, False), (8192, 4096, False)])
+def test_both_tiles_of_the_skinny_gemm_against_the_oracle(ops, oracle, N, K, bias, cd, nbits):
+    """a launch of <= 2048 packed rows is served by the narrow tile (a shape rule, never M); the same call with OPT_SKINNY_WIDE by the wide
+    one: both within 1e-3 (fp16) / one bf16 ulp of the double-accumulated oracle on the oracle's exact weights, ragged last panels,
+    bias, 5..64 rows, and reproducible run to run; a row's bits do not depend on the batch it is computed in"""
+    code = oracle.F16 if cd == "f16" else oracle.BF16
+    tdt = torch.float16 if cd == "f16" else torch.bfloat16
+    rng, P, s, z = _synthetic(oracle, N, K, nbits, code, N * 3 + K + nbits)
+    Pd, sd, zd = dev(P), dev(s).view(tdt), dev(z).view(tdt)
+    Wd = oracle.dequantize(nbits, P, s, z, N, K, 64, code)
+    b = oracle.to_cd(rng.standard_normal(N, dtype=np.float32) * 0.1, code) if bias else None
+    bd = dev(b).view(tdt) if bias else None
+    rtol, atol = (1e-3, 2e-3) if cd == "f16" else (2 ** -7, 4e-3)
+    xs64 = oracle.to_cd(rng.standard_normal((64, K), dtype=np.float32), code)
+    for M in (5, 17, 33, 64):
+        x = xs64[:M]
+        yo, _ = oracle.matmul(x, Wd, b, code)
+        want = torch.from_numpy(oracle.from_cd(yo, code))
+        for name, o in (("rule", 0), ("wide", ops.OPT_SKINNY_WIDE)):
+            y = ops.forward(dev(x).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
+            y2 = ops.forward(dev(x).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
+            assert torch.equal(y, y2), "reproducible"
+            torch.testing.assert_close(y.float().cpu(), want, rtol=rtol, atol=atol)
+    for name, o in (("rule", 0), ("wide", ops.OPT_SKINNY_WIDE)):
+        y64 = ops.forward(dev(xs64).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
+        y17 = ops.forward(dev(xs64[:17]).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
+        assert torch.equal(y64[:17], y17), f"{name}: a row must not depend on the batch it is computed in"
