@@ -311,7 +311,7 @@ def test_workspace_growth_never_invalidates_a_captured_graph(ops):
 def test_a_call_that_needs_workspace_says_so_at_the_abi(ops):
     import ctypes
     from hqq_amd import _C
-    nbits, N, K, M = 4, 256, 1024, 32
+    nbits, N, K, M = 4, 256, 4096, 32   # (few panels, sixteen chunks: the skinny kernel cuts K and parks partial tiles)
     Wq, s, z = _qlayer(ops, N, K, nbits, seed=1)
     x = torch.zeros(M, K, device="cuda", dtype=torch.float16)
     y = torch.empty(M, N, device="cuda", dtype=torch.float16)
