@@ -667,7 +667,7 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
     auto kern = skinny_f16_kernel<NBITS, MT, BF16, SUB>;                                                          \
     if (lds > 64 * 1024) {                                                                                    \
       static LdsRaised raised;                                                                                \
-      if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), 128 * 1024, "hqq_hip_gemv")) return rc; \
+      if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), 160 * 1024, "hqq_hip_gemv")) return rc; \
     }                                                                                                         \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                        \
     break;                                                                                                    \

@@ -272,3 +272,17 @@ def test_both_tiles_of_the_skinny_gemm_against_the_oracle(ops, oracle, N, K, bia
         y64 = ops.forward(dev(xs64).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
         y17 = ops.forward(dev(xs64[:17]).view(tdt), Pd, sd, zd, bd, N, K, 64, nbits, opts=o)
         assert torch.equal(y64[:17], y17), f"{name}: a row must not depend on the batch it is computed in"
+
+
+def test_skinny_gemm_with_more_than_128_kib_of_lds(ops, oracle):
+    """2-bit, 64 rows, one K split of sixteen chunks on the wide tile: 64 KiB of x stages + 66.5 KiB of group constants — above the
+    128 KiB the kernel used to ask for, inside gfx950's 160 KiB"""
+    N, K, nbits = 4 * 64 * 150, 4096, 2
+    rng, P, s, z = _synthetic(oracle, N, K, nbits, oracle.F16, 99)
+    Pd, sd, zd = dev(P), dev(s).view(torch.float16), dev(z).view(torch.float16)
+    x = oracle.to_cd(rng.standard_normal((64, K), dtype=np.float32), oracle.F16)
+    y = ops.forward(dev(x).view(torch.float16), Pd, sd, zd, None, N, K, 64, nbits, opts=ops.OPT_SKINNY_WIDE)
+    rows = rng.integers(0, N, size=512)
+    Wd = oracle.dequantize(nbits, P, s, z, N, K, 64, oracle.F16)[rows]
+    yo, _ = oracle.matmul(x, Wd, None, oracle.F16)
+    torch.testing.assert_close(y[:, torch.from_numpy(rows).cuda()].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=2e-3)
