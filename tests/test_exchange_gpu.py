@@ -99,6 +99,30 @@ for rnd in range(25):
         px.run(e, mine)
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(px.full(e, j), f)) for j, f in enumerate(fulls))
+# under hipGraph replay (what bench.py --gpus N does): the four points captured once with fixed slice buffers, refilled between replays
+bufs = [[torch.empty(1, N // world, device="cuda", dtype=torch.float16) for N in pt] for pt in points]
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for e in range(len(points)):
+        px.run(e, bufs[e])
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+dist.barrier()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+    for e in range(len(points)):
+        px.run(e, bufs[e])
+for rnd in range(20):
+    fulls = [[torch.randn(1, N, generator=g).half().cuda() for N in pt] for pt in points]
+    for e, pt in enumerate(points):
+        for j, N in enumerate(pt):
+            bufs[e][j].copy_(fulls[e][j][:, shard.shard_rows(N, nbits, rank, world).cuda()])
+    graph.replay()
+    torch.cuda.synchronize()
+    bad += sum(int(not torch.equal(px.full(e, j), fulls[e][j])) for e, pt in enumerate(points) for j in range(len(pt)))
+    dist.barrier()   # (a rank must not refill its slices... they are private; the barrier only keeps the ranks' rounds aligned for the compare)
+
 # the product path: two column-sharded layers whose decode outputs are exchanged by the kernel (hqq_amd.shard.ShardedHQQForward, peer=...)
 from hqq_amd import ops
 gw = torch.Generator().manual_seed(5)
