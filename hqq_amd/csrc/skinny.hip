@@ -84,6 +84,9 @@ constexpr int SK_KC = 256;               // k per chunk
 constexpr int SK_BLK = SK_KC / 64;       // 64-k blocks (= groups) per chunk
 constexpr int SK_T = SK_WAVES * 64;
 constexpr int SK_BPW = SK_BLK / SK_SPLIT;     // blocks per wave and chunk
+#ifndef SK_X_EARLY
+#define SK_X_EARLY 1
+#endif
 #ifndef SK_RING_DEPTH
 #define SK_RING_DEPTH 2
 #endif
@@ -478,9 +481,15 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #pragma unroll
     for (int k = 0; k < SK_RING; ++k) {
       // chunks past the range (the ring is deeper than the remainder) meet zero x: finite dummy weights, exactly 0 added
+#if SK_X_EARLY   // x of chunk i + k + 2 requested BEFORE this half's consume: almost two half-iterations of lead instead of one
+      xload(i + k + 2, k & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       consume(un[k], k & 1, i + k < c1 ? i + k : c1 - 1);
       __builtin_amdgcn_sched_barrier(0);
+#if !SK_X_EARLY
       xload(i + k + 2, k & 1);
+#endif
       issue(un[k], i + k + SK_RING);
       __builtin_amdgcn_sched_barrier(0);
       xstore((k + 1) & 1, (k + 1) & 1);   // x of chunk i + k + 1, requested one half-iteration ago
