@@ -15,7 +15,8 @@
 //   Wq     [N/per, K] bytes; byte (p, k) holds W_q[p + s*N/per, k] for slab s at bit 8 - nbits*(s+1)
 //   scale  [N*G], zero [N*G] fp16, G = K/64; output row n uses [n*G, (n+1)*G)
 //
-// Work decomposition.  A *panel* is 64 packed rows (-> 64*per output rows): one workgroup of eight waves — four row groups of 16
+// Work decomposition (the WIDE tile; the narrow one — see SK_NARROW below — has 32-row panels: two row groups, four waves each taking one
+// block of a chunk).  A *panel* is 64 packed rows (-> 64*per output rows): one workgroup of eight waves — four row groups of 16
 // packed rows, two waves per row group, each dequantising two of a chunk's four 64-k blocks (their partial tiles meet in LDS
 // once, at the end; one wave per row group left the SIMDs half idle).  K is walked in chunks of 256: lane (r = lane & 15,
 // c = lane >> 4) loads the 16 packed bytes of row r at k = 256*chunk + 64*j + 16*c for its blocks j
