@@ -163,6 +163,7 @@ class PeerExchange:
                 off += 2 * n
             self._row_off.append(offs)
         self.arena_bytes = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        assert self.arena_bytes == self._layout_bytes(self.points, self.world)
         self.spin_limit = int(spin_limit)
         self._last = None
         if _arenas is not None:      # single-process group (tests): the ranks' arenas are plain tensors of this process
@@ -185,11 +186,17 @@ class PeerExchange:
         mine = self._arenas[self.rank]
         elems = {torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}[dtype]
         self._rows = [[mine[o:o + 2 * n].view(elems).view(1, n) for o, n in zip(offs, pt)] for offs, pt in zip(self._row_off, self.points)]
+        # per point: every rank's row addresses and flag-block address (what hqq_hip_exchange takes), computed once
+        self._full_ptrs = [[[b + o for o in offs] for b in self._base] for offs in self._row_off]
+        self._flag_ptrs = [[b + f for b in self._base] for f in self._flag_off]
+        self._n_loc = [[n // self.world for n in pt] for pt in self.points]
 
     @classmethod
     def local_group(cls, points, nbits: int, dtype, device, world: int, spin_limit: int = 0):
-        """`world` ranks inside ONE process (tests, dry runs): same kernels and layout, the arenas are ordinary tensors.  Run every
-        rank's exchange of a point on a stream of its own — each kernel waits for the others."""
+        """`world` ranks inside ONE process (tests): same kernel and layout, the arenas are ordinary tensors.  One process cannot count on
+        its ranks' kernels being resident together (streams share hardware queues, and a kernel would wait for one queued behind it):
+        pass spin_limit=1 — the waits give up at once, the stores still happen — and clear flags and status between rounds, as
+        tests/test_exchange_gpu.py does.  Real waits need one process per rank."""
         arenas = [torch.zeros(cls._layout_bytes(points, world), dtype=torch.uint8, device=device) for _ in range(world)]
         return [cls(points, nbits, dtype, device, spin_limit=spin_limit, _arenas=arenas, _rank=r, _world=world) for r in range(world)]
 
@@ -217,6 +224,5 @@ class PeerExchange:
         pt = self.points[e]
         if len(y_loc) != len(pt):
             raise ValueError(f"hqq_amd: exchange point {e} holds {len(pt)} layers, got {len(y_loc)}")
-        ops.exchange(list(y_loc), [n // self.world for n in pt], self.nbits, self.world, self.rank,
-                     [[b + o for o in self._row_off[e]] for b in self._base], [b + self._flag_off[e] for b in self._base],
+        ops.exchange(list(y_loc), self._n_loc[e], self.nbits, self.world, self.rank, self._full_ptrs[e], self._flag_ptrs[e],
                      self._base[self.rank] + self._status_off, self.spin_limit)
