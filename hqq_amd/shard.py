@@ -220,9 +220,9 @@ class PeerExchange:
     def run(self, e: int, y_loc) -> None:
         if self._last == e:
             raise RuntimeError("hqq_amd: consecutive exchanges must alternate between at least two points (csrc/exchange.hip re-use rule)")
-        self._last = e
         pt = self.points[e]
         if len(y_loc) != len(pt):
             raise ValueError(f"hqq_amd: exchange point {e} holds {len(pt)} layers, got {len(y_loc)}")
         ops.exchange(list(y_loc), self._n_loc[e], self.nbits, self.world, self.rank, self._full_ptrs[e], self._flag_ptrs[e],
                      self._base[self.rank] + self._status_off, self.spin_limit)
+        self._last = e   # (only an exchange that was enqueued counts)

@@ -123,3 +123,34 @@ def test_peer_exchange_layout_is_the_same_on_every_rank_and_rows_do_not_overlap(
             off += 2 * n
     assert (off + 255) // 256 * 256 == total
     assert all(a1 <= b0 for (a0, a1), (b0, b1) in zip(spans, spans[1:])) and spans[0][0] >= 128 * 5
+
+
+def test_peer_exchange_host_logic_without_a_gpu():
+    """argument checks, the arena views and the re-use rule are host logic: rows are views of the rank's own arena at the layout's
+    offsets; the kernel call itself refuses CPU tensors (no fallback)"""
+    import pytest
+    from hqq_amd.shard import PeerExchange
+    with pytest.raises(ValueError, match="at least two exchange points"):
+        PeerExchange.local_group([[512]], 4, torch.float16, "cpu", 2)
+    with pytest.raises(ValueError, match="cannot be split"):
+        PeerExchange.local_group([[510], [512]], 4, torch.float16, "cpu", 4)
+    with pytest.raises(ValueError, match="1..4 layers"):
+        PeerExchange.local_group([[512] * 5, [512]], 4, torch.float16, "cpu", 2)
+    points = [[1024, 256], [512]]
+    grp = PeerExchange.local_group(points, 4, torch.bfloat16, "cpu", 2)
+    assert [g.rank for g in grp] == [0, 1] and all(g.world == 2 for g in grp)
+    a0 = grp[0]._arenas[0]
+    assert grp[0].full(0, 1).shape == (1, 256) and grp[0].full(0, 1).dtype == torch.bfloat16
+    assert grp[0].full(0, 0).data_ptr() == a0.data_ptr() + grp[0]._row_off[0][0] and grp[0]._row_off[0][0] % 256 == 0
+    assert grp[1].full(1, 0).data_ptr() == grp[1]._arenas[1].data_ptr() + grp[1]._row_off[1][0]
+    # every rank addresses rank 1's rows the same way: base of arena 1 + the shared offsets
+    assert grp[0]._full_ptrs[1][1] == grp[1]._full_ptrs[1][1] == [grp[0]._arenas[1].data_ptr() + o for o in grp[0]._row_off[1]]
+    y = [torch.zeros(1, 512, dtype=torch.bfloat16), torch.zeros(1, 128, dtype=torch.bfloat16)]
+    with pytest.raises(ValueError, match="holds 2 layers"):
+        grp[0].run(0, y[:1])
+    with pytest.raises(RuntimeError, match="need tensors on the GPU"):
+        grp[0].run(1, [torch.zeros(1, 256, dtype=torch.bfloat16)])
+    assert grp[0]._last is None                      # a call that was not enqueued does not count as the last exchange
+    grp[0]._last = 1                                 # (as after an enqueued exchange of point 1)
+    with pytest.raises(RuntimeError, match="alternate between at least two points"):
+        grp[0].run(1, [torch.zeros(1, 256, dtype=torch.bfloat16)])
