@@ -178,8 +178,18 @@ class PeerExchange:
                 handles = [None] * self.world
                 dist.all_gather_object(handles, reduce_tensor(mine), group=group)
                 # (a process cannot open its own handle; peers' arenas are mapped into this process: stores to them travel over xGMI)
-                self._arenas = [mine if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
-                dist.barrier(group=group)   # every rank has mapped every arena before anyone stores into one
+                err = None
+                try:
+                    self._arenas = [mine if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
+                except Exception as e:   # noqa: BLE001  (IPC not available between these devices / processes)
+                    err = e
+                # every rank reports; this is also the barrier: nobody stores into an arena before every rank has mapped all of them, and
+                # a rank that could not map them does not leave the others waiting
+                oks = [None] * self.world
+                dist.all_gather_object(oks, err is None, group=group)
+                if not all(oks):
+                    bad = [p for p, o in enumerate(oks) if not o]
+                    raise RuntimeError(f"hqq_amd: PeerExchange: rank(s) {bad} could not map their peers' arenas" + (f" ({type(err).__name__}: {err})" if err else ""))
         if any(a.numel() < self.arena_bytes for a in self._arenas):
             raise ValueError("hqq_amd: PeerExchange arenas are smaller than the layout (ranks disagree about the points)")
         self._base = [a.data_ptr() for a in self._arenas]
