@@ -484,24 +484,35 @@ def main():
         # Build the peer arenas (collective), then VALIDATE three rounds of every exchange point against the collective on fresh random
         # slices; every rank must agree, else the mode is dropped.  Waits are bounded: a peer that never delivers is reported, not hung on.
         from hqq_amd import shard as _shard
-        ok, why = 1.0, ""
-        try:
+        ok, why, px = 1.0, "", None
+        try:   # (collective, and consistent: either every rank gets its object or every rank raises — hqq_amd/shard.py)
             px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in EXCHANGE_GROUPS], nbits, cd, dev)
+        except Exception as e:   # noqa: BLE001
+            ok, why = 0.0, f"{type(e).__name__}: {e}"
+        if px is not None:
             gv = torch.Generator(device=dev).manual_seed(977 + rank)
+            alive = True   # (a rank whose peer path raised keeps taking part in the collectives of the remaining rounds)
             for rnd in range(3):
-                for e, grp in enumerate(EXCHANGE_GROUPS):
+                # the collectives first, all of them, outside any try: a rank whose peer path fails below must not leave the others in one
+                for grp in EXCHANGE_GROUPS:
                     for t in out_local[grp]:
                         t.copy_(torch.randn(t.shape, device=dev, generator=gv).to(cd))
                     exchange(grp)                       # the collective (xmode holds no peer object yet) -> out_full
-                    px.run(e, out_local[grp])
-                    torch.cuda.synchronize()
-                    for j in range(len(grp)):
-                        if not torch.equal(px.full(e, j), out_full[grp][j]):
-                            ok, why = 0.0, f"rows differ from the collective's (round {rnd}, point {e}, layer {j})"
-            if px.status() != 0:
-                ok, why = 0.0, f"a wait gave up (status {px.status()})"
-        except Exception as e:   # noqa: BLE001
-            ok, why = 0.0, f"{type(e).__name__}: {e}"
+                want = {grp: [t.clone() for t in out_full[grp]] for grp in EXCHANGE_GROUPS}
+                torch.cuda.synchronize()
+                if not alive:
+                    continue
+                try:   # the peer path: no collective inside, waits bounded
+                    for e, grp in enumerate(EXCHANGE_GROUPS):
+                        px.run(e, out_local[grp])
+                        torch.cuda.synchronize()
+                        for j in range(len(grp)):
+                            if not torch.equal(px.full(e, j), want[grp][j]):
+                                ok, why = 0.0, f"rows differ from the collective's (round {rnd}, point {e}, layer {j})"
+                    if px.status() != 0:
+                        ok, why = 0.0, f"a wait gave up (status {px.status()})"
+                except Exception as e:   # noqa: BLE001
+                    ok, why, alive = 0.0, f"{type(e).__name__}: {e}", False
         okt = torch.tensor([ok], device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if float(okt) > 0:
