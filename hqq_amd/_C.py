@@ -25,6 +25,9 @@ SYMBOLS = {
     "hqq_hip_unpack": (_i32, [_i32, _vp, _i64, _i64, _vp, _i32, _vp]),
     "hqq_hip_dequantize": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "hqq_hip_meta_check": (_i32, [_i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "hqq_hip_w3s_pack": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "hqq_hip_w3s_unpack": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "hqq_hip_w3s_meta_check": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
@@ -49,7 +52,7 @@ SYMBOLS = {
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -16,7 +16,12 @@ from ..core.quantize import HQQLinear, Quantizer
 
 class HQQLinearHIP(nn.Module):
     """y = x @ dequantize(W_q)^T (+ bias) through hqq_hip_forward.  Keeps the packed tensor bit-identical to the
-    HQQLinear it was built from, so `state_dict()`-level round trips back to the reference stay possible."""
+    HQQLinear it was built from, so `state_dict()`-level round trips back to the reference stay possible.
+
+    3-bit layers (group_size 64, even out_features) are RE-LAID OUT here, once: the reference's container (ten unrelated row slabs per
+    int32, bitpack.py:69-91) becomes the 3-bit stream layout of csrc/w3s.h — what torchao / marlin patching does for their kernels
+    (hqq/backends/torchao.py:202-241, marlin.py:74-123) — and the layer then runs through the 4-bit container's kernels (`self.w3s`).
+    `state_dict()` still carries the reference's container (restored bit for bit by hqq_hip_w3s_unpack) and `load_state_dict` takes it."""
 
     def __init__(self, hqq_layer: HQQLinear):
         super().__init__()
@@ -31,6 +36,9 @@ class HQQLinearHIP(nn.Module):
         W_q = hqq_layer.W_q.data
         if m["view_as_float"]:
             W_q = W_q.view(m["unpack_view_dtype"])
+        self.w3s = bool(self.nbits == 3 and ops.w3s_covers(self.out_features, self.in_features, self.group_size) and W_q.is_cuda)
+        if self.w3s:
+            W_q = ops.w3s_pack(W_q.contiguous(), self.out_features, self.in_features)
         self.W_q = nn.Parameter(W_q.contiguous(), requires_grad=False)
         self.register_buffer("scale", m["scale"].reshape(-1).contiguous(), persistent=True)
         self.register_buffer("zero", m["zero"].reshape(-1).contiguous(), persistent=True)
@@ -40,11 +48,27 @@ class HQQLinearHIP(nn.Module):
     def refresh_opts(self) -> None:
         """May the exact weight rebuild use its three-op form on this layer's (zero, scale)?  (include/hqq_hip.h, hqq_hip_meta_check.)
         Checked when the layer is built and again whenever a state dict is loaded into it; call it after editing `scale` / `zero` in place."""
+        if self.w3s:
+            self.opts = ops.OPT_W3S | (ops.OPT_META_SCALABLE if (self.compute_dtype == torch.float16 and self.scale.is_cuda and
+                                                                  ops.w3s_meta_scalable(self.scale, self.zero, self.out_features, self.in_features)) else 0)
+            return
         self.opts = ops.OPT_META_SCALABLE if (self.compute_dtype == torch.float16 and self.nbits in (8, 4, 2, 1) and self.scale.is_cuda and
                                                ops.meta_scalable(self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits)) else 0
 
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
+    def _container_numel(self) -> int:
+        return ((self.out_features * self.in_features // 64 + 9) // 10) * 64
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.w3s:   # the reference's bytes leave the layer, whatever layout it computes on
+            destination[prefix + "W_q"] = ops.w3s_unpack(self.W_q.data, self.out_features, self.in_features)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "W_q"
+        if self.w3s and key in state_dict and state_dict[key].numel() == self._container_numel() and state_dict[key].dtype == torch.int32:
+            state_dict = dict(state_dict)   # (shallow: only this entry is replaced, the caller's dict stays as it was)
+            state_dict[key] = ops.w3s_pack(state_dict[key].to(self.W_q.device).contiguous(), self.out_features, self.in_features)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
         self.refresh_opts()   # scale / zero are persistent buffers: a loaded checkpoint may not satisfy what the old values did
 
     @staticmethod
@@ -57,7 +81,7 @@ class HQQLinearHIP(nn.Module):
         N, K = m["shape"]
         dt = hqq_layer.compute_dtype
         covered = (dt == torch.float16 and (m["packing"] in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8") or (m["packing"] == "3bit_32" and gs == 64))) or \
-                  (dt == torch.bfloat16 and m["packing"] in ("4bit_u8", "2bit_u8"))
+                  (dt == torch.bfloat16 and (m["packing"] in ("4bit_u8", "2bit_u8") or (m["packing"] == "3bit_32" and ops.w3s_covers(N, K, gs))))
         return (m["axis"] == 1 and covered
                 and bool(gs) and gs % 16 == 0 and K % gs == 0 and (m["packing"] == "3bit_32" or N % ops.PER[Quantizer._packing_bits[m["packing"]]] == 0)
                 and not m.get("quant_scale") and not m.get("quant_zero") and hqq_layer.W_q.is_cuda)
@@ -66,12 +90,16 @@ class HQQLinearHIP(nn.Module):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, nbits={self.nbits}, group_size={self.group_size}"
 
     def dequantize(self) -> Tensor:
-        return ops.dequantize(self.W_q, self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits, 1)
+        W_q = ops.w3s_unpack(self.W_q.data, self.out_features, self.in_features) if self.w3s else self.W_q
+        return ops.dequantize(W_q, self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits, 1)
 
     def forward(self, x: Tensor) -> Tensor:
         if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
         rows = x.numel() // x.shape[-1]
+        if self.w3s:   # every M: GEMV / skinny GEMM on the stream layout, library GEMM on the restored weights beyond 64 rows (ops.forward)
+            return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, 3,
+                               opts=ops.layer_opts(self.opts))
         if (self.compute_dtype == torch.bfloat16 or self.nbits == 3) and rows > 4 and \
                 not ops.skinny_covers(x.dtype, rows, self.out_features, self.in_features, self.group_size, self.nbits):
             # bf16 / 3-bit beyond the decode kernels' 4 rows: HIP dequantise kernel + library GEMM
@@ -128,7 +156,7 @@ class _GroupedMember(nn.Module):
         layers = [m.layer for m in g.members]
         outs = ops.gemv_grouped(x, [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers], self.in_features,
                                 layers[0].group_size, layers[0].nbits,
-                                opts=ops.layer_opts(ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0))
+                                opts=ops.layer_opts(g.opts))
         g.x, g.version, g.outs = x, ver, list(outs)
         out, g.outs[self._index] = g.outs[self._index], None
         return out
@@ -146,20 +174,20 @@ def group_projections(parent: nn.Module, names) -> bool:
     if not all(isinstance(L, HQQLinearHIP) for L in layers) or not 2 <= len(layers) <= ops.GEMV_MAX_GROUP:
         return False
     L0 = layers[0]
-    if any((L.in_features, L.nbits, L.group_size, L.compute_dtype) != (L0.in_features, L0.nbits, L0.group_size, torch.float16) for L in layers):
+    if any((L.in_features, L.nbits, L.group_size, L.compute_dtype, L.w3s) != (L0.in_features, L0.nbits, L0.group_size, torch.float16, L0.w3s) for L in layers):
         return False
     if L0.nbits == 3 and any(L.group_size != 64 for L in layers):
         return False
     state = _GroupState()
     state.max_rows = 4 if (L0.nbits == 3 or L0.in_features % 64) else ops.GEMV_MAX_M   # (5..16 rows need K % 64 == 0)
-    if L0.nbits == 3:   # long K: fewer rows of x fit the kernel's LDS staging (70B down_proj: 2)
+    if L0.nbits == 3 and not L0.w3s:   # long K: fewer rows of x fit the kernel's LDS staging (70B down_proj: 2)
         while state.max_rows and not all(ops.decode_covers(torch.float16, state.max_rows, L.out_features, L.in_features, 64, 3) for L in layers):
             state.max_rows -= 1
         if not state.max_rows:
             return False
-    if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits) for L in layers):
+    if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits, L.w3s) for L in layers):
         state.max_rows = ops.SKINNY_MAX_M   # decode with a batch: still one weight-streaming launch for the group
-    state.opts = ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0
+    state.opts = (ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0) | (ops.OPT_W3S if L0.w3s else 0)
     for i, (n, L) in enumerate(zip(names, layers)):
         m = _GroupedMember(L, state, i)
         state.members.append(m)

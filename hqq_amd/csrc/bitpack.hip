@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "hqq_common.h"
+#include "w3s.h"
 
 namespace hqq {
 
@@ -198,6 +199,51 @@ static int dispatch_bits(int nbits, const void* packed, const void* scale, const
   return HQQ_ERR_NBITS;
 }
 
+
+// =================================================================================================
+// 3-bit: the reference container <-> the stream layout of this build (w3s.h).  Patch-time work (HQQLinearHIP), once per layer.
+//   reference: unpacked row r = n G + k / 64 (G = K / 64) sits in slab t = r / step of word (r % step, k % 64), bits [27 - 3 t, +3)
+// =================================================================================================
+// one thread per (packed row p, chunk c): 2 x 16 consecutive words of the reference container in, 12 bytes out
+__global__ __launch_bounds__(256) void w3s_pack_kernel(const uint32_t* __restrict__ ref, uint32_t* __restrict__ out, int N, int K, int64_t step) {
+  const int chunks = K / W3S_CHUNK_K, G = K / 64;
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= static_cast<int64_t>(N / 2) * chunks) return;
+  const int p = static_cast<int>(id / chunks), c = static_cast<int>(id % chunks);
+  uint32_t D[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int64_t r = static_cast<int64_t>(p + s * (N / 2)) * G + (c >> 2);
+    const int t = static_cast<int>(r / step);
+    const uint32_t* src = ref + (r - t * step) * 64 + (c & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w3s_put(D, s, i, (src[i] >> (27 - 3 * t)) & 7u);
+  }
+  uint32_t* dst = out + id * 3;
+  dst[0] = D[0]; dst[1] = D[1]; dst[2] = D[2];
+}
+// one thread per word of the reference container: its ten levels gathered from the stream layout (rows past R: the zero padding)
+__global__ __launch_bounds__(256) void w3s_unpack_kernel(const uint32_t* __restrict__ w3s, uint32_t* __restrict__ ref, int N, int K, int64_t step, int64_t R) {
+  const int chunks = K / W3S_CHUNK_K, G = K / 64;
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= step * 64) return;
+  const int64_t i = id >> 6;
+  const int col = static_cast<int>(id & 63);
+  uint32_t word = 0u;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    const int64_t r = t * step + i;
+    if (r < R) {
+      const int n = static_cast<int>(r / G), k = static_cast<int>(r % G) * 64 + col;
+      const int s = n >= N / 2 ? 1 : 0, p = n - s * (N / 2);
+      const uint32_t* src = w3s + (static_cast<int64_t>(p) * chunks + (k >> 4)) * 3;
+      const uint32_t D[3] = {src[0], src[1], src[2]};
+      word |= w3s_get(D, s, k & 15) << (27 - 3 * t);
+    }
+  }
+  ref[id] = word;
+}
+
 }  // namespace hqq
 
 using namespace hqq;
@@ -281,6 +327,32 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #undef HQQ_DQ
   set_error("hqq_hip_dequantize: bad dtype %d", dtype);
   return HQQ_ERR_DTYPE;
+}
+
+static int w3s_check(const char* who, const void* a, const void* b, int64_t N, int64_t K) {
+  if (N <= 0 || K <= 0 || N % 2 || K % 64) { set_error("%s: the 3-bit stream layout needs N %% 2 == 0 and K %% 64 == 0 (got %lld x %lld)", who, (long long)N, (long long)K); return HQQ_ERR_SHAPE; }
+  if (N * (K / 64) > INT32_MAX || N * K / 2 > static_cast<int64_t>(INT32_MAX) * 8) { set_error("%s: size overflow", who); return HQQ_ERR_SHAPE; }
+  if (!a || !b) { set_error("%s: null argument", who); return HQQ_ERR_SHAPE; }
+  if (!aligned16(a) || !aligned16(b)) { set_error("%s: pointers must be 16-byte aligned", who); return HQQ_ERR_ALIGN; }
+  return 0;
+}
+
+int hqq_hip_w3s_pack(const void* Wq_ref, void* w3s_out, int64_t N, int64_t K, void* stream) {
+  clear_stale_error();
+  if (const int rc = w3s_check("hqq_hip_w3s_pack", Wq_ref, w3s_out, N, K)) return rc;
+  const int64_t R = N * (K / 64), step = (R + 9) / 10, n = (N / 2) * (K / W3S_CHUNK_K);
+  hipLaunchKernelGGL(w3s_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const uint32_t*>(Wq_ref),
+                     static_cast<uint32_t*>(w3s_out), static_cast<int>(N), static_cast<int>(K), step);
+  return check_launch("hqq_hip_w3s_pack");
+}
+
+int hqq_hip_w3s_unpack(const void* w3s, void* Wq_ref_out, int64_t N, int64_t K, void* stream) {
+  clear_stale_error();
+  if (const int rc = w3s_check("hqq_hip_w3s_unpack", w3s, Wq_ref_out, N, K)) return rc;
+  const int64_t R = N * (K / 64), step = (R + 9) / 10, n = step * 64;
+  hipLaunchKernelGGL(w3s_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const uint32_t*>(w3s),
+                     static_cast<uint32_t*>(Wq_ref_out), static_cast<int>(N), static_cast<int>(K), step, R);
+  return check_launch("hqq_hip_w3s_unpack");
 }
 
 }  // extern "C"

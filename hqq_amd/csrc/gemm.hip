@@ -477,8 +477,9 @@ size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t 
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
   // (the same test as hqq_hip_forward's dispatch)
   if (M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
-  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
-      N % (8 / nbits) == 0)
+  const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);   // the 3-bit stream layout: two row slabs per packed row, served like a 4-bit layer
+  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2 || w3s) && group_size == 64 && K % 256 == 0 && K >= 512 &&
+      N % (w3s ? 2 : 8 / nbits) == 0)
     return hqq_hip_gemv_workspace_bytes(nbits, 1, &N, M, K, group_size, dtype, opts);
   return hqq_hip_gemm_workspace_bytes(nbits, M, N, K, group_size, dtype, opts);
 }
@@ -531,8 +532,9 @@ int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale,
                     void* stream) {
   if (M >= 1 && M <= (nbits == 3 ? 4 : HQQ_GEMV_MAX_M)) return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
   // a batch of 17..64 rows is still weight-streaming work: the skinny-GEMM kernel where it applies (same conditions as skinny_covers)
-  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2) && group_size == 64 && K % 256 == 0 && K >= 512 &&
-      N % (8 / nbits) == 0)
+  const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);
+  if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && (nbits == 8 || nbits == 4 || nbits == 2 || w3s) && group_size == 64 && K % 256 == 0 && K >= 512 &&
+      N % (w3s ? 2 : 8 / nbits) == 0)
     return hqq_hip_gemv(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
   return hqq_hip_gemm(nbits, x, Wq, scale, zero, bias, y, M, N, K, group_size, dtype, opts, workspace, workspace_bytes, stream);
 }

@@ -42,6 +42,7 @@
 #include <type_traits>
 
 #include "gemv_shared.h"
+#include "w3s.h"
 
 namespace hqq {
 
@@ -561,6 +562,8 @@ size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
                hipStream_t st);
+int gemv_w3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
+                 void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, hipStream_t st);
 size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts);
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts,
@@ -621,12 +624,28 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
-  const bool skinny_ok = N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, N, n_layers);
+  if ((opts & HQQ_OPT_W3S) && nbits != 3) { set_error("hqq_hip_gemv: HQQ_OPT_W3S is a 3-bit layout (nbits=%d)", nbits); return HQQ_ERR_SHAPE; }
+  const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);   // the 3-bit stream layout runs through the 4-bit container's kernels (w3s.h)
+  const bool skinny_ok = N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(w3s ? 4 : nbits, M, K, group_size, N, n_layers);
   if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
     set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 8-/4-/2-bit, group_size 64, K %% 256 == 0)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
     return HQQ_ERR_SHAPE;
   }
   if (K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemv: bad K/group_size"); return HQQ_ERR_SHAPE; }
+  if (w3s) {
+    if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
+    if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
+    if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    if (M <= GV_EXACT_ROWWISE_MAX_M) return gemv_w3s_run(n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, dtype, opts, as_stream(stream));
+    if (!skinny_ok) { set_error("hqq_hip_gemv: 3-bit stream layout: M=%lld beyond %d rows needs group_size 64, K %% 256 == 0, K >= 512", (long long)M, GV_EXACT_ROWWISE_MAX_M); return HQQ_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n_layers; ++i) {
+      if (N[i] <= 0 || N[i] % 2) { set_error("hqq_hip_gemv: needs N %% 2 == 0 (got N=%lld)", (long long)N[i]); return N[i] <= 0 ? HQQ_ERR_SHAPE : HQQ_ERR_UNSUPPORTED; }
+      if (N[i] * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+      if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
+      if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    }
+    return skinny_run(3, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
+  }
   if (nbits == 3) {   // int32 containers, ten slabs: its own kernel (gemv3.hip), fp16, exact weights
     if (dtype != HQQ_F16) { set_error("hqq_hip_gemv: the fused 3-bit kernel covers fp16 (got dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
     if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemv: null argument"); return HQQ_ERR_SHAPE; }
@@ -726,6 +745,10 @@ extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void
 
 extern "C" size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
   if (!N || n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || M < 1 || K <= 0 || group_size <= 0) return 0;
+  if (nbits == 3 && (opts & HQQ_OPT_W3S)) {
+    if (M <= GV_EXACT_ROWWISE_MAX_M) return 0;
+    return ((dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(4, M, K, group_size, N, n_layers)) ? skinny_workspace_bytes(3, n_layers, N, M, K, opts) : 0;
+  }
   if (nbits == 3) return gemv3_workspace_bytes(n_layers, N, M, K, group_size, opts);
   if ((dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, N, n_layers)) return skinny_workspace_bytes(nbits, n_layers, N, M, K, opts);
   if (n_layers > 1 && M > GV_EXACT_ROWWISE_MAX_M) {   // a partly covered group is launched layer by layer (hqq_hip_gemv_grouped)
@@ -771,4 +794,21 @@ extern "C" int hqq_hip_meta_check(int nbits, const void* scale, const void* zero
     case 1: hipLaunchKernelGGL(meta_check_kernel<1>, dim3(grid), dim3(256), 0, st, sp, zp, R, static_cast<int>(G), static_cast<int>(N / per), fail_count); break;
   }
   return check_launch("hqq_hip_meta_check");
+}
+
+// every group of a layer in the 3-bit stream layout: zero 2^-9 exact, scale 2^9 finite (the largest J of w3s.h's three field offsets;
+// the smaller ones follow) — meta_check_kernel<8> checks exactly J = 9 for every row
+extern "C" int hqq_hip_w3s_meta_check(const void* scale, const void* zero, int64_t N, int64_t K, uint32_t* fail_count, void* stream) {
+  clear_stale_error();
+  if (!scale || !zero || !fail_count) { set_error("hqq_hip_w3s_meta_check: null argument"); return HQQ_ERR_SHAPE; }
+  if (N <= 0 || K <= 0 || K % 64) { set_error("hqq_hip_w3s_meta_check: bad N/K"); return HQQ_ERR_SHAPE; }
+  const int64_t G = K / 64, R = N * G;
+  if (R > INT32_MAX) { set_error("hqq_hip_w3s_meta_check: size overflow"); return HQQ_ERR_SHAPE; }
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(fail_count, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) { set_error("hqq_hip_w3s_meta_check: hipMemsetAsync: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+  const int grid = static_cast<int>((R + 255) / 256 > 2048 ? 2048 : (R + 255) / 256);
+  hipLaunchKernelGGL(meta_check_kernel<8>, dim3(grid), dim3(256), 0, st, static_cast<const half_t*>(scale), static_cast<const half_t*>(zero), R, static_cast<int>(G),
+                     static_cast<int>(N), fail_count);
+  return check_launch("hqq_hip_w3s_meta_check");
 }

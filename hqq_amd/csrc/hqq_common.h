@@ -14,6 +14,7 @@ using half_t = _Float16;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct bf16_t { uint16_t v; };

@@ -43,6 +43,7 @@
 #include <type_traits>
 
 #include "hqq_common.h"
+#include "w3s.h"
 #include <stdlib.h>
 
 #ifdef SK_LAB_TS
@@ -93,6 +94,8 @@ constexpr int SK_BPW = SK_BLK / SK_SPLIT;     // blocks per wave and chunk
 #endif
 constexpr int SK_RING = SK_RING_DEPTH;        // units in flight per wave (even: the two x buffers alternate with the halves); 4 measured no better
 constexpr int SK_MAX_CPS = 16;          // chunks per K split (the group constants of a split are fetched in one batch)
+// nbits = 3 is the 3-bit STREAM layout (w3s.h): two row slabs per packed row like the 4-bit container, 12 bytes per lane and block
+constexpr int sk_per(int nbits) { return nbits == 3 ? 2 : 8 / nbits; }
 
 typedef _Float16 sk_h8_t __attribute__((ext_vector_type(8)));
 
@@ -263,13 +266,45 @@ struct SkSlabBF16 {
   }
 };
 
+// 3-bit stream layout (w3s.h): one 64-k block of both slabs — the lane's 12 bytes rebuilt exactly (fp16: three- or four-op form; bf16
+// through fp32) into natural-order A fragments, contracted with every m-tile's activation octets
+template <int MT, bool BF16, bool SUB>
+struct SkSlabW3s {
+  template <class FRAG>
+  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[2], const FRAG (&b0)[MT], const FRAG (&b1)[MT], f32x4 (&acc)[2][MT], uint32_t magic) {
+    if constexpr (BF16) {
+      w3s_bf8_t a0[2], a1[2];
+      w3s_rebuild_bf16(w.x, w.y, w.z, zs, a0, a1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[s], b0[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[s], b1[t], acc[s][t], 0, 0, 0);
+        }
+    } else {
+      h8_t a0[2], a1[2];
+      w3s_rebuild_f16<SUB>(w.x, w.y, w.z, zs, magic, a0, a1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[s], b0[t], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s], b1[t], acc[s][t], 0, 0, 0);
+        }
+    }
+  }
+};
+
 struct SkUnit {   // one wave's share of one chunk: SK_BPW KiB of packed weights
   u32x4 w[SK_BPW];
 };
 
 template <int NBITS, int MT, bool BF16, bool SUB = false>
 __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
-  constexpr int PER = 8 / NBITS;
+  constexpr bool W3 = NBITS == 3;
+  constexpr int PER = sk_per(NBITS);
+  constexpr int LB = W3 ? 12 : 16;                  // bytes per lane and block (16 k of PER rows)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [2 buffers][MT][SK_BLK][2 halves][64 lanes] x 16 B
   constexpr int XS_BUF = MT * SK_BLK * 2 * 64;  // u32x4 per buffer
@@ -304,7 +339,10 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   const int rows_per_slab = ly.N / PER;
   int p = (panel - ly.panel0) * SK_ROWS + rg * 16 + r;         // packed row inside the layer
   p = p < rows_per_slab ? p : rows_per_slab - 1;               // ragged last panel: duplicate the last row (masked at the store)
-  const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * K + c * 16;
+  const uint8_t* wrow = ly.Wq + static_cast<int64_t>(p) * (K / 16 * LB) + c * LB;
+  // (3-bit: 12-byte loads through a buffer descriptor over the layer — offsets below 4 GiB, checked on the host)
+  const __amdgpu_buffer_rsrc_t wrs = buffer_rsrc(ly.Wq);
+  const uint32_t wvoff = static_cast<uint32_t>(p) * static_cast<uint32_t>(K / 16 * LB) + static_cast<uint32_t>(c * LB);
   // Whole-line loads (SK_LINE_LOADS, two blocks per wave): a wave instruction that reads 16 rows x 64 B touches HALF of sixteen 128-byte
   // lines, and the other halves come with the next instruction — measured on pure loads (tools/floor_probe.hip, profiles/r03_floor_probe5.txt)
   // that pattern streams 26 % slower than contiguous KiBs, 8 rows x 128 B only 4.5 % slower.  So load L0 = rows 0-7 and L1 = rows 8-15 of
@@ -356,7 +394,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     for (int i = 0; i < XP; ++i) {
       int f = wave + SK_WAVES * i;
       f = f < 8 * MT ? f : 8 * MT - 1;
-      const u32x4 v = sk_permute_x8(xr[set][i]);
+      const u32x4 v = W3 ? xr[set][i] : sk_permute_x8(xr[set][i]);   // (3-bit stream layout: natural k order)
       xs[buf * XS_BUF + f * 64 + lane] = u32x4{v.x & xkeep[set], v.y & xkeep[set], v.z & xkeep[set], v.w & xkeep[set]};
     }
   };
@@ -368,9 +406,14 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
 #pragma unroll
     for (int jl = 0; jl < SK_BPW; ++jl) {
       const int j = hf * SK_BPW + jl;
+      if constexpr (W3) {
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(wrs, live ? wvoff : 0u, live ? (chunk * SK_BLK + j) * (4 * LB) : 0, 2 /* nt */);
+        un.w[jl] = u32x4{v.x, v.y, v.z, 0u};
+      } else {
       const uint8_t* at = LINES ? wline[jl] + static_cast<int64_t>(chunk) * SK_KC + hf * 128 : wrow + static_cast<int64_t>(chunk) * SK_KC + j * 64;
       const u32x4* src = live ? reinterpret_cast<const u32x4*>(at) : reinterpret_cast<const u32x4*>(a.x);
       un.w[jl] = __builtin_nontemporal_load(src);
+      }
     }
   };
 
@@ -404,7 +447,8 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         b0[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
         b1[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
       }
-      if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
+      if constexpr (W3) SkSlabW3s<MT, BF16, SUB>::run(cur.w[jl], zs, b0, b1, acc, magic);
+      else if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else
       SkSlab<NBITS, MT, 0, PER, SUB>::run(cur.w[jl], zs, b0, b1, acc, magic);
     }
@@ -455,7 +499,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       if (cc < c1 - c0) {
         uint16_t* dst = reinterpret_cast<uint16_t*>(mz + (row * PER + s) * mstride + cc * SK_BLK) + hi;
         u32x2 v = mv[rd][pass];
-        if constexpr (SUB) {   // (z, s) -> (z 2^-J, s 2^J), J = 9 - shift of the slab: exact for every group (hqq_hip_meta_check)
+        if constexpr (SUB && !W3) {   // (z, s) -> (z 2^-J, s 2^J), J = 9 - shift of the slab: exact for every group (hqq_hip_meta_check); 3-bit: per field offset, by the consumer
           const int J = 9 - NBITS * (PER - 1 - s);
           const uint16_t fb = static_cast<uint16_t>((hi ? 15 + J : 15 - J) << 10);
           const half2_t f = {__builtin_bit_cast(half_t, fb), __builtin_bit_cast(half_t, fb)};
@@ -644,7 +688,7 @@ static void sk_choose(int total_panels, int nchunks, int forced, int& ks, int& c
   ks = (nchunks + cps - 1) / cps;             // drop empty splits
 }
 static size_t sk_part_bytes(int nbits, int ks, int total_panels, int mt) {
-  return ks > 1 ? static_cast<size_t>(ks) * total_panels * SK_ROWS * (8 / nbits) * 16 * mt * sizeof(float) : 0;
+  return ks > 1 ? static_cast<size_t>(ks) * total_panels * SK_ROWS * sk_per(nbits) * 16 * mt * sizeof(float) : 0;
 }
 
 template <int NBITS, bool BF16, bool SUB = false>
@@ -667,9 +711,9 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
     a.cnt = static_cast<int*>(ws);
     a.part = reinterpret_cast<float*>(static_cast<char*>(ws) + SK_CNT_BYTES);
   }
-  size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * (8 / NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
+  size_t lds = static_cast<size_t>(2) * mt * SK_BLK * 2 * 64 * sizeof(u32x4) + static_cast<size_t>(SK_ROWS) * sk_per(NBITS) * (cps * SK_BLK + 1) * sizeof(uint32_t);
   // the partial tiles of a row group's upper waves meet in the same LDS once the loop is done: (SK_SPLIT - 1) tiles per row group and slab
-  const size_t red = static_cast<size_t>(SK_SPLIT - 1) * SK_RG * (8 / NBITS) * mt * 64 * sizeof(f32x4);
+  const size_t red = static_cast<size_t>(SK_SPLIT - 1) * SK_RG * sk_per(NBITS) * mt * 64 * sizeof(f32x4);
   lds = lds > red ? lds : red;
   const dim3 grid(8, static_cast<unsigned>((a.total_panels + 7) / 8), static_cast<unsigned>(ks)), block(SK_T);   // see the kernel
 #define HQQ_SK_CASE(MT)                                                                                       \
@@ -692,8 +736,8 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
 
 // shapes this kernel covers; everything else stays on the tile kernel of gemv_mfma.hip / the library composition
 bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers) {
-  if ((nbits != 8 && nbits != 4 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
-  const int per = 8 / nbits;
+  if ((nbits != 8 && nbits != 4 && nbits != 3 && nbits != 2) || group_size != 64 || M < 5 || M > 64 || K % SK_KC != 0 || K < 2 * SK_KC) return false;
+  const int per = sk_per(nbits);
   for (int i = 0; i < n_layers; ++i)
     if (N[i] % per != 0 || N[i] / per < 1) return false;
   return true;
@@ -701,7 +745,7 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
 
 // bytes of workspace a skinny launch of this shape needs (0: it does not split K)
 size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts) {
-  const int per = 8 / nbits;
+  const int per = sk_per(nbits);
   int64_t panels = 0;
   for (int i = 0; i < n_layers; ++i) panels += (N[i] / per + SK_ROWS - 1) / SK_ROWS;
   int ks, cps;
@@ -712,7 +756,7 @@ size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
                hipStream_t st) {
-  const int per = 8 / nbits;
+  const int per = sk_per(nbits);
   SkArgs a;
   int64_t panels = 0, ntot = 0;
   for (int i = 0; i < n_layers; ++i) {
@@ -720,6 +764,7 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
     panels += (N[i] / per + SK_ROWS - 1) / SK_ROWS;
     ntot += N[i];
     if (panels > INT32_MAX / 32 || ntot > INT32_MAX / 2) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
+    if (nbits == 3 && (N[i] / 2) * (K / 4) * 3 > static_cast<int64_t>(UINT32_MAX)) { set_error("hqq_hip_gemv: size overflow"); return HQQ_ERR_SHAPE; }
     a.Wq[i] = static_cast<const uint8_t*>(Wq[i]);
     a.scale[i] = static_cast<const half_t*>(scale[i]);
     a.zero[i] = static_cast<const half_t*>(zero[i]);
@@ -738,6 +783,7 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
   a.n_total = static_cast<int>(ntot);
   a.M = static_cast<int>(M);
   a.x = static_cast<const half_t*>(x);
+  if (nbits == 3) return dtype == HQQ_BF16 ? sk_launch<3, true>(a, opts, ws, ws_bytes, st) : (opts & HQQ_OPT_META_SCALABLE) ? sk_launch<3, false, true>(a, opts, ws, ws_bytes, st) : sk_launch<3, false>(a, opts, ws, ws_bytes, st);
   if (dtype == HQQ_BF16) return nbits == 4 ? sk_launch<4, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, true>(a, opts, ws, ws_bytes, st);
   if (opts & HQQ_OPT_META_SCALABLE)
     return nbits == 4 ? sk_launch<4, false, true>(a, opts, ws, ws_bytes, st) : nbits == 2 ? sk_launch<2, false, true>(a, opts, ws, ws_bytes, st) : sk_launch<8, false, true>(a, opts, ws, ws_bytes, st);
@@ -761,7 +807,7 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
 #endif
 static bool sk_takes_narrow(int nbits, int n_layers, const int64_t* N, uint32_t opts) {
   if ((opts & HQQ_OPT_SKINNY_WIDE) || nbits == 8) return false;   // (8-bit: one slab per byte — the narrow tile's constant staging has fewer lines than threads; not built)
-  const int per = 8 / nbits;
+  const int per = sk_wide::sk_per(nbits);
   int64_t prows = 0;
   for (int i = 0; i < n_layers; ++i) prows += N[i] / per;
   return prows <= (nbits == 2 ? 4 : 1) * static_cast<int64_t>(SK_NARROW_MAX_PROWS);

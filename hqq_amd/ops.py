@@ -23,6 +23,7 @@ GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 # per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
 OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC, OPT_GEMM_NARROW, OPT_GEMM_WIDE, OPT_GEMM_NOHYBRID, OPT_SKINNY_WIDE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+OPT_W3S = 1024   # nbits = 3: W_q is the 3-bit stream layout of w3s_pack(), not the reference container
 
 
 def OPT_SKINNY_KS(n: int) -> int:
@@ -85,7 +86,9 @@ def _opts(opts) -> int:
 def layer_opts(meta_opts: int) -> int:
     """Option bits for a LAYER's forward: its own meta-dependent bits (0 / OPT_META_SCALABLE), unless set_gemv_mode(GEMV_FACTORED) is in
     force — then the factored arithmetic for every layer (the three-op bit belongs to the exact rebuild and is dropped)."""
-    return OPT_FACTORED if (_default_opts & OPT_FACTORED) else int(meta_opts)
+    if _default_opts & OPT_FACTORED:
+        return OPT_FACTORED | (int(meta_opts) & OPT_W3S)   # (the layout bit describes the tensor, not the arithmetic: it always travels)
+    return int(meta_opts)
 
 
 # ---- caller-owned workspace of the split-K / slab-sharing decode launches (include/hqq_hip.h "Workspace") --------------------
@@ -159,6 +162,49 @@ def meta_scalable(scale: Tensor, zero: Tensor, N: int, K: int, group_size: int, 
     with torch.cuda.device(scale.device):
         rc = _C.lib().hqq_hip_meta_check(int(nbits), _p(scale.contiguous()), _p(zero.contiguous()), int(N), int(K), int(group_size), F16, _p(cnt), _stream())
     _C.check(rc, "hqq_hip_meta_check")
+    return int(cnt.item()) == 0
+
+
+def w3s_covers(N: int, K: int, group_size) -> bool:
+    """layers the 3-bit stream layout (csrc/w3s.h) can hold: group_size 64, an even number of output rows"""
+    return group_size == 64 and N % 2 == 0 and K % 64 == 0 and N > 0 and K > 0
+
+
+def w3s_pack(W_q: Tensor, N: int, K: int) -> Tensor:
+    """The reference's 3-bit container ([ceil(N K / 640), 64] int32, BitPack.pack_3bit_32) -> the stream layout [N/2, K/16 * 3] int32 that the
+    decode / GEMM kernels read with OPT_W3S (hqq_hip_w3s_pack).  What HQQLinearHIP does once when a 3-bit layer is patched — the
+    re-layout step of the reference's optimised backends (hqq/backends/torchao.py:202-241, marlin.py:74-123)."""
+    _dev(W_q)
+    if W_q.dtype != torch.int32 or W_q.numel() != ((N * K // 64 + 9) // 10) * 64:
+        raise ValueError(f"hqq_amd: w3s_pack takes the [ceil(N K / 640), 64] int32 container of a {N} x {K} layer")
+    out = torch.empty((N // 2, K // 16 * 3), dtype=torch.int32, device=W_q.device)
+    with torch.cuda.device(W_q.device):
+        rc = _C.lib().hqq_hip_w3s_pack(_p(W_q.contiguous()), _p(out), int(N), int(K), _stream())
+    _C.check(rc, "hqq_hip_w3s_pack")
+    return out
+
+
+def w3s_unpack(w3s: Tensor, N: int, K: int) -> Tensor:
+    """stream layout -> the reference's container, bit for bit (zero padding rows included): state_dict() / dequantize() of a patched layer"""
+    _dev(w3s)
+    if w3s.dtype != torch.int32 or w3s.numel() != (N // 2) * (K // 16) * 3:
+        raise ValueError(f"hqq_amd: w3s_unpack takes the [N/2, K/16 * 3] int32 stream layout of a {N} x {K} layer")
+    out = torch.empty(((N * K // 64 + 9) // 10, 64), dtype=torch.int32, device=w3s.device)
+    with torch.cuda.device(w3s.device):
+        rc = _C.lib().hqq_hip_w3s_unpack(_p(w3s.contiguous()), _p(out), int(N), int(K), _stream())
+    _C.check(rc, "hqq_hip_w3s_unpack")
+    return out
+
+
+def w3s_meta_scalable(scale: Tensor, zero: Tensor, N: int, K: int) -> bool:
+    """meta_scalable() for a layer in the 3-bit stream layout (hqq_hip_w3s_meta_check): OPT_META_SCALABLE may accompany OPT_W3S then.  Synchronises."""
+    _dev(scale, zero)
+    if scale.dtype != torch.float16 or zero.dtype != torch.float16:
+        return False
+    cnt = torch.empty(1, dtype=torch.int32, device=scale.device)
+    with torch.cuda.device(scale.device):
+        rc = _C.lib().hqq_hip_w3s_meta_check(_p(scale.contiguous()), _p(zero.contiguous()), int(N), int(K), _p(cnt), _stream())
+    _C.check(rc, "hqq_hip_w3s_meta_check")
     return int(cnt.item()) == 0
 
 
@@ -471,8 +517,11 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None
 LIBRARY_GEMM_MIN_M = 17
 
 
-def skinny_covers(dtype, M, N, K, group_size, nbits) -> bool:
-    """a batch of up to SKINNY_MAX_M rows that the weight-streaming skinny-GEMM kernel serves (csrc/skinny.hip: skinny_covers)"""
+def skinny_covers(dtype, M, N, K, group_size, nbits, w3s: bool = False) -> bool:
+    """a batch of up to SKINNY_MAX_M rows that the weight-streaming skinny-GEMM kernel serves (csrc/skinny.hip: skinny_covers); 3-bit layers
+    in the stream layout only (w3s=True)"""
+    if nbits == 3:
+        return bool(w3s) and dtype in (torch.float16, torch.bfloat16) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512 and N % 2 == 0
     return (dtype in (torch.float16, torch.bfloat16) and nbits in (8, 4, 2) and group_size == 64 and 5 <= M <= SKINNY_MAX_M and K % 256 == 0 and K >= 512
             and N % (8 // nbits) == 0)
 
@@ -500,6 +549,18 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
     M = x.numel() // K if K else 0
     if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
         raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
+    if nbits == 3 and (_opts(opts) & OPT_W3S):
+        # the 3-bit stream layout: the 4-bit container's kernels (1..4 rows: row-per-wave GEMV; 5..64: the skinny GEMM); beyond, the reference
+        # container is restored on the fly for the dequantise kernel + library GEMM (prefill of a patched 3-bit layer)
+        if M <= 4 or (M <= SKINNY_MAX_M and group_size == 64 and K % 256 == 0 and K >= 512 and x.dtype in (torch.float16, torch.bfloat16)):
+            return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
+        if fused:
+            raise NotImplementedError("hqq_amd: no fused GEMM for the 3-bit stream layout beyond 64 rows")
+        W = dequantize(w3s_unpack(W_q, N, K), scale.reshape(-1), zero.reshape(-1), N, K, group_size, 3, 1)
+        y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
+        if bias is not None:
+            y += bias
+        return y.reshape(*x.shape[:-1], N)
     if fused is None:
         fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
             (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M)) or \

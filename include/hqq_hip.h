@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 4
+#define HQQ_HIP_ABI_VERSION 5
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -113,13 +113,27 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_GEMM_WIDE   128u   /* pipelined fused GEMM: force 8 waves per workgroup (128 packed rows per tile) — tuning */
 #define HQQ_OPT_GEMM_NOHYBRID 256u  /* pipelined fused GEMM: never split only the last round of tiles (tuning) */
 #define HQQ_OPT_SKINNY_WIDE 512u  /* 5..64 rows: force the 64-packed-row tile for launches the 32-row tile would serve (tests / tuning) */
-#define HQQ_OPT_ALL (1023u | (255u << 24))
+#define HQQ_OPT_W3S        1024u  /* nbits = 3: Wq is the 3-bit STREAM layout written by hqq_hip_w3s_pack (below), not the reference container */
+#define HQQ_OPT_ALL (2047u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.
  * scale / zero as in hqq_hip_dequantize, axis = 1, fp16.  (No reference counterpart: the reference always does two torch ops.) */
 int hqq_hip_meta_check(int nbits, const void* scale, const void* zero, int64_t N, int64_t K, int64_t group_size, int dtype,
                        uint32_t* fail_count, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * The 3-bit STREAM layout (ABI 5; csrc/w3s.h).  BitPack.pack_3bit_32 (hqq/core/bitpack.py:69-91) ORs ten row slabs of the level
+ * matrix into one int32 with a slab height that is not a multiple of a row's groups: a word mixes ten unrelated output rows.  Like
+ * every optimised backend of the reference (hqq/backends/torchao.py:202-241, marlin.py:74-123: re-layout when a layer is patched),
+ * HQQLinearHIP converts the container ONCE into [N/2, K/16, 3] uint32 — packed row p = output rows p and p + N/2, 12 bytes = 16 k of
+ * both, exactly 3 bits per level — which the decode / GEMM kernels stream like a 4-bit layer (pass HQQ_OPT_W3S with nbits = 3).
+ * scale / zero are unchanged.  hqq_hip_w3s_unpack restores the reference's container bit for bit (state_dict(), dequantize()).
+ * Needs group_size 64 layers: N % 2 == 0, K % 64 == 0.  Wq_ref: [ceil(N K / 640), 64] int32; w3s: N K 3 / 8 bytes.
+ * hqq_hip_w3s_meta_check: hqq_hip_meta_check for a layer in this layout (every group: zero 2^-9 exact, scale 2^9 finite), fp16.
+ * ------------------------------------------------------------------------------------------- */
+int hqq_hip_w3s_pack(const void* Wq_ref, void* w3s_out, int64_t N, int64_t K, void* stream);
+int hqq_hip_w3s_unpack(const void* w3s, void* Wq_ref_out, int64_t N, int64_t K, void* stream);
+int hqq_hip_w3s_meta_check(const void* scale, const void* zero, int64_t N, int64_t K, uint32_t* fail_count, void* stream);
 size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts);
 int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,

@@ -157,6 +157,69 @@ def unpack_np(nbits: int, Pk: np.ndarray) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
+# The 3-bit STREAM layout of this build (hqq_amd/csrc/w3s.h) — no reference counterpart: like the reference's optimised backends
+# (hqq/backends/torchao.py:202-241, marlin.py:74-123) HQQLinearHIP re-lays the levels out when a layer is patched.  Restated here,
+# independently of the HIP code, as the checker of hqq_hip_w3s_pack / hqq_hip_w3s_unpack: [N/2, K/16, 3] uint32, packed row p = output
+# rows p and p + N/2, chunk c = their k 16c..16c+15; a dword holds 5 pair fields (bits [3f, 3f+3) = the pair's even k, [16+3f, +3) its odd k).
+# ---------------------------------------------------------------------------------------------
+def w3s_pos(s: int, i: int):
+    """(dword, bit offset) of level (slab s, i = k % 16) of a chunk; dword -1: the scattered pair — bit t of the level is bit `offset` of dword t"""
+    j, h = i >> 1, (i & 1) * 16
+    if s == 0:
+        return (0, 3 * j + h) if j < 5 else (2, 3 * (j - 5) + h)
+    if j < 5:
+        return (1, 3 * j + h)
+    if j < 7:
+        return (2, 3 * (j - 2) + h)
+    return (-1, 15 + h)
+
+
+def w3s_from_levels(L: np.ndarray) -> np.ndarray:
+    """levels [N, K] (0..7) -> stream layout [N/2, K/16, 3] uint32"""
+    L = np.asarray(L, np.uint8)
+    N, K = L.shape
+    assert N % 2 == 0 and K % 64 == 0
+    out = np.zeros((N // 2, K // 16, 3), np.uint32)
+    for s in range(2):
+        Ls = L[s * (N // 2):(s + 1) * (N // 2)].reshape(N // 2, K // 16, 16).astype(np.uint32)
+        for i in range(16):
+            d, b = w3s_pos(s, i)
+            if d >= 0:
+                out[:, :, d] |= Ls[:, :, i] << np.uint32(b)
+            else:
+                for t in range(3):
+                    out[:, :, t] |= ((Ls[:, :, i] >> np.uint32(t)) & np.uint32(1)) << np.uint32(b)
+    return out
+
+
+def w3s_to_levels(D: np.ndarray, N: int, K: int) -> np.ndarray:
+    D = np.asarray(D, np.uint32).reshape(N // 2, K // 16, 3)
+    L = np.zeros((N, K), np.uint8)
+    for s in range(2):
+        Ls = np.zeros((N // 2, K // 16, 16), np.uint32)
+        for i in range(16):
+            d, b = w3s_pos(s, i)
+            if d >= 0:
+                Ls[:, :, i] = (D[:, :, d] >> np.uint32(b)) & np.uint32(7)
+            else:
+                for t in range(3):
+                    Ls[:, :, i] |= ((D[:, :, t] >> np.uint32(b)) & np.uint32(1)) << np.uint32(t)
+        L[s * (N // 2):(s + 1) * (N // 2)] = Ls.reshape(N // 2, K).astype(np.uint8)
+    return L
+
+
+def w3s_pack_np(ref_container: np.ndarray, N: int, K: int) -> np.ndarray:
+    """the reference's 3-bit container ([ceil(R/10), 64] int32, bitpack.py:69-91) -> stream layout"""
+    R = N * K // 64
+    return w3s_from_levels(unpack_np(3, ref_container)[:R].reshape(N, K))
+
+
+def w3s_unpack_np(w3s: np.ndarray, N: int, K: int) -> np.ndarray:
+    """stream layout -> the reference's container, bit for bit (zero padding rows included)"""
+    return pack_np(3, w3s_to_levels(w3s, N, K).reshape(N * K // 64, 64))
+
+
+# ---------------------------------------------------------------------------------------------
 # Quantizer.quantize (axis=1) with the legacy proximal solver, float32
 # ---------------------------------------------------------------------------------------------
 def max_v_of(nbits) -> int:

@@ -38,7 +38,7 @@ def test_argument_errors_do_not_need_a_gpu():
     rc = L.hqq_hip_gemv(5, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, 0, None, 0, None)
     assert rc == -4 and b"not covered" in L.hqq_hip_last_error()
     # unknown option bits are an argument error, not ignored
-    assert L.hqq_hip_gemv(4, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, 1 << 10, None, 0, None) == -2
+    assert L.hqq_hip_gemv(4, 16, 16, 16, 16, None, 16, 1, 64, 64, 64, 1, 1 << 15, None, 0, None) == -2
     # the decode kernel addresses a layer with 32-bit byte offsets: 2^22 packed rows x 1024 bytes is one byte too many, and says so
     assert L.hqq_hip_gemv(4, 16, 16, 16, 16, None, 16, 1, 1 << 23, 1024, 64, 1, 0, None, 0, None) == -2
     assert b"size overflow" in L.hqq_hip_last_error()
