@@ -120,6 +120,12 @@ def make_layer(ops, name, N, K, nbits, dev, seed, random_codes, cd=torch.float16
         Wq, s, z = ops.quantize(W, nbits=nbits, group_size=64, round_zero=(nbits == 4))
         # HQQLinear.cuda(): meta is cast to compute_dtype (quantize.py:515-583)
         L.Wq, L.scale, L.zero = Wq, s.to(cd), z.to(cd)
+    if nbits == 3 and ops.w3s_covers(N, K, 64):
+        # what HQQLinearHIP holds for a 3-bit layer: the levels re-laid out ONCE, at patch time, into the stream layout (csrc/w3s.h) — the
+        # reference's optimised backends re-lay out at patch time too (hqq/backends/torchao.py:202-241, marlin.py:74-123); scale / zero unchanged
+        L.Wq = ops.w3s_pack(L.Wq, N, K)
+        L.opts = ops.OPT_W3S | (ops.OPT_META_SCALABLE if (cd == torch.float16 and ops.w3s_meta_scalable(L.scale, L.zero, N, K)) else 0)
+        return L
     L.opts = ops.OPT_META_SCALABLE if (cd == torch.float16 and nbits in (8, 4, 3, 2) and ops.meta_scalable(L.scale, L.zero, N, K, 64, nbits)) else 0
     return L
 
@@ -367,9 +373,10 @@ def main():
     base_opts = ops.OPT_FACTORED if a.gemv_mode == "factored" else 0
 
     def group_opts(Ls):
+        lay = ops.OPT_W3S if (Ls[0].opts & ops.OPT_W3S) else 0   # (the layout bit describes the tensor: it travels in every mode)
         if a.gemv_mode != "exact":
-            return base_opts
-        return ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0
+            return base_opts | lay
+        return (ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0) | lay
 
     per_slab = 1 if nbits == 3 else 8 // nbits
 
@@ -764,10 +771,16 @@ def main():
                         for blk in blks:
                             for grp in EXCHANGE_GROUPS:
                                 Ls = [blk[name] for name in grp]
-                                o_ = ops.OPT_META_SCALABLE if (a.gemv_mode == "exact" and all(L.opts & ops.OPT_META_SCALABLE for L in Ls)) else 0
+                                o_ = group_opts(Ls)
                                 ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nb, outs=out_local[grp], opts=o_)
                     leg(f"7b-stack bs=1 int{nb} (128 stream-ordered launches)", step_nb, nblocks * sum(gemv_bytes(N, K, nb, 1) for _, N, K in BLOCK), 1,
                         nblocks * len(EXCHANGE_GROUPS), _decode_kernel_name(nb, 1, a.dtype, a.gemv_mode))
+                    if nb == 3:   # the bytes the launches actually read (stream layout: exactly 3 bits per level) beside SURVEY.md section 8d's (the reference container)
+                        stored = nblocks * sum(N * K * 3 // 8 + 4 * (N * K // 64) + 2 * K + 2 * N for _, N, K in BLOCK)
+                        legs[-1]["stored_bytes_per_step"] = stored
+                        legs[-1]["roofline_frac_on_stored_bytes"] = round(legs[-1]["roofline_frac"] * stored / (nblocks * sum(gemv_bytes(N, K, 3, 1) for _, N, K in BLOCK)), 4)
+                        legs[-1]["layout"] = "3-bit stream layout (csrc/w3s.h), re-laid out once at patch time as HQQLinearHIP does; value / roofline_frac on SURVEY.md section 8d bytes"
+                        legs[-1]["three_op_rebuild"] = f"{sum(1 for blk in blks for L in blk.values() if L.opts & ops.OPT_META_SCALABLE)}/{nblocks * len(BLOCK)}"
                     del blks
                     torch.cuda.empty_cache()
                 except Exception as e:
@@ -849,7 +862,8 @@ def main():
 def _decode_kernel_name(nbits, M, dtype, mode):
     """the kernel hqq_hip_gemv dispatches the bench's launches to (gemv.hip / skinny.hip / gemv3*.hip)"""
     if nbits == 3:
-        return "hqq::gemv3s_kernel + gemv3s_finish_kernel (launches >= 19 MB) / hqq::gemv3_f16_kernel"
+        return ("hqq::gemv_w3s_kernel<3, %d, gs64, exact, %s> (3-bit stream layout)" % (M, "bf16" if dtype == "bf16" else "f16")) if M < 5 else \
+               f"hqq::skinny_f16_kernel<3 (stream layout), {(M + 15) // 16}, {'bf16' if dtype == 'bf16' else 'f16'}>"
     if M >= 5:
         return f"hqq::skinny_f16_kernel<{nbits}, {(M + 15) // 16}, {'bf16' if dtype == 'bf16' else 'f16'}>"
     arith = "factored" if mode == "factored" else ("exact, three-op rebuild" if mode == "exact" and dtype == "f16" else "exact")
