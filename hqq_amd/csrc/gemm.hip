@@ -459,6 +459,7 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
 constexpr int64_t GEMM_PIPE_MAX_M = GEMM_PIPE_MAX_M_VALUE;
 static bool use_pipe(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts) {
   if (opts & (HQQ_OPT_GEMM_REGTILE | HQQ_OPT_GEMM_CLASSIC)) return false;
+  if (nbits == 3 && !(opts & HQQ_OPT_W3S)) return false;   // (the reference's 3-bit container has no fused GEMM; the stream layout runs like a 4-bit layer)
   return (M <= GEMM_PIPE_MAX_M || nbits == 8) && gemm_pipe_covers(nbits, M, N, K, gs, dtype);   // (8-bit: the only fused GEMM there is)
 }
 
@@ -492,7 +493,7 @@ int hqq_hip_gemm_plan(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_
   return 0;
 }
 
-int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {
+int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {   // (nbits = 3: asked for a layer in the stream layout)
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
   if (M <= HQQ_GEMV_MAX_M) return 1;          // decode: always the weight-streaming kernels (hqq_hip_gemv reports what it does not cover)
   if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, &N, 1)) return 1;

@@ -27,9 +27,12 @@
 //   split-K   grid = tiles x KS; every split parks its fp32 tile in the caller's workspace and a second small launch adds the KS
 //             tiles in split order, rounds, adds the bias and stores: fixed order, reproducible bits.
 #include "decode_common.h"
+#include "w3s.h"
 
 namespace hqq {
 
+// nbits = 3 is the 3-bit STREAM layout (w3s.h): two row slabs per packed row like the 4-bit container, 12 bytes per lane and step
+constexpr int gd_per(int nbits) { return nbits == 3 ? 2 : 8 / nbits; }
 constexpr int GD_K = 64;   // k per step.  Waves per workgroup NW (4 or 8: 16 NW packed rows per tile) and tokens per tile BM (128 or 256) are template parameters
 constexpr int GD_MAX_KS = 16;
 template <int NW, int BM> struct GdCfg {   // LDS rings: x stages / steps ahead, packed-weight slots / steps ahead (odd), (zero, scale) slots of two steps
@@ -60,6 +63,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void gd_dma16(const void* src, uint8_t* lds_wave_base) {   // lane l: 16 bytes from src -> lds_wave_base + 16 l
   __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void gd_dma12(const void* src, uint8_t* lds_wave_base) {   // lane l: 12 bytes -> lds_wave_base + 12 l
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 12, 0, 0);
 }
 __device__ __forceinline__ void gd_dma4(const void* src, uint8_t* lds_wave_base) {    // lane l: 4 bytes -> lds_wave_base + 4 l
   __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 4, 0, 0);
@@ -160,14 +166,16 @@ template <bool BF> __device__ __forceinline__ uint16_t gd_out(float v, const hal
 }
 
 template <int NBITS> struct GdMeta {   // (zero, scale) DMA: one dword = the two steps' values of one (row, slab, zero | scale)
-  static constexpr int PER = 8 / NBITS;
+  static constexpr int PER = gd_per(NBITS);
   static constexpr int NI = (PER * 2 * 16 + 63) / 64;         // DMA instructions per wave and pair of steps
   static constexpr int SLOT = NI * 256;                        // bytes per wave and pair of steps
 };
 
 template <int NBITS, bool SUB, int NW, int BM, bool BF>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
-  constexpr int PER = 8 / NBITS;
+  constexpr bool W3 = NBITS == 3;
+  constexpr int PER = gd_per(NBITS);
+  constexpr int LB = W3 ? 12 : 16;   // bytes per lane and step (16 k of PER rows)
   using CF = GdCfg<NW, BM>;
   constexpr int GD_BM = BM, GD_MT = BM / 16, GD_DX = CF::DX, GD_PX = CF::PX, GD_DW = CF::DW, GD_PW = CF::PW, GD_DM = CF::DM, GD_XSTAGE = CF::XSTAGE;
   constexpr int GD_WAVES = NW, GD_T = 64 * NW, GD_PROWS = 16 * NW, XP = BM / 8 / NW;   // XP: x DMA pieces (1 KiB = 8 token rows) per wave and step
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   //      M read row 0: their accumulator columns are never stored, and a column depends on its own x row only) ----
   const bool w_active = (p0 + r) < rows_per_slab;
   const int wrow = w_active ? p0 + r : rows_per_slab - 1;
-  const uint8_t* wsrc = a.Wq + static_cast<int64_t>(wrow) * K + c * 16 + static_cast<int64_t>(kt0) * GD_K;
+  const uint8_t* wsrc = a.Wq + static_cast<int64_t>(wrow) * (K / 16 * LB) + c * LB + static_cast<int64_t>(kt0) * (4 * LB);
   const half_t* xsrc[XP];
 #pragma unroll
   for (int q = 0; q < XP; ++q) {   // piece XP w + q fills rows 8 (XP w + q) .. + 7 of the stage: lane -> (row, position)
@@ -231,7 +239,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
 
   auto issue_w = [&](int step) {   // packed weights of `step`
     const int sc = step < nsteps ? step : nsteps - 1;   // past the range: the last step again (cached; lands in a slot nobody reads)
-    gd_dma16(wsrc + static_cast<int64_t>(sc) * GD_K, wring + ((step % GD_DW) * GD_WAVES + wave) * 1024);
+    if constexpr (W3) gd_dma12(wsrc + static_cast<int64_t>(sc) * (4 * LB), wring + ((step % GD_DW) * GD_WAVES + wave) * 1024);
+    else gd_dma16(wsrc + static_cast<int64_t>(sc) * GD_K, wring + ((step % GD_DW) * GD_WAVES + wave) * 1024);
   };
   auto issue_m = [&](int step) {   // step even: the (zero, scale) pairs of steps (step, step + 1)
     const int sc = step < nsteps ? step : ((nsteps - 1) & ~1);
@@ -256,9 +265,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
       sc_[0][s] = static_cast<uint16_t>(sd) & smask; sc_[1][s] = static_cast<uint16_t>(sd >> 16) & smask;
     }
   };
-  auto read_w = [&](int step) { return *reinterpret_cast<const u32x4*>(wring + ((step % GD_DW) * GD_WAVES + wave) * 1024 + lane * 16); };
+  auto read_w = [&](int step) {
+    const uint8_t* slot = wring + ((step % GD_DW) * GD_WAVES + wave) * 1024;
+    if constexpr (W3) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(slot + lane * 12);
+      return u32x4{q[0], q[1], q[2], 0u};
+    } else {
+      return *reinterpret_cast<const u32x4*>(slot + lane * 16);
+    }
+  };
   auto rebuild = [&](const u32x4& raw, int step, u32x4 (&a0)[PER], u32x4 (&a1)[PER]) {
-    if constexpr (BF) {
+    if constexpr (W3) {   // the stream layout is in natural k order already
+      const uint32_t zs[2] = {static_cast<uint32_t>(zc[step & 1][0]) | (static_cast<uint32_t>(sc_[step & 1][0]) << 16),
+                              static_cast<uint32_t>(zc[step & 1][1]) | (static_cast<uint32_t>(sc_[step & 1][1]) << 16)};
+      if constexpr (BF) {
+        w3s_bf8_t h0[2], h1[2];
+        w3s_rebuild_bf16(raw.x, raw.y, raw.z, zs, h0, h1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { a0[s] = __builtin_bit_cast(u32x4, h0[s]); a1[s] = __builtin_bit_cast(u32x4, h1[s]); }
+      } else {
+        h8_t h0[2], h1[2];
+        w3s_rebuild_f16<SUB>(raw.x, raw.y, raw.z, zs, 0x64006400u, h0, h1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { a0[s] = __builtin_bit_cast(u32x4, h0[s]); a1[s] = __builtin_bit_cast(u32x4, h1[s]); }
+      }
+    } else if constexpr (BF) {
       GdSlabBF<NBITS, 0, PER>::run(raw, zc[step & 1], sc_[step & 1], a0, a1);
     } else {
       u32x4 w;
@@ -503,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
 // inside the first kernel (ticket scheme) read its KS x 64 KiB alone and cost 2-3 us per split.
 template <int NBITS, int NW, int BM, bool BF>
 __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs a) {
-  constexpr int PER = 8 / NBITS, GD_T = 64 * NW, GD_PROWS = 16 * NW, GD_BM = BM, GD_MT = BM / 16;
+  constexpr int PER = gd_per(NBITS), GD_T = 64 * NW, GD_PROWS = 16 * NW, GD_BM = BM, GD_MT = BM / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, c = lane >> 4;
   const int sj = blockIdx.x % (PER * GD_MT), stile = blockIdx.x / (PER * GD_MT), tile = a.full + stile;   // (the split tiles only)
@@ -544,7 +575,7 @@ struct GpPlan { int NW, BM, n_tiles, m_tiles, KS, kps, full; };   // full: tiles
 
 static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm, int ks) {
   GpPlan p;
-  const int64_t rows_per_slab = N / (8 / nbits);
+  const int64_t rows_per_slab = N / gd_per(nbits);
   const int nk = static_cast<int>(K / GD_K);
   p.NW = nw;
   p.BM = bm;
@@ -619,7 +650,7 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   if (p.KS <= 1) return 0;
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full;
-  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * p.BM * (16 * p.NW) * (8 / nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
+  return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * p.BM * (16 * p.NW) * gd_per(nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
 }
 
 // Where this kernel beats "dequantise kernel + library GEMM" on MI355X (profiles/r02_prefill_sweep.md, Llama-2-7B shapes, int4): up to
@@ -641,8 +672,8 @@ void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opt
 }
 
 bool gemm_pipe_covers(int nbits, int64_t M, int64_t N, int64_t K, int64_t gs, int dtype) {
-  if ((dtype != HQQ_F16 && dtype != HQQ_BF16) || (nbits != 8 && nbits != 4 && nbits != 2)) return false;
-  const int per = 8 / nbits;
+  if ((dtype != HQQ_F16 && dtype != HQQ_BF16) || (nbits != 8 && nbits != 4 && nbits != 3 && nbits != 2)) return false;   // (3: the stream layout — the caller checks HQQ_OPT_W3S)
+  const int per = gd_per(nbits);
   // group_size 64 = one step: a step's weights share one (zero, scale) per row; K / 64 even: two steps' constants per DMA dword
   return N % per == 0 && (N / per) % 4 == 0 && gs == 64 && K % 128 == 0 && M >= 1;
 }
@@ -666,7 +697,7 @@ static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
   hipLaunchKernelGGL((gemm_pipe_f16_kernel<NBITS, SUB, NW, BM, BF>), dim3(static_cast<unsigned>(blocks)), dim3(64 * NW), lds_bytes, st, a);
   int rc = check_launch("hqq_hip_gemm(pipelined)");
   if (rc || a.KS <= 1) return rc;
-  const int64_t rblocks = (static_cast<int64_t>(a.n_tiles) * a.m_tiles - a.full) * ((8 / NBITS) * (BM / 16));
+  const int64_t rblocks = (static_cast<int64_t>(a.n_tiles) * a.m_tiles - a.full) * (gd_per(NBITS) * (BM / 16));
   hipLaunchKernelGGL((gemm_pipe_reduce_kernel<NBITS, NW, BM, BF>), dim3(static_cast<unsigned>(rblocks)), dim3(64 * NW), 0, st, a);
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
@@ -676,7 +707,7 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
   const GpPlan p = gp_plan(nbits, M, N, K, opts);
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
   const int64_t blocks = p.full + (tiles - p.full) * p.KS;
-  if (blocks * ((8 / nbits) * (p.BM / 16)) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
+  if (blocks * (gd_per(nbits) * (p.BM / 16)) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
   GdArgs a;
   a.x = static_cast<const half_t*>(x); a.Wq = static_cast<const uint8_t*>(Wq); a.scale = static_cast<const half_t*>(scale);
   a.zero = static_cast<const half_t*>(zero); a.bias = static_cast<const half_t*>(bias); a.y = static_cast<half_t*>(y);
@@ -697,6 +728,7 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
 #define GP_GO(NB) (dtype == HQQ_BF16 ? GP_GO3(NB, false, true) : sub ? GP_GO3(NB, true, false) : GP_GO3(NB, false, false))
   if (nbits == 8) return GP_GO(8);
   if (nbits == 4) return GP_GO(4);
+  if (nbits == 3) return GP_GO(3);
   return GP_GO(2);
 #undef GP_GO3
 #undef GP_GO

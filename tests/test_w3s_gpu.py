@@ -37,9 +37,10 @@ def _layer(N, K, seed, dt=torch.float16, sub_friendly=False):
     z = (torch.rand(R, 1, generator=g) * 7).to(dt)
     if sub_friendly:
         z = z.float().clamp_min(0.0625).to(dt)   # lowest bit of every zero-point >= 2^-15: z 2^-9 is exact in fp16
-    else:   # a few zero-points far below one level: q - z must still round once; and tiny ones that fail the meta check
+    else:   # a few zero-points far below one level: q - z must still round once; and one whose lowest bit (2^-16) fails the meta check
         z.view(-1)[::5] = 0.00836
         z.view(-1)[1::11] = 2.0 ** -12
+        z.view(-1)[2] = 2.0 ** -6 * (1 + 2.0 ** -10)
     return U, s, z
 
 
@@ -74,7 +75,7 @@ def _probe_ks(K):
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
 @pytest.mark.parametrize("NK", [(512, 1024), (130, 192), (12, 128), (1002, 4096), (4096, 4096), (64, 11008), (256, 2048 + 768)])
 def test_w3s_gemv_vs_oracle(ops, oracle, M, NK):
-    """1..4 activation rows, fp16: the row-per-wave decode kernel on the stream layout (general four-op rebuild: these zero-points fail the meta check)"""
+    """1..4 activation rows, fp16: the row-per-wave decode kernel on the stream layout (general four-op rebuild: one zero-point fails the meta check)"""
     N, K = NK
     U, s, z = _layer(N, K, seed=N + K + M)
     P, Wd = _oracle_W(oracle, U, s, z, N, K, 1)
@@ -82,7 +83,8 @@ def test_w3s_gemv_vs_oracle(ops, oracle, M, NK):
     bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).half() if M % 2 else None
     yo, _ = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
     W3, sd, zd = ops.w3s_pack(dev(P), N, K), s.cuda(), z.cuda()
-    assert not ops.w3s_meta_scalable(sd, zd, N, K)
+    if N * K // 64 > 2:
+        assert not ops.w3s_meta_scalable(sd, zd, N, K)
     y = ops.gemv(x.cuda(), W3, sd, zd, None if bias is None else bias.cuda(), N, K, 64, 3, opts=ops.OPT_W3S)
     torch.testing.assert_close(y.float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3)
     assert torch.equal(y, ops.forward(x.cuda(), W3, sd, zd, None if bias is None else bias.cuda(), N, K, 64, 3, opts=ops.OPT_W3S))
@@ -176,6 +178,53 @@ def test_w3s_skinny_gemm_vs_oracle(ops, oracle, dt, M, NK):
     ye = ops.gemv(e, W3, sd, zd, None, N, K, 64, 3, opts=ops.OPT_W3S)
     for r, k in enumerate(ks):
         assert torch.equal(ye[r], Wdev[:, k]), f"column {k}"
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(65, 256, 256), (200, 384, 512), (128, 4096, 4096), (1000, 512, 4096), (640, 128, 11008)])
+def test_w3s_pipelined_gemm_vs_oracle(ops, oracle, dt, M, N, K):
+    """beyond 64 rows: the pipelined split-K MFMA GEMM (gemm_pipe.hip) on the stream layout — LDS-DMA in 12-byte pieces, the same rebuild"""
+    code = 2 if dt == torch.bfloat16 else 1
+    U, s, z = _layer(N, K, seed=N + K + M, dt=dt, sub_friendly=(M % 2 == 0))
+    P, Wd = _oracle_W(oracle, U, s, z, N, K, code)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dt)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(2)).to(dt) if M % 2 else None
+    if code == 2:
+        yo, _ = oracle.matmul(raw16(x), Wd, None if bias is None else raw16(bias), 2)
+        want = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+    else:
+        yo, _ = oracle.matmul(x.numpy(), Wd, None if bias is None else bias.numpy(), 1)
+        want = torch.from_numpy(yo.astype(np.float32))
+    W3, sd, zd = ops.w3s_pack(dev(P), N, K), s.cuda(), z.cuda()
+    o = ops.OPT_W3S | (ops.OPT_META_SCALABLE if (code == 1 and ops.w3s_meta_scalable(sd, zd, N, K)) else 0)
+    y = ops.forward(x.cuda(), W3, sd, zd, None if bias is None else bias.cuda(), N, K, 64, 3, fused=True, opts=o)
+    if code == 2:
+        torch.testing.assert_close(y.float().cpu(), want, rtol=2.0 ** -7, atol=2e-3)
+    else:
+        torch.testing.assert_close(y.float().cpu(), want, rtol=1e-3, atol=1e-3)
+    if o & ops.OPT_META_SCALABLE:   # the three-op rebuild gives the four-op form's bits
+        assert torch.equal(y, ops.forward(x.cuda(), W3, sd, zd, None if bias is None else bias.cuda(), N, K, 64, 3, fused=True, opts=ops.OPT_W3S))
+    Wdev = ops.dequantize(dev(P), sd.reshape(-1), zd.reshape(-1), N, K, 64, 3)
+    ks = _probe_ks(K)
+    e = torch.zeros(M, K, dtype=dt, device="cuda")
+    for r, k in enumerate(ks): e[r, k] = 1.0
+    ye = ops.forward(e, W3, sd, zd, None, N, K, 64, 3, fused=True, opts=o)
+    for r, k in enumerate(ks):
+        assert torch.equal(ye[r], Wdev[:, k]), f"column {k}"
+    assert torch.count_nonzero(ye[len(ks):]) == 0
+
+
+def test_w3s_meta_check_reports_a_zero_point_below_the_grid(ops):
+    N, K = 16, 128
+    s = torch.full((N * K // 64, 1), 0.003, dtype=torch.float16, device="cuda")
+    z = torch.full((N * K // 64, 1), 3.5, dtype=torch.float16, device="cuda")
+    assert ops.w3s_meta_scalable(s, z, N, K)
+    z[7] = 2.0 ** -6 * (1 + 2.0 ** -10)     # lowest bit 2^-16: z 2^-9 is not a multiple of 2^-24
+    assert not ops.w3s_meta_scalable(s, z, N, K)
+    z[7] = 2.0 ** -5 * (1 + 2.0 ** -10)     # lowest bit 2^-15: exact
+    assert ops.w3s_meta_scalable(s, z, N, K)
+    s[3] = 200.0                            # scale 2^9 overflows fp16
+    assert not ops.w3s_meta_scalable(s, z, N, K)
 
 
 def test_w3s_grouped_launch_equals_single_launches(ops, oracle):
