@@ -493,9 +493,10 @@ int hqq_hip_gemm_plan(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_
   return 0;
 }
 
-int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {   // (nbits = 3: asked for a layer in the stream layout)
+int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype) {
   if (M < 1 || N <= 0 || K <= 0 || group_size <= 0) return 0;
   if (M <= HQQ_GEMV_MAX_M) return 1;          // decode: always the weight-streaming kernels (hqq_hip_gemv reports what it does not cover)
+  if (nbits == 3) return 0;   // the reference's 3-bit container has no fused kernel beyond the decode rows; a layer in the stream layout asks with nbits = 4 (same kernels, same plan)
   if (M <= HQQ_GEMV_MAX_M_SKINNY && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(nbits, M, K, group_size, &N, 1)) return 1;
   return gemm_pipe_covers(nbits, M, N, K, group_size, dtype) && gemm_pipe_wins(nbits, M, N, K) ? 1 : 0;
 }

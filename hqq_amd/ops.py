@@ -553,7 +553,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
         # the 3-bit stream layout: the 4-bit container's kernels (1..4 rows: row-per-wave GEMV; 5..64: the skinny GEMM); beyond, the reference
         # container is restored on the fly for the dequantise kernel + library GEMM (prefill of a patched 3-bit layer)
         if M <= 4 or (M <= SKINNY_MAX_M and group_size == 64 and K % 256 == 0 and K >= 512 and x.dtype in (torch.float16, torch.bfloat16)) or fused or \
-                (fused is None and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(3, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):
+                (fused is None and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(4, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):   # (asked as a 4-bit layer: same kernels, same plan)
             return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
         W = dequantize(w3s_unpack(W_q, N, K), scale.reshape(-1), zero.reshape(-1), N, K, group_size, 3, 1)
         y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
