@@ -372,8 +372,10 @@ def main():
     grouped = decode and not a.no_group and nbits in (4, 3, 2, 8, 1)
     base_opts = ops.OPT_FACTORED if a.gemv_mode == "factored" else 0
 
+    extra_opts = int(os.environ.get("HQQ_BENCH_OPTS", "0"), 0)   # study switch: option bits OR-ed into every decode call (e.g. 4096 = OPT_BATCH_OLD)
+
     def group_opts(Ls):
-        lay = ops.OPT_W3S if (Ls[0].opts & ops.OPT_W3S) else 0   # (the layout bit describes the tensor: it travels in every mode)
+        lay = (ops.OPT_W3S if (Ls[0].opts & ops.OPT_W3S) else 0) | extra_opts   # (the layout bit describes the tensor: it travels in every mode)
         if a.gemv_mode != "exact":
             return base_opts | lay
         return (ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0) | lay
