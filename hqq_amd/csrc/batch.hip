@@ -29,6 +29,9 @@
 //            or what else was in the launch — so a row's bits do not depend on the batch or the group it was computed in.
 #include "decode_common.h"
 
+#ifdef BT_LAB_TS
+extern unsigned long long* g_bt_lab_ts;
+#endif
 namespace hqq {
 namespace bt {
 
@@ -49,7 +52,15 @@ struct BtArgs {
   int unit_end[BT_MAXL];    // end (exclusive) of layer i's units in the concatenated unit space (unused entries repeat the last)
   const half_t* x;
   int M, K, G, total_units, HU, MH, RS;   // MH: token halves (1: M <= 32, 2: 33..64); RS: bytes per row of the group constants in LDS
+#ifdef BT_LAB_TS
+  unsigned long long* ts;   // lab only (tools/batch_lab.hip): eight time stamps per wave
+#endif
 };
+#ifdef BT_LAB_TS
+#define BT_TS(i) do { if (t_[i] == 0) t_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)   /* 100 MHz, one clock for the whole device; first occurrence */
+#else
+#define BT_TS(i)
+#endif
 
 typedef __attribute__((address_space(3))) void* bt_lds_t;
 typedef const __attribute__((address_space(1))) void* bt_glb_t;
@@ -141,7 +152,7 @@ __device__ __forceinline__ void bt_rebuild_bf16(const u32x4& w, uint16_t z, uint
 // ---- the loader wave: group constants of the tile, then the packed chunks, D - 1 chunks ahead of the compute waves -------------------
 // LDS weight slot of a chunk: [block b][unit u][16 / PER rows][64 bytes] — (b HU + u) UB bytes in; one DMA instruction = PER (block, unit) pairs.
 template <int NBITS, int HU, int D>
-__device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT_HUMAX], uint8_t* wring, uint8_t* zmeta, uint8_t* smeta, int lane, int nchunks, int BPC) {
+__device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT_HUMAX], uint8_t* wring, uint8_t* zmeta, uint8_t* smeta, int lane, int nchunks, int BPC, unsigned long long* t_) {
   constexpr int PER = 8 / NBITS, UR = 16 / PER, UB = UR * 64, LPP = 64 / PER;   // rows per unit, bytes per (unit, block), lanes per pair
   const int K = a.K, G = a.G, RS = a.RS, nblocks = K / 64;
   const int chw = BPC * HU * UB;          // bytes per chunk slot
@@ -191,13 +202,18 @@ __device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT
   };
 #pragma unroll
   for (int c = 0; c < D - 1; ++c) issue_w(c);
+  BT_TS(2);
   for (int c = 0; c < nchunks; ++c) {
     // everything up to chunk c has landed: the instructions issued after it are those of chunks c + 1 .. c + D - 2
     if (BPC == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (8 * HU / PER)) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (4 * HU / PER > 0 ? 4 * HU / PER : 1)) : "memory");
     __builtin_amdgcn_s_barrier();              // b_c: chunk c is in LDS for everyone; the compute waves have finished reading chunk c - 1
+#ifdef BT_LAB_TS
+    if (c == 0) BT_TS(3); else if (c == 1) BT_TS(4); else if (c == nchunks - 1) BT_TS(5);
+#endif
     issue_w(c + D - 1);                        // into the slot of chunk c - 1
   }
+  BT_TS(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the rings are re-used / the workgroup is gone
 }
 
@@ -219,6 +235,12 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
   uint8_t* const smeta = zmeta + HU * 16 * RS;
   float* const red = reinterpret_cast<float*>(lds);                  // after the loop: [MH][8 classes][HU][MTW][64 lanes] x 4 floats
 
+#ifdef BT_LAB_TS
+  unsigned long long t_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  BT_TS(0);
+#else
+  unsigned long long* t_ = nullptr;
+#endif
   BtUnit un[BT_HUMAX];
 #pragma unroll
   for (int u = 0; u < BT_HUMAX; ++u) {
@@ -227,11 +249,12 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
     un[u] = bt_unit<PER>(a, U);
   }
 
+  BT_TS(1);
   if (wave == BT_CW) {
     // ================================ loader wave ================================
-    if (HU == 1) bt_loader<NBITS, 1, 8>(a, un, wring, zmeta, smeta, lane, nchunks, BPC);
-    else if (HU == 2) bt_loader<NBITS, 2, 5>(a, un, wring, zmeta, smeta, lane, nchunks, BPC);
-    else bt_loader<NBITS, 3, 4>(a, un, wring, zmeta, smeta, lane, nchunks, BPC);
+    if (HU == 1) bt_loader<NBITS, 1, 8>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
+    else if (HU == 2) bt_loader<NBITS, 2, 5>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
+    else bt_loader<NBITS, 3, 4>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
     __builtin_amdgcn_s_barrier();   // e1 (below)
     __builtin_amdgcn_s_barrier();   // e2
   } else {
@@ -299,6 +322,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
     // ---- main loop: one chunk per iteration; x blocks BT_R ahead in the wave's own queue ----
 #pragma unroll
     for (int c = 0; c < BT_R; ++c) issue_x(c);
+    BT_TS(2);
     for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -306,6 +330,9 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
         if (cc < nchunks) {   // (wave-uniform; the barrier count is the same for every wave: nchunks)
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BT_R - 1) * 2 * MTW) : "memory");   // x block cc has landed (this wave's own pieces)
           __builtin_amdgcn_s_barrier();                                                  // b_cc: the loader's chunk cc has landed
+#ifdef BT_LAB_TS
+          if (cc == 0) BT_TS(3); else if (cc == 1) BT_TS(4); else if (cc == nchunks - 1) BT_TS(5);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           if (cc * BPC + b < nblocks) {
             if (MH == 2 && h == 1) consume(cc, std::integral_constant<int, 1>{});
@@ -317,6 +344,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
         }
       }
     }
+    BT_TS(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // e1: every ring is dead (all waves past their last read, every DMA landed): LDS becomes the reduction buffer
     // ---- block classes meet in LDS: class = k-block index % 8 (one-half mode: the wave; two-half mode: block + 4 x chunk parity) ----
@@ -370,6 +398,10 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
     }
     *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(c.y) + static_cast<int64_t>(m) * c.N + n) = *reinterpret_cast<u32x2*>(o);
   }
+#ifdef BT_LAB_TS
+  BT_TS(7);
+  if (lane == 0 && a.ts) { const int w_ = static_cast<int>(blockIdx.x) * (BT_CW + 1) + wave; for (int q = 0; q < 8; ++q) a.ts[w_ * 8 + q] = t_[q]; }
+#endif
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -455,6 +487,9 @@ int batch_run(int nbits, int n_layers, const void* x, const void* const* Wq, con
   const int mtw = a.MH == 2 ? 2 : mt;                 // token tiles per compute wave (two halves of 32 tokens beyond 32 rows)
   a.HU = bt_choose_hu(nbits, mtw, a.MH, K, units);
   a.RS = static_cast<int>((2 * (K / 64) + 127) / 128) * 128;
+#ifdef BT_LAB_TS
+  a.ts = g_bt_lab_ts;
+#endif
   const size_t lds = bt_lds_bytes(nbits, mtw, a.HU, a.MH, K);
   const unsigned grid = static_cast<unsigned>((units + a.HU - 1) / a.HU);
   const bool bf = dtype == HQQ_BF16;

@@ -64,7 +64,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void gd_dma16(const void* src, uint8_t* lds_wave_base) {   // lane l: 16 bytes from src -> lds_wave_base + 16 l
   __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ void gd_dma12(const void* src, uint8_t* lds_wave_base) {   // lane l: 12 bytes -> lds_wave_base + 12 l
+__device__ __forceinline__ void gd_dma12(const void* src, uint8_t* lds_wave_base) {   // lane l: 12 bytes -> lds_wave_base + 16 l (the 12-byte form keeps the 16-byte lane stride: measured, tools/dma12_probe.hip)
   __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_wave_base, 12, 0, 0);
 }
 __device__ __forceinline__ void gd_dma4(const void* src, uint8_t* lds_wave_base) {    // lane l: 4 bytes -> lds_wave_base + 4 l
@@ -267,12 +267,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel
   };
   auto read_w = [&](int step) {
     const uint8_t* slot = wring + ((step % GD_DW) * GD_WAVES + wave) * 1024;
-    if constexpr (W3) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(slot + lane * 12);
-      return u32x4{q[0], q[1], q[2], 0u};
-    } else {
-      return *reinterpret_cast<const u32x4*>(slot + lane * 16);
-    }
+    return *reinterpret_cast<const u32x4*>(slot + lane * 16);   // (3-bit stream layout: 12 bytes landed at the same 16-byte lane stride; the fourth dword is not read)
   };
   auto rebuild = [&](const u32x4& raw, int step, u32x4 (&a0)[PER], u32x4 (&a1)[PER]) {
     if constexpr (W3) {   // the stream layout is in natural k order already
