@@ -39,7 +39,14 @@ constexpr int BT_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int BT_CW = 8;              // compute waves
 constexpr int BT_T = (BT_CW + 1) * 64;
 constexpr int BT_HUMAX = 3;           // units per workgroup
-constexpr int BT_R = 2;               // x blocks in flight per compute wave
+#ifndef BT_R_DEPTH
+#define BT_R_DEPTH 2
+#endif
+constexpr int BT_R = BT_R_DEPTH;      // x blocks in flight per compute wave
+#ifndef BT_WARM_DIV
+#define BT_WARM_DIV 4                 // every workgroup touches 1 / BT_WARM_DIV of x's lines at its start (0: no warm-up)
+#endif
+constexpr int BT_DUMMY = 1024;        // bytes of LDS that the warm-up's loads land in (never read)
 constexpr int BT_RED_CLASSES = 8;
 
 struct BtArgs {
@@ -65,6 +72,7 @@ struct BtArgs {
 typedef __attribute__((address_space(3))) void* bt_lds_t;
 typedef const __attribute__((address_space(1))) void* bt_glb_t;
 __device__ __forceinline__ void bt_dma16(const void* src, uint8_t* lds_wave_base) { __builtin_amdgcn_global_load_lds((bt_glb_t)src, (bt_lds_t)lds_wave_base, 16, 0, 0); }
+__device__ __forceinline__ void bt_dma16_nt(const void* src, uint8_t* lds_wave_base) { __builtin_amdgcn_global_load_lds((bt_glb_t)src, (bt_lds_t)lds_wave_base, 16, 0, 2); }   // streamed once
 __device__ __forceinline__ void bt_dma4(const void* src, uint8_t* lds_wave_base) { __builtin_amdgcn_global_load_lds((bt_glb_t)src, (bt_lds_t)lds_wave_base, 4, 0, 0); }
 // position of a 16-byte chunk inside a 128-byte row of an x block: chunk ^ bt_swz(row) (gemm_pipe.hip's map: conflict-free B-fragment reads)
 __device__ __forceinline__ int bt_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
@@ -149,33 +157,14 @@ __device__ __forceinline__ void bt_rebuild_bf16(const u32x4& w, uint16_t z, uint
   a1 = u32x4{o[4], o[5], o[6], o[7]};
 }
 
-// ---- the loader wave: group constants of the tile, then the packed chunks, D - 1 chunks ahead of the compute waves -------------------
+// ---- the loader wave: the packed chunks, D - 1 chunks ahead of the compute waves; nothing else in its queue ----------------------------
 // LDS weight slot of a chunk: [block b][unit u][16 / PER rows][64 bytes] — (b HU + u) UB bytes in; one DMA instruction = PER (block, unit) pairs.
 template <int NBITS, int HU, int D>
-__device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT_HUMAX], uint8_t* wring, uint8_t* zmeta, uint8_t* smeta, int lane, int nchunks, int BPC, unsigned long long* t_) {
+__device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT_HUMAX], uint8_t* wring, int lane, int nchunks, int BPC, unsigned long long* t_) {
   constexpr int PER = 8 / NBITS, UR = 16 / PER, UB = UR * 64, LPP = 64 / PER;   // rows per unit, bytes per (unit, block), lanes per pair
-  const int K = a.K, G = a.G, RS = a.RS, nblocks = K / 64;
+  const int K = a.K, nblocks = K / 64;
   const int chw = BPC * HU * UB;          // bytes per chunk slot
   const int nW = chw / 1024;              // DMA instructions per chunk (BPC HU / PER; an integer for BPC = 8 or 4)
-  // ---- group constants: rows (u, i) = (unit, A-tile row); half-slot hs = 128 bytes of one row: hs = row SPR + seg ----
-  {
-    const int SPR = RS / 128, nhs = HU * 16 * SPR, half = lane >> 5, l32 = lane & 31;
-    for (int hs0 = 0; hs0 < nhs; hs0 += 2) {
-      int hs = hs0 + half;
-      hs = hs < nhs ? hs : nhs - 1;
-      const int row = hs / SPR, seg = hs - row * SPR, u = row >> 4, i = row & 15;
-      // (HU <= 3: wave-uniform unit records picked per lane by selects)
-      const int prow0 = pick(u == 0, un[0].prow0, pick(u == 1, un[1].prow0, un[2].prow0));
-      const int Nl = pick(u == 0, un[0].N, pick(u == 1, un[1].N, un[2].N));
-      const half_t* zb = pick(u == 0, un[0].zero, pick(u == 1, un[1].zero, un[2].zero));
-      const half_t* sb = pick(u == 0, un[0].scale, pick(u == 1, un[1].scale, un[2].scale));
-      const int64_t n = prow0 + (i % UR) + static_cast<int64_t>(i / UR) * (Nl / PER);
-      int off = seg * 128 + l32 * 4;
-      off = off < 2 * G - 4 ? off : 2 * G - 4;            // past the row's constants: its last dword again (lands in the padding)
-      bt_dma4(reinterpret_cast<const uint8_t*>(zb + n * G) + off, zmeta + hs0 * 128);
-      bt_dma4(reinterpret_cast<const uint8_t*>(sb + n * G) + off, smeta + hs0 * 128);
-    }
-  }
   // ---- per-lane source of every DMA instruction of a chunk (block 0 of chunk 0) ----
   constexpr int NWMAX = HU * 8 / PER;        // nW at 8 blocks per chunk (half of it at 4)
   const uint8_t* wsrc[NWMAX];
@@ -190,31 +179,36 @@ __device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT
     wsrc[d] = base + static_cast<int64_t>(prow0 + row) * K + col * 16;
     wblk[d] = b;
   }
-  auto issue_w = [&](int c) {
+  auto issue_w = [&](int c) {   // c < nchunks
 #pragma unroll
     for (int d = 0; d < NWMAX; ++d) {
       if (d < nW) {   // (wave-uniform)
         int j = c * BPC + wblk[d];
-        j = j < nblocks ? j : nblocks - 1;       // past the row (K not a multiple of the chunk, chunks past the last): the last block again, never consumed
-        bt_dma16(wsrc[d] + static_cast<int64_t>(j) * 64, wring + (c % D) * chw + d * 1024);
+        j = j < nblocks ? j : nblocks - 1;       // K not a multiple of the chunk: the row's last block again, never consumed
+        bt_dma16_nt(wsrc[d] + static_cast<int64_t>(j) * 64, wring + (c % D) * chw + d * 1024);
       }
     }
   };
 #pragma unroll
-  for (int c = 0; c < D - 1; ++c) issue_w(c);
+  for (int c = 0; c < D - 1; ++c)
+    if (c < nchunks) issue_w(c);
   BT_TS(2);
   for (int c = 0; c < nchunks; ++c) {
-    // everything up to chunk c has landed: the instructions issued after it are those of chunks c + 1 .. c + D - 2
-    if (BPC == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (8 * HU / PER)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (4 * HU / PER > 0 ? 4 * HU / PER : 1)) : "memory");
+    // everything up to chunk c has landed: the instructions issued after it are those of chunks c + 1 .. c + D - 2 (near the end of the row
+    // fewer are behind it: wait for all of them)
+    if (c + D - 2 < nchunks) {
+      if (BPC == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (8 * HU / PER)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (4 * HU / PER > 0 ? 4 * HU / PER : 1)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();              // b_c: chunk c is in LDS for everyone; the compute waves have finished reading chunk c - 1
 #ifdef BT_LAB_TS
     if (c == 0) BT_TS(3); else if (c == 1) BT_TS(4); else if (c == nchunks - 1) BT_TS(5);
 #endif
-    issue_w(c + D - 1);                        // into the slot of chunk c - 1
+    if (c + D - 1 < nchunks) issue_w(c + D - 1);   // into the slot of chunk c - 1
   }
   BT_TS(6);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the rings are re-used / the workgroup is gone
 }
 
 template <int NBITS, int MTW, bool BF>
@@ -233,6 +227,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
   uint8_t* const wring = lds + BT_CW * BT_R * XS;                    // [D][chw]
   uint8_t* const zmeta = wring + D * chw;                            // [HU 16 rows][RS]
   uint8_t* const smeta = zmeta + HU * 16 * RS;
+  uint8_t* const dummy = smeta + HU * 16 * RS;                       // [BT_DUMMY] landing place of the warm-up loads
   float* const red = reinterpret_cast<float*>(lds);                  // after the loop: [MH][8 classes][HU][MTW][64 lanes] x 4 floats
 
 #ifdef BT_LAB_TS
@@ -252,9 +247,9 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
   BT_TS(1);
   if (wave == BT_CW) {
     // ================================ loader wave ================================
-    if (HU == 1) bt_loader<NBITS, 1, 8>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
-    else if (HU == 2) bt_loader<NBITS, 2, 5>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
-    else bt_loader<NBITS, 3, 4>(a, un, wring, zmeta, smeta, lane, nchunks, BPC, t_);
+    if (HU == 1) bt_loader<NBITS, 1, 8>(a, un, wring, lane, nchunks, BPC, t_);
+    else if (HU == 2) bt_loader<NBITS, 2, 5>(a, un, wring, lane, nchunks, BPC, t_);
+    else bt_loader<NBITS, 3, 4>(a, un, wring, lane, nchunks, BPC, t_);
     __builtin_amdgcn_s_barrier();   // e1 (below)
     __builtin_amdgcn_s_barrier();   // e2
   } else {
@@ -272,7 +267,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
       const int tok = m0 + row;
       xsrc[p] = a.x + static_cast<int64_t>(tok < M ? tok : 0) * K + ch * 8;   // token rows past M read row 0: their columns are never stored
     }
-    auto issue_x = [&](int c) {
+    auto issue_x = [&](int c) {   // c < nchunks
       int j = c * BPC + b;
       j = j < nblocks ? j : nblocks - 1;
 #pragma unroll
@@ -319,16 +314,63 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
         }
       }
     };
+    // ---- group constants of the tile: rows (u, i) = (unit, A-tile row), 128-byte half-slots hs = row SPR + seg, dealt over the compute
+    //      waves.  They sit in front of the wave's first x block in its queue, so every wave has its share in LDS before it arrives at
+    //      barrier 0 — after which every wave may read all of them.  16 bytes per lane where a row's constants are whole 16-byte pieces ----
+    {
+      const int G = a.G, SPR = RS / 128, nhs = HU * 16 * SPR;
+      const bool wide = (2 * G) % 16 == 0;
+      const int per_instr = wide ? 8 : 2;                        // half-slots one DMA instruction fills
+      const int n_instr = (nhs + per_instr - 1) / per_instr;     // per tensor
+      for (int q = wave; q < 2 * n_instr; q += BT_CW) {
+        const bool is_s = q >= n_instr;
+        const int hs0 = (is_s ? q - n_instr : q) * per_instr;
+        int hs = hs0 + (wide ? lane >> 3 : lane >> 5);
+        hs = hs < nhs ? hs : nhs - 1;
+        const int row = hs / SPR, seg = hs - row * SPR, u = row >> 4, i = row & 15;
+        const int prow0 = pick(u == 0, un[0].prow0, pick(u == 1, un[1].prow0, un[2].prow0));
+        const int Nl = pick(u == 0, un[0].N, pick(u == 1, un[1].N, un[2].N));
+        const half_t* zb = pick(u == 0, un[0].zero, pick(u == 1, un[1].zero, un[2].zero));
+        const half_t* sb = pick(u == 0, un[0].scale, pick(u == 1, un[1].scale, un[2].scale));
+        const int64_t n = prow0 + (i % UR) + static_cast<int64_t>(i / UR) * (Nl / PER);
+        const uint8_t* rowp = reinterpret_cast<const uint8_t*>((is_s ? sb : zb) + n * G);
+        uint8_t* dst = (is_s ? smeta : zmeta) + hs0 * 128;
+        if (wide) {
+          int off = seg * 128 + (lane & 7) * 16;
+          off = off < 2 * G - 16 ? off : 2 * G - 16;            // past the row's constants: its last piece again (lands in the padding)
+          bt_dma16(rowp + off, dst);
+        } else {
+          int off = seg * 128 + (lane & 31) * 4;
+          off = off < 2 * G - 4 ? off : 2 * G - 4;
+          bt_dma4(rowp + off, dst);
+        }
+      }
+    }
+    // ---- warm-up of x: every workgroup walks the same x at the same time, so a line's FIRST request in an XCD would be everybody's
+    //      (each chunk one fabric latency: measured 0.6 us per chunk whatever M).  Each workgroup touches a quarter of x's lines right
+    //      away (4 bytes per line into a dummy), the workgroups of an XCD together all of them: later chunks are L2 hits ----
+    if (BT_WARM_DIV > 0) {
+      const int xlines = M * (K / 64);                          // 128-byte lines of x
+      const int phase = (static_cast<int>(blockIdx.x) >> 3) % BT_WARM_DIV;
+      for (int t = wave * BT_WARM_DIV + phase; t * 64 < xlines; t += BT_CW * BT_WARM_DIV) {
+        int line = t * 64 + lane;
+        line = line < xlines ? line : xlines - 1;
+        bt_dma4(a.x + static_cast<int64_t>(line) * 64, dummy);
+      }
+    }
     // ---- main loop: one chunk per iteration; x blocks BT_R ahead in the wave's own queue ----
 #pragma unroll
-    for (int c = 0; c < BT_R; ++c) issue_x(c);
+    for (int c = 0; c < BT_R; ++c)
+      if (c < nchunks) issue_x(c);
     BT_TS(2);
     for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int cc = c + h;
         if (cc < nchunks) {   // (wave-uniform; the barrier count is the same for every wave: nchunks)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BT_R - 1) * 2 * MTW) : "memory");   // x block cc has landed (this wave's own pieces)
+          // x block cc has landed (this wave's own pieces; near the end of the row fewer blocks are behind it: wait for all)
+          if (cc + BT_R <= nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BT_R - 1) * 2 * MTW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();                                                  // b_cc: the loader's chunk cc has landed
 #ifdef BT_LAB_TS
           if (cc == 0) BT_TS(3); else if (cc == 1) BT_TS(4); else if (cc == nchunks - 1) BT_TS(5);
@@ -340,7 +382,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragment reads have left the LDS before the DMA below may overwrite the block
           __builtin_amdgcn_sched_barrier(0);
-          issue_x(cc + BT_R);
+          if (cc + BT_R < nchunks) issue_x(cc + BT_R);
         }
       }
     }
@@ -417,7 +459,7 @@ static int bt_num_cus() {
 static size_t bt_lds_bytes(int nbits, int mtw, int hu, int mh, int64_t K) {
   const int per = 8 / nbits, ub = (16 / per) * 64, bpc = BT_CW / mh, d = hu == 1 ? 8 : (hu == 2 ? 5 : 4);
   const size_t rs = static_cast<size_t>((2 * (K / 64) + 127) / 128) * 128;
-  const size_t rings = static_cast<size_t>(BT_CW) * BT_R * mtw * 2048 + static_cast<size_t>(d) * bpc * hu * ub + 2 * static_cast<size_t>(hu) * 16 * rs;
+  const size_t rings = static_cast<size_t>(BT_CW) * BT_R * mtw * 2048 + static_cast<size_t>(d) * bpc * hu * ub + 2 * static_cast<size_t>(hu) * 16 * rs + BT_DUMMY;
   const size_t red = static_cast<size_t>(mh) * BT_RED_CLASSES * hu * mtw * 1024;
   return rings > red ? rings : red;
 }
