@@ -44,7 +44,7 @@ constexpr int BT_HUMAX = 3;           // units per workgroup
 #endif
 constexpr int BT_R = BT_R_DEPTH;      // x blocks in flight per compute wave
 #ifndef BT_WARM_DIV
-#define BT_WARM_DIV 4                 // every workgroup touches 1 / BT_WARM_DIV of x's lines at its start (0: no warm-up)
+#define BT_WARM_DIV 0                 // lab: every workgroup touches 1 / BT_WARM_DIV of x's lines at its start (0: no warm-up — measured: no gain, the chunk time is not x latency)
 #endif
 constexpr int BT_DUMMY = 1024;        // bytes of LDS that the warm-up's loads land in (never read)
 constexpr int BT_RED_CLASSES = 8;
@@ -196,17 +196,29 @@ __device__ __forceinline__ void bt_loader(const BtArgs& a, const BtUnit (&un)[BT
   for (int c = 0; c < nchunks; ++c) {
     // everything up to chunk c has landed: the instructions issued after it are those of chunks c + 1 .. c + D - 2 (near the end of the row
     // fewer are behind it: wait for all of them)
+#ifdef BT_LAB_FINE
+    if (c == 2) { t_[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (c + D - 2 < nchunks) {
       if (BPC == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (8 * HU / PER)) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * (4 * HU / PER > 0 ? 4 * HU / PER : 1)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifdef BT_LAB_FINE
+    if (c == 2) { t_[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     __builtin_amdgcn_s_barrier();              // b_c: chunk c is in LDS for everyone; the compute waves have finished reading chunk c - 1
-#ifdef BT_LAB_TS
+#ifdef BT_LAB_FINE
+    if (c == 2) { t_[3] = __builtin_amdgcn_s_memrealtime(); }
+#elif defined(BT_LAB_TS)
     if (c == 0) BT_TS(3); else if (c == 1) BT_TS(4); else if (c == nchunks - 1) BT_TS(5);
 #endif
     if (c + D - 1 < nchunks) issue_w(c + D - 1);   // into the slot of chunk c - 1
+#ifdef BT_LAB_FINE
+    if (c == 2) { t_[5] = __builtin_amdgcn_s_memrealtime(); }
+    if (c == 3) { t_[6] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   }
   BT_TS(6);
 }
@@ -245,7 +257,8 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
   }
 
   BT_TS(1);
-  if (wave == BT_CW) {
+  // (the loader is the workgroup's FIRST wave: the last one starts ~0.9 us after the first — measured — and the first packed chunk is what everybody waits for)
+  if (wave == 0) {
     // ================================ loader wave ================================
     if (HU == 1) bt_loader<NBITS, 1, 8>(a, un, wring, lane, nchunks, BPC, t_);
     else if (HU == 2) bt_loader<NBITS, 2, 5>(a, un, wring, lane, nchunks, BPC, t_);
@@ -255,10 +268,11 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
   } else {
     // ================================ compute waves ================================
     const int r = lane & 15, c4 = lane >> 4;
-    const int b = wave % BPC, mh = wave / BPC, m0 = mh * 32;
+    const int cw = wave - 1;                              // compute wave index 0..7
+    const int b = cw % BPC, mh = cw / BPC, m0 = mh * 32;
     const int prow = r % UR, slab = r / UR;
     const uint32_t shl = static_cast<uint32_t>(NBITS * (PER - 1 - slab));   // the lane's slab field -> bit 0 of every byte
-    uint8_t* const xmine = xring + wave * BT_R * XS;
+    uint8_t* const xmine = xring + cw * BT_R * XS;
     // x pieces: piece p fills token rows 8 p .. 8 p + 7 of the block; lane -> (row, 16-byte position); the chunk a position holds is XOR-ed
     const half_t* xsrc[2 * MTW];
 #pragma unroll
@@ -284,10 +298,29 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
       if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf8_t, A), __builtin_bit_cast(bt_bf8_t, B), C, 0, 0, 0);
       else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, A), __builtin_bit_cast(h8_t, B), C, 0, 0, 0);
     };
-    auto consume = [&](int c, auto parity) {
+    // One chunk, in the order that keeps the chain behind the barrier short (measured with in-kernel stamps: reads -> rebuild -> MFMA ->
+    // DMA issue behind the barrier made a chunk 0.7 us whatever M): in FRONT of the barrier — this wave's x block has landed (its own queue),
+    // its B fragments go to registers, and the DMA of the block two chunks ahead is issued into the slot just read; BEHIND it only the packed
+    // bytes -> rebuild -> MFMA.  The group constants of a chunk are read one chunk early (they are all in LDS from barrier 0 on).
+    uint32_t zs_next[BT_HUMAX];   // (zero | scale << 16) of the NEXT chunk's group, per unit
+    auto read_meta = [&](int c) {
+      int j = c * BPC + b;
+      j = j < nblocks ? j : nblocks - 1;
+#pragma unroll
+      for (int u = 0; u < BT_HUMAX; ++u)
+        if (u < HU) {
+          const uint32_t zb = *reinterpret_cast<const uint16_t*>(zmeta + (u * 16 + r) * RS + j * 2);
+          const uint32_t sb = *reinterpret_cast<const uint16_t*>(smeta + (u * 16 + r) * RS + j * 2);
+          zs_next[u] = zb | (sb << 16);
+        }
+    };
+    auto chunk = [&](int cc, auto parity) {
       constexpr int pa = decltype(parity)::value;
-      const int j = c * BPC + b;
-      const uint8_t* xs = xmine + (c % BT_R) * XS;
+      // ---- in front of the barrier ----
+      // x block cc has landed (this wave's own pieces; near the end of the row fewer blocks are behind it: wait for all)
+      if (cc + BT_R <= nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BT_R - 1) * 2 * MTW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint8_t* xs = xmine + (cc % BT_R) * XS;
       u32x4 f0[MTW], f1[MTW];
 #pragma unroll
       for (int t = 0; t < MTW; ++t) {
@@ -295,23 +328,47 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
         f0[t] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c4) ^ bt_swz(row)) << 4));
         f1[t] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c4 + 1) ^ bt_swz(row)) << 4));
       }
-      const uint8_t* ws = wring + (c % D) * chw + b * HU * UB + prow * 64 + c4 * 16;
+      uint32_t zs[BT_HUMAX];
 #pragma unroll
-      for (int u = 0; u < BT_HUMAX; ++u) {
-        if (u < HU) {   // (wave-uniform)
-          const u32x4 raw = *reinterpret_cast<const u32x4*>(ws + u * UB);
-          const u32x4 w = u32x4{raw[0] >> shl, raw[1] >> shl, raw[2] >> shl, raw[3] >> shl};
-          const uint16_t zb = *reinterpret_cast<const uint16_t*>(zmeta + (u * 16 + r) * RS + j * 2);
-          const uint16_t sb = *reinterpret_cast<const uint16_t*>(smeta + (u * 16 + r) * RS + j * 2);
-          u32x4 a0, a1;
-          if constexpr (BF) bt_rebuild_bf16<NBITS>(w, zb, sb, a0, a1);
-          else bt_rebuild_f16<NBITS>(w, __builtin_bit_cast(half_t, zb), __builtin_bit_cast(half_t, sb), a0, a1);
+      for (int u = 0; u < BT_HUMAX; ++u) zs[u] = zs_next[u];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragment reads have left the LDS before the DMA below may overwrite the block
+      __builtin_amdgcn_sched_barrier(0);
+      if (cc + BT_R < nchunks) issue_x(cc + BT_R);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                          // b_cc: the loader's chunk cc has landed
+#ifdef BT_LAB_TS
+      if (cc == 0) BT_TS(3); else if (cc == 1) BT_TS(4); else if (cc == nchunks - 1) BT_TS(5);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- behind the barrier ----
+      if (cc == 0) {   // (the constants became everybody's at this barrier: chunk 0 reads its own here)
+        read_meta(0);
 #pragma unroll
-          for (int t = 0; t < MTW; ++t) {
-            acc[pa][u][t] = mfma(a0, f0[t], acc[pa][u][t]);
-            acc[pa][u][t] = mfma(a1, f1[t], acc[pa][u][t]);
+        for (int u = 0; u < BT_HUMAX; ++u) zs[u] = zs_next[u];
+      }
+      if (cc * BPC + b < nblocks) {
+        const uint8_t* ws = wring + (cc % D) * chw + b * HU * UB + prow * 64 + c4 * 16;
+        u32x4 raw[BT_HUMAX];
+#pragma unroll
+        for (int u = 0; u < BT_HUMAX; ++u)
+          if (u < HU) raw[u] = *reinterpret_cast<const u32x4*>(ws + u * UB);
+        if (cc + 1 < nchunks) read_meta(cc + 1);
+#pragma unroll
+        for (int u = 0; u < BT_HUMAX; ++u) {
+          if (u < HU) {   // (wave-uniform)
+            const u32x4 w = u32x4{raw[u][0] >> shl, raw[u][1] >> shl, raw[u][2] >> shl, raw[u][3] >> shl};
+            u32x4 a0, a1;
+            if constexpr (BF) bt_rebuild_bf16<NBITS>(w, static_cast<uint16_t>(zs[u]), static_cast<uint16_t>(zs[u] >> 16), a0, a1);
+            else bt_rebuild_f16<NBITS>(w, __builtin_bit_cast(half_t, static_cast<uint16_t>(zs[u])), __builtin_bit_cast(half_t, static_cast<uint16_t>(zs[u] >> 16)), a0, a1);
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+              acc[pa][u][t] = mfma(a0, f0[t], acc[pa][u][t]);
+              acc[pa][u][t] = mfma(a1, f1[t], acc[pa][u][t]);
+            }
           }
         }
+      } else if (cc + 1 < nchunks) {
+        read_meta(cc + 1);
       }
     };
     // ---- group constants of the tile: rows (u, i) = (unit, A-tile row), 128-byte half-slots hs = row SPR + seg, dealt over the compute
@@ -322,7 +379,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
       const bool wide = (2 * G) % 16 == 0;
       const int per_instr = wide ? 8 : 2;                        // half-slots one DMA instruction fills
       const int n_instr = (nhs + per_instr - 1) / per_instr;     // per tensor
-      for (int q = wave; q < 2 * n_instr; q += BT_CW) {
+      for (int q = cw; q < 2 * n_instr; q += BT_CW) {
         const bool is_s = q >= n_instr;
         const int hs0 = (is_s ? q - n_instr : q) * per_instr;
         int hs = hs0 + (wide ? lane >> 3 : lane >> 5);
@@ -346,13 +403,10 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
         }
       }
     }
-    // ---- warm-up of x: every workgroup walks the same x at the same time, so a line's FIRST request in an XCD would be everybody's
-    //      (each chunk one fabric latency: measured 0.6 us per chunk whatever M).  Each workgroup touches a quarter of x's lines right
-    //      away (4 bytes per line into a dummy), the workgroups of an XCD together all of them: later chunks are L2 hits ----
-    if (BT_WARM_DIV > 0) {
+    if (BT_WARM_DIV > 0) {   // lab (see BT_WARM_DIV)
       const int xlines = M * (K / 64);                          // 128-byte lines of x
-      const int phase = (static_cast<int>(blockIdx.x) >> 3) % BT_WARM_DIV;
-      for (int t = wave * BT_WARM_DIV + phase; t * 64 < xlines; t += BT_CW * BT_WARM_DIV) {
+      const int phase = (static_cast<int>(blockIdx.x) >> 3) % (BT_WARM_DIV > 0 ? BT_WARM_DIV : 1);
+      for (int t = cw * BT_WARM_DIV + phase; t * 64 < xlines; t += BT_CW * BT_WARM_DIV) {
         int line = t * 64 + lane;
         line = line < xlines ? line : xlines - 1;
         bt_dma4(a.x + static_cast<int64_t>(line) * 64, dummy);
@@ -363,27 +417,13 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
     for (int c = 0; c < BT_R; ++c)
       if (c < nchunks) issue_x(c);
     BT_TS(2);
-    for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cc = c + h;
-        if (cc < nchunks) {   // (wave-uniform; the barrier count is the same for every wave: nchunks)
-          // x block cc has landed (this wave's own pieces; near the end of the row fewer blocks are behind it: wait for all)
-          if (cc + BT_R <= nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((BT_R - 1) * 2 * MTW) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();                                                  // b_cc: the loader's chunk cc has landed
-#ifdef BT_LAB_TS
-          if (cc == 0) BT_TS(3); else if (cc == 1) BT_TS(4); else if (cc == nchunks - 1) BT_TS(5);
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-          if (cc * BPC + b < nblocks) {
-            if (MH == 2 && h == 1) consume(cc, std::integral_constant<int, 1>{});
-            else consume(cc, std::integral_constant<int, 0>{});
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragment reads have left the LDS before the DMA below may overwrite the block
-          __builtin_amdgcn_sched_barrier(0);
-          if (cc + BT_R < nchunks) issue_x(cc + BT_R);
-        }
+    for (int u = 0; u < BT_HUMAX; ++u) zs_next[u] = 0u;
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk(c, std::integral_constant<int, 0>{});
+      if (c + 1 < nchunks) {   // (wave-uniform; the barrier count is the same for every wave: nchunks)
+        if (MH == 2) chunk(c + 1, std::integral_constant<int, 1>{});
+        else chunk(c + 1, std::integral_constant<int, 0>{});
       }
     }
     BT_TS(6);
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(BT_T, 1) void batch_f16_kernel(const BtArgs a) {
 #pragma unroll
     for (int pa = 0; pa < 2; ++pa) {
       if (pa == 0 || MH == 2) {
-        const int cls = MH == 1 ? wave : b + 4 * pa;
+        const int cls = MH == 1 ? cw : b + 4 * pa;
 #pragma unroll
         for (int u = 0; u < BT_HUMAX; ++u)
           if (u < HU)

@@ -50,15 +50,19 @@ int main(int argc, char** argv) {
   hipMemcpy(h.data(), g_bt_lab_ts, nw * 64, hipMemcpyDeviceToHost);
   unsigned long long t0 = ~0ull;
   for (int w = 0; w < nw; ++w) if (h[w * 8]) t0 = h[w * 8] < t0 ? h[w * 8] : t0;
+#ifdef BT_LAB_FINE
+  const char* names[8] = {"wave start", "iteration 2 begins", "  its wait done", "  its barrier passed", "  reads+rebuild+MFMA issued, lgkm drained", "  DMA issued (end)", "iteration 3 ends", "wave end"};
+#else
   const char* names[8] = {"wave start", "units looked up", "prologue issued", "barrier 0 passed", "barrier 1 passed", "last barrier passed", "loop end", "wave end"};
+#endif
   for (int kind = 0; kind < 2; ++kind) {
     printf("%s %s M=%d: time since the first wave start, units of 10 ns: min / median / max over the waves\n", shape, kind ? "LOADER waves" : "compute waves", M);
     for (int i = 0; i < 8; ++i) {
       std::vector<unsigned long long> v;
-      for (int w = 0; w < nw; ++w) if (((w % 9) == 8) == (kind == 1) && h[w * 8] && h[w * 8 + i]) v.push_back(h[w * 8 + i] - t0);
+      for (int w = 0; w < nw; ++w) if (((w % 9) == 0) == (kind == 1) && h[w * 8] && h[w * 8 + i]) v.push_back(h[w * 8 + i] - t0);
       if (v.empty()) continue;
       std::sort(v.begin(), v.end());
-      printf("  %-22s n=%5zu  %7llu %7llu %7llu\n", names[i], v.size(), v.front(), v[v.size() / 2], v.back());
+      printf("  %-42s n=%5zu  %7llu %7llu %7llu\n", names[i], v.size(), v.front(), v[v.size() / 2], v.back());
     }
   }
   return 0;
