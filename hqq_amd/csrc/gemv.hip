@@ -564,12 +564,6 @@ int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, co
                hipStream_t st);
 int gemv_w3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
                  void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, hipStream_t st);
-namespace bt {
-bool batch_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers, int dtype);
-bool batch_prefers(int nbits, int n_layers, const int64_t* N);
-int batch_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
-              void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, hipStream_t st);
-}  // namespace bt
 size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts);
 int gemv3_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts,
@@ -693,11 +687,6 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-    // 5..64 rows: launches that fill at least half the chip with whole-K tiles take the kernel without a K split (batch.hip: no partial
-    // tiles, no finish); the others keep the split-K skinny GEMM.  Shapes only — and a row's bits are the same in both of batch.hip's modes
-    if (skinny_ok && !(opts & HQQ_OPT_BATCH_OLD) && bt::batch_covers(nbits, M, K, group_size, N, n_layers, dtype) &&
-        ((opts & HQQ_OPT_BATCH_NEW) || bt::batch_prefers(nbits, n_layers, N)))
-      return bt::batch_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, as_stream(stream));
     if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }

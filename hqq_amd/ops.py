@@ -23,7 +23,6 @@ GEMV_EXACT, GEMV_FACTORED = 0, 1
 GEMV_MAX_GROUP = 4
 # per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
 OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC, OPT_GEMM_NARROW, OPT_GEMM_WIDE, OPT_GEMM_NOHYBRID, OPT_SKINNY_WIDE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
-OPT_BATCH_NEW, OPT_BATCH_OLD = 2048, 4096   # 5..64 rows: force / forbid the no-K-split kernel (csrc/batch.hip)
 OPT_W3S = 1024   # nbits = 3: W_q is the 3-bit stream layout of w3s_pack(), not the reference container
 
 

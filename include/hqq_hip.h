@@ -114,9 +114,7 @@ int hqq_hip_dequantize(int nbits, const void* Wq, const void* scale, const void*
 #define HQQ_OPT_GEMM_NOHYBRID 256u  /* pipelined fused GEMM: never split only the last round of tiles (tuning) */
 #define HQQ_OPT_SKINNY_WIDE 512u  /* 5..64 rows: force the 64-packed-row tile for launches the 32-row tile would serve (tests / tuning) */
 #define HQQ_OPT_W3S        1024u  /* nbits = 3: Wq is the 3-bit STREAM layout written by hqq_hip_w3s_pack (below), not the reference container */
-#define HQQ_OPT_BATCH_NEW  2048u  /* 5..64 rows: force the no-K-split kernel (csrc/batch.hip) wherever it covers the call (default: launches of >= half a chip of units) — tests / tuning */
-#define HQQ_OPT_BATCH_OLD  4096u  /* 5..64 rows: never the no-K-split kernel (the split-K skinny GEMM, csrc/skinny.hip) — tests / tuning */
-#define HQQ_OPT_ALL (8191u | (255u << 24))
+#define HQQ_OPT_ALL (2047u | (255u << 24))
 /* Which groups of a layer can NOT take the three-op exact rebuild: (zero, scale) pairs for which zero * 2^-J is inexact in fp16,
  * |zero| > 2^15 or scale * 2^J overflows (J = 9 - bit offset of the row's slab).  Writes the count to *fail_count (device memory,
  * uint32; the call clears it first).  Run once per layer when it is prepared; pass HQQ_OPT_META_SCALABLE only if it came out 0.

@@ -1,10 +1,10 @@
 // batch_lab.hip — stand-alone timing / timestamp harness for the no-K-split batched-decode kernel (development aid; no Python, no torch).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DBT_LAB_TS] tools/batch_lab.hip hqq_amd/csrc/common.hip -o tools/batch_lab[_ts].bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I hqq_amd/csrc [-DBT_LAB_TS] tools/lab_batch/batch_lab.hip hqq_amd/csrc/common.hip -o tools/lab_batch/batch_lab[_ts].bin
 //   batch_lab.bin <shape: o|qkv|gateup|down> <M>
 #ifdef BT_LAB_TS
 unsigned long long* g_bt_lab_ts = nullptr;
 #endif
-#include "../hqq_amd/csrc/batch.hip"
+#include "batch.hip"
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
