@@ -667,3 +667,40 @@ def quantize_tensorwise(W: Tensor, nbits=4, round_zero: bool = False):
                                               _p(W_q), _p(meta), meta.data_ptr() + 4, _p(ws), ws.numel(), _stream())
     _C.check(rc, "hqq_hip_quantize_tensor")
     return W_q, meta[0], meta[1]
+
+
+# ---- the steps either side of the GEMVs in a decode step (csrc/block.hip; include/hqq_hip.h) --------------------------------------------
+def add_rmsnorm(h: Tensor, delta, weight: Tensor, eps: float, out: Tensor | None = None) -> Tensor:
+    """h += delta (in place, if delta is given), then LlamaRMSNorm(h) with `weight` — HF's arithmetic, one kernel.  h: [..., H] fp16, dense."""
+    _dev(h, delta, weight)
+    H = h.shape[-1]
+    if out is None:
+        out = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        rc = _C.lib().hqq_hip_add_rmsnorm(_p(h), _p(delta), _p(weight), float(eps), _p(out), h.numel() // H, H, _dt(h.dtype), _stream())
+    _C.check(rc, "hqq_hip_add_rmsnorm")
+    return out
+
+
+def rope_cache(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: Tensor, k_cache: Tensor, v_cache: Tensor, q_out: Tensor) -> Tensor:
+    """one token: q_out = rotary(q); rotary(k) and v go into the static caches [n_kv_heads, cache_len, head_dim] at position pos[0] (device int64)"""
+    _dev(q, k, v, cos, sin, pos, k_cache, v_cache, q_out)
+    hd = cos.shape[-1]
+    if pos.dtype != torch.int64 or k_cache.shape[-1] != hd or not k_cache.is_contiguous() or not v_cache.is_contiguous():
+        raise ValueError("hqq_amd: rope_cache takes an int64 position tensor and dense [n_kv_heads, cache_len, head_dim] caches")
+    with torch.cuda.device(q.device):
+        rc = _C.lib().hqq_hip_rope_cache(_p(q), _p(k), _p(v), _p(cos), _p(sin), _p(pos), _p(q_out), _p(k_cache), _p(v_cache), q.numel() // hd, k.numel() // hd, hd,
+                                         k_cache.shape[-2], _dt(q.dtype), _stream())
+    _C.check(rc, "hqq_hip_rope_cache")
+    return q_out
+
+
+def silu_mul(gate: Tensor, up: Tensor, out: Tensor | None = None) -> Tensor:
+    """LlamaMLP's act_fn(gate) * up in one kernel (fp16)"""
+    _dev(gate, up)
+    if out is None:
+        out = torch.empty_like(gate)
+    with torch.cuda.device(gate.device):
+        rc = _C.lib().hqq_hip_silu_mul(_p(gate), _p(up), _p(out), gate.numel(), _dt(gate.dtype), _stream())
+    _C.check(rc, "hqq_hip_silu_mul")
+    return out

@@ -11,9 +11,17 @@ from torch import Tensor
 
 
 class GraphedGreedyDecoder:
-    def __init__(self, model, max_cache_len: int = 512):
+    """fused=True (default): a Llama-shaped model whose decoder linears are HQQLinearHIP layers decodes through hqq_amd.utils.llama_fused —
+    RMSNorm (+ the residual adds), rotary + KV-cache write and SiLU * up as one HIP kernel each around the grouped GEMVs, HF's own attention
+    function on HF's cache: the same tokens in a third of the launches.  Any other model, or fused=False: the model's own forward."""
+
+    def __init__(self, model, max_cache_len: int = 512, fused: bool = True):
         from transformers import StaticCache
+        from . import llama_fused
         self.model = model.eval()
+        self.fused = bool(fused) and llama_fused.supports(model)
+        self._fused_mod = llama_fused
+        self.step = None
         self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
         self.max_cache_len = max_cache_len
         self._StaticCache = StaticCache
@@ -21,6 +29,9 @@ class GraphedGreedyDecoder:
 
     @torch.no_grad()
     def _decode_once(self):
+        if self.step is not None:
+            self.next_tok.copy_(self.step(self.tok, self.pos).argmax(-1, keepdim=True))
+            return
         out = self.model(self.tok, past_key_values=self.cache, cache_position=self.pos, use_cache=True)
         self.next_tok.copy_(out.logits[:, -1].argmax(-1, keepdim=True))
 
@@ -36,6 +47,7 @@ class GraphedGreedyDecoder:
         self.tok = out.logits[:, -1].argmax(-1, keepdim=True)
         self.next_tok = torch.empty_like(self.tok)
         self.pos = torch.tensor([T], device=self.device)
+        self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len) if self.fused else None
         toks = [self.tok.clone()]
         self.graph = None
         for i in range(max_new_tokens - 1):
@@ -59,6 +71,8 @@ class GraphedGreedyDecoder:
             self.tok.copy_(self.next_tok)
             self.pos += 1
             toks.append(self.tok.clone())
+        if self.step is not None:
+            self.step.account_tokens(max_new_tokens - 1)
         return torch.cat([ids] + toks, dim=1)
 
     @torch.no_grad()

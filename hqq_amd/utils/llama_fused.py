@@ -1,0 +1,134 @@
+"""One decode step of a Llama-type HF model whose decoder linears are HQQLinearHIP layers, with the steps either side of the fused
+GEMVs fused too (the loop the reference's headline tok/s is measured on: hqq/utils/generation_hf.py:117-540, Readme.md:153).
+
+HF's decoder block around the seven linears is ~25 eager kernels per block at batch 1 (RMSNorm 5-6, rotary 8, cache update 2, SiLU * up 2,
+residual adds 2, ...): 79 % of a token once the linears are fused.  Here a block is
+    add_rmsnorm -> q|k|v (one grouped GEMV) -> rope_cache -> attention (HF's own attention function on the static cache) -> o ->
+    add_rmsnorm (the residual add of o rides in it) -> gate|up (one grouped GEMV) -> silu_mul -> down (its residual add rides in the next block's add_rmsnorm)
+= 8 launches + the attention's.  The three glue kernels (csrc/block.hip) restate the HF modules rounding for rounding and the attention is
+HF's function on HF's cache tensors, so the step emits the same tokens as `model(...)` does on the same kernels — and as the same model
+under HQQBackend.PYTORCH_FORWARD does on the reference's arithmetic (tests/test_model_gpu.py).
+
+Only what the step needs is taken from the model: module weights and the HF StaticCache's tensors are used in place (nothing is copied).
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import ops
+from ..backends.hip import HQQLinearHIP, _GroupedMember
+
+
+def _hip(layer):
+    return layer.layer if isinstance(layer, _GroupedMember) else layer
+
+
+def supports(model) -> bool:
+    """a LlamaForCausalLM-shaped model (model.model.layers[*].self_attn.{q,k,v,o}_proj, .mlp.{gate,up,down}_proj, RMSNorm without bias),
+    fp16, every decoder linear an HQQLinearHIP without bias whose group can share one launch"""
+    try:
+        inner = model.model
+        layers = inner.layers
+        if not hasattr(inner, "rotary_emb") or not hasattr(inner, "embed_tokens") or not hasattr(model, "lm_head"):
+            return False
+        for blk in layers:
+            at, mlp = blk.self_attn, blk.mlp
+            lin = [_hip(getattr(at, n)) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + [_hip(getattr(mlp, n)) for n in ("gate_proj", "up_proj", "down_proj")]
+            if not all(isinstance(L, HQQLinearHIP) and L.bias is None and L.compute_dtype == torch.float16 and L.W_q.is_cuda for L in lin):
+                return False
+            if len({(L.nbits, L.group_size, L.w3s) for L in lin[:3]}) != 1 or len({(L.nbits, L.group_size, L.w3s) for L in lin[4:6]}) != 1:
+                return False
+            if not ops.decode_covers(torch.float16, 1, lin[0].out_features, lin[0].in_features, lin[0].group_size, lin[0].nbits) and not lin[0].w3s:
+                return False
+            if type(getattr(mlp, "act_fn", None)).__name__ not in ("SiLUActivation", "SiLU"):
+                return False
+            for nrm in (blk.input_layernorm, blk.post_attention_layernorm):
+                if nrm.weight.dtype != torch.float16 or nrm.weight.shape[0] % 8:
+                    return False
+        return inner.norm.weight.dtype == torch.float16
+    except AttributeError:
+        return False
+
+
+class FusedLlamaStep:
+    """decode step t -> logits of token t + 1, on the model's own weights and an HF StaticCache that a prefill has filled"""
+
+    def __init__(self, model, cache, max_cache_len: int):
+        from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+        from transformers.models.llama.modeling_llama import eager_attention_forward
+        self.model = model
+        inner = model.model
+        self.inner = inner
+        cfg = model.config
+        self.device = inner.embed_tokens.weight.device
+        self.n_heads = cfg.num_attention_heads
+        self.n_kv = getattr(cfg, "num_key_value_heads", None) or cfg.num_attention_heads
+        self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        self.H = cfg.hidden_size
+        self.L = max_cache_len
+        self.attn_fn = ALL_ATTENTION_FUNCTIONS.get_interface(cfg._attn_implementation, eager_attention_forward)
+        self.blocks = []
+        dev = self.device
+        for li, blk in enumerate(inner.layers):
+            at, mlp = blk.self_attn, blk.mlp
+            q, k, v, o = (_hip(getattr(at, n)) for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+            g, u, d = (_hip(getattr(mlp, n)) for n in ("gate_proj", "up_proj", "down_proj"))
+            lay = cache.layers[li]
+            if not getattr(lay, "is_initialized", False) or lay.keys.shape[0] != 1 or lay.keys.shape[2] != max_cache_len or not lay.keys.is_contiguous():
+                raise ValueError("hqq_amd: the fused decode step needs an HF StaticCache that a batch-1 prefill has initialised")
+            self.blocks.append({
+                "attn": at, "n1": blk.input_layernorm, "n2": blk.post_attention_layernorm,
+                "qkv": [(L.W_q, L.scale, L.zero, None, L.out_features) for L in (q, k, v)], "qkv_opts": self._gopts((q, k, v)), "qkv_nbits": q.nbits, "qkv_gs": q.group_size, "gu_gs": g.group_size,
+                "o": o, "gu": [(L.W_q, L.scale, L.zero, None, L.out_features) for L in (g, u)], "gu_opts": self._gopts((g, u)), "gu_nbits": g.nbits, "d": d,
+                "kc": lay.keys[0], "vc": lay.values[0], "len": lay.cumulative_length,
+                # outputs of the launches (static addresses: the step is captured in a hipGraph)
+                "q": torch.empty(1, q.out_features, dtype=torch.float16, device=dev), "k": torch.empty(1, k.out_features, dtype=torch.float16, device=dev),
+                "v": torch.empty(1, v.out_features, dtype=torch.float16, device=dev), "qr": torch.empty(1, self.n_heads, 1, self.hd, dtype=torch.float16, device=dev),
+                "g": torch.empty(1, g.out_features, dtype=torch.float16, device=dev), "u": torch.empty(1, u.out_features, dtype=torch.float16, device=dev),
+                "a": torch.empty(1, g.out_features, dtype=torch.float16, device=dev),
+            })
+        self.h = torch.empty(1, self.H, dtype=torch.float16, device=dev)       # the residual stream
+        self.xn = torch.empty(1, self.H, dtype=torch.float16, device=dev)      # its normalised copy, input of the next linears
+        self.delta = torch.empty(1, self.H, dtype=torch.float16, device=dev)   # output of o / down, added by the next add_rmsnorm
+        self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.bool, device=dev)
+        self.ar = torch.arange(max_cache_len, device=dev)
+
+    @staticmethod
+    def _gopts(Ls) -> int:
+        lay = ops.OPT_W3S if Ls[0].w3s else 0
+        return ops.layer_opts((ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0) | lay)
+
+    @torch.no_grad()
+    def __call__(self, tok: Tensor, pos: Tensor) -> Tensor:
+        """tok [1, 1] int64, pos [1] int64 (its position; both on the device) -> logits [1, vocab] of the next token"""
+        inner = self.inner
+        h = self.h
+        h.copy_(inner.embed_tokens(tok).view(1, self.H))
+        cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))       # [1, 1, hd] each, the model's own rotary module
+        cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
+        torch.le(self.ar, pos, out=self.mask.view(-1))                          # the causal mask of one query at `pos` over the static cache
+        delta = None
+        for b in self.blocks:
+            at = b["attn"]
+            ops.add_rmsnorm(h, delta, b["n1"].weight, b["n1"].variance_epsilon, out=self.xn)
+            K = self.H
+            ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
+            ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
+            att, _ = self.attn_fn(at, b["qr"], b["kc"].unsqueeze(0), b["vc"].unsqueeze(0), self.mask, dropout=0.0, scaling=at.scaling)
+            o = b["o"]
+            ops.gemv(att.reshape(1, -1), o.W_q, o.scale, o.zero, None, o.out_features, o.in_features, o.group_size, o.nbits, out=self.delta,
+                     opts=ops.layer_opts(o.opts))
+            ops.add_rmsnorm(h, self.delta, b["n2"].weight, b["n2"].variance_epsilon, out=self.xn)
+            ops.gemv_grouped(self.xn, b["gu"], K, b["gu_gs"], b["gu_nbits"], outs=[b["g"], b["u"]], opts=b["gu_opts"])
+            ops.silu_mul(b["g"], b["u"], out=b["a"])
+            d = b["d"]
+            ops.gemv(b["a"], d.W_q, d.scale, d.zero, None, d.out_features, d.in_features, d.group_size, d.nbits, out=self.delta, opts=ops.layer_opts(d.opts))
+            delta = self.delta
+        ops.add_rmsnorm(h, delta, inner.norm.weight, inner.norm.variance_epsilon, out=self.xn)
+        return self.model.lm_head(self.xn)
+
+    def account_tokens(self, n: int) -> None:
+        """StaticLayer.update's bookkeeping for the n tokens the fused steps appended (kept out of the captured step: one add per layer)"""
+        for b in self.blocks:
+            b["len"].add_(n)

@@ -235,6 +235,21 @@ int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int nbits, int6
 int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t plan_bytes, void* stream);
 size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
 
+/* ---------------------------------------------------------------------------------------------
+ * The steps either side of the GEMVs in a decode step (ABI 5; csrc/block.hip).  The reference's headline is the
+ * tok/s of its generate loop (hqq/utils/generation_hf.py:117-540, Readme.md:153), whose decoder block around HQQLinear.forward is HF's
+ * eager code: ~25 small kernels per block.  These three restate the HF modules' arithmetic rounding for rounding (transformers
+ * models/llama/modeling_llama.py: LlamaRMSNorm.forward, apply_rotary_pos_emb, LlamaMLP.forward; cache_utils.StaticLayer.update), fp16:
+ *   hqq_hip_add_rmsnorm  h[rows, H] += delta (if delta != NULL: the residual add, fp16), then xn = weight * fp16(float(h) * rsqrt(mean(h^2) + eps))
+ *   hqq_hip_rope_cache   q_out[n_heads, hd] = (q * cos) + (rotate_half(q) * sin); the same for k, written with v into the caches
+ *                        [n_kv_heads, cache_len, hd] at position *pos_dev (device memory: the call is graph-replay safe)
+ *   hqq_hip_silu_mul     out[n] = fp16(silu(gate)) * up
+ * ------------------------------------------------------------------------------------------- */
+int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float eps, void* xn_out, int64_t rows, int64_t H, int dtype, void* stream);
+int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* q_out, void* k_cache,
+                       void* v_cache, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, int dtype, void* stream);
+int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
+
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */
 size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);

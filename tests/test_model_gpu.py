@@ -122,3 +122,80 @@ def test_quantize_model_matches_the_reference_fixture(nbits):
         assert sha(m.W_q.data.cpu().numpy()) == g[f"Wq__{n}"].tobytes(), f"{n}: packed W_q differs from the reference"
         assert sha(m.meta["zero"].float().cpu().numpy()) == g[f"zero__{n}"].tobytes(), f"{n}: zero differs from the reference"
         assert sha(m.meta["scale"].float().cpu().numpy()) == g[f"scale__{n}"].tobytes(), f"{n}: scale differs from the reference"
+
+
+def test_block_glue_kernels_restate_the_hf_modules():
+    """csrc/block.hip against the HF modules it replaces in the fused decode step: rotary + cache write and SiLU * up bit for bit (elementwise,
+    the same roundings); RMSNorm within one fp16 ulp on a handful of elements (the fp32 sum of squares is taken in another order)"""
+    import torch.nn.functional as F
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
+    from hqq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H, nh, nkv, hd, L = 4096, 32, 8, 128, 64
+    # RMSNorm (+ residual add)
+    h = torch.randn(1, H, device="cuda", generator=g).half()
+    d = (torch.randn(1, H, device="cuda", generator=g) * 0.3).half()
+    norm = LlamaRMSNorm(H, eps=1e-5).cuda().half()
+    norm.weight.data = (1 + 0.1 * torch.randn(H, device="cuda", generator=g)).half()
+    want_h = h + d
+    want = norm(want_h)
+    h2 = h.clone()
+    got = ops.add_rmsnorm(h2, d, norm.weight, norm.variance_epsilon)
+    assert torch.equal(h2, want_h)
+    diff = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+    assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= 8, (int(diff.max()), int((diff > 0).sum()))
+    assert torch.equal(ops.add_rmsnorm(h.clone(), None, norm.weight, norm.variance_epsilon)[0, :4].isfinite(), torch.ones(4, dtype=torch.bool, device="cuda"))
+    # rotary + cache write
+    cfg = LlamaConfig(hidden_size=H, num_attention_heads=nh, num_key_value_heads=nkv, max_position_embeddings=2048)
+    rot = LlamaRotaryEmbedding(cfg).cuda()
+    pos = torch.tensor([37], device="cuda")
+    q = torch.randn(1, nh * hd, device="cuda", generator=g).half()
+    k = torch.randn(1, nkv * hd, device="cuda", generator=g).half()
+    v = torch.randn(1, nkv * hd, device="cuda", generator=g).half()
+    cos, sin = rot(q.view(1, 1, -1), pos.view(1, 1))
+    qe, ke = apply_rotary_pos_emb(q.view(1, 1, nh, hd).transpose(1, 2), k.view(1, 1, nkv, hd).transpose(1, 2), cos, sin)
+    kc = torch.zeros(nkv, L, hd, dtype=torch.float16, device="cuda")
+    vc = torch.zeros(nkv, L, hd, dtype=torch.float16, device="cuda")
+    qr = torch.empty(1, nh, 1, hd, dtype=torch.float16, device="cuda")
+    ops.rope_cache(q, k, v, cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous(), pos, kc, vc, qr)
+    assert torch.equal(qr, qe) and torch.equal(kc[:, 37], ke[0, :, 0]) and torch.equal(vc[:, 37], v.view(nkv, hd))
+    assert torch.count_nonzero(kc[:, :37]) == 0 and torch.count_nonzero(kc[:, 38:]) == 0
+    # SiLU(gate) * up
+    gt = (torch.randn(1, 11008, device="cuda", generator=g) * 2).half()
+    up = torch.randn(1, 11008, device="cuda", generator=g).half()
+    assert torch.equal(ops.silu_mul(gt, up), F.silu(gt) * up)
+
+
+@pytest.mark.parametrize("nbits", [4, 3])
+def test_fused_decoder_emits_the_tokens_of_the_pytorch_backend(nbits):
+    """SURVEY.md §8 f3, not against itself: the graph-replayed fused decode loop (grouped GEMVs + csrc/block.hip + HF's attention function) against
+    the SAME quantised model decoding with HF's generate under HQQBackend.PYTORCH_FORWARD (dequantise + dense matmul: the reference's
+    arithmetic, hqq/core/quantize.py:894-898) — 32 greedy tokens, identical"""
+    import copy
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear
+    from hqq_amd.utils import llama_fused
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    model = _tiny_llama()
+    quantize_model(model, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    ref_model = copy.deepcopy(model)
+    ids = torch.randint(0, 512, (1, 6), generator=torch.Generator().manual_seed(3)).cuda()
+    HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+    try:
+        with torch.no_grad():
+            want = ref_model.generate(ids, max_new_tokens=32, do_sample=False)
+    finally:
+        HQQLinear.set_backend(HQQBackend.HIP)
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    assert llama_fused.supports(model)
+    dec = GraphedGreedyDecoder(model, max_cache_len=64)
+    assert dec.fused
+    got = dec.generate(ids, 32, use_graph=True)
+    assert dec.graph is not None and dec.step is not None
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+    plain = GraphedGreedyDecoder(model, max_cache_len=64, fused=False).generate(ids, 32, use_graph=True)   # the model's own forward: same tokens
+    assert torch.equal(plain, want)
