@@ -845,8 +845,10 @@ def main():
                                      "linear_stack_ms": round(lin_ms, 4), "linear_stack_share": round(lin_ms / r["ms_per_token"], 3), "build_s": round(t_build, 1),
                                      "model": "random-init Llama-2-7B-shaped LlamaForCausalLM (32 blocks, hidden 4096, intermediate 11008, vocab 32000, fp16), every decoder linear int4 gs=64 "
                                               f"via hqq_amd.utils.model.quantize_model (HIP solver), prepare_for_inference(backend='hip'), {ngrp} grouped q|k|v / gate|up launches",
-                                     "loop": "hqq_amd.utils.generation.GraphedGreedyDecoder: static KV cache, one captured hipGraph per token (attention, norms, rotary, lm_head are torch's "
-                                             "kernels inside the graph), argmax fed back on the device"}
+                                     "loop": "hqq_amd.utils.generation.GraphedGreedyDecoder, fused step (hqq_amd.utils.llama_fused): per decoder block add_rmsnorm -> q|k|v (grouped GEMV) -> "
+                                             "rope_cache -> HF's attention function on the static cache -> o -> add_rmsnorm (residual add inside) -> gate|up (grouped GEMV) -> silu_mul -> down; "
+                                             "csrc/block.hip restates the HF modules rounding for rounding; one captured hipGraph per token, argmax fed back on the device",
+                                     "fused_step": bool(dec.fused)}
                 del model, dec
                 torch.cuda.empty_cache()
             except Exception as e:
