@@ -11,8 +11,8 @@ Headline (N = 1; BASELINE.json configs[1], the configuration the metric is quote
   every step is HBM traffic).  Weights are synthetic N(0, 0.02^2) fp16 tensors quantised on the GPU by the
   HIP half-quadratic solver before timing.  Arithmetic: exact weights (round16(round16(q - z) * s), the
   reference's), in the three-op form wherever hqq_hip_meta_check allows it.
-  `legs` adds the other shapes the metric names (bs=32; one 4096x4096 layer at bs=1 / bs=32) and the persistent
-  engine (csrc/engine.hip) on the same stack; `cpu_baseline` times the reference's per-call arithmetic
+  `legs` adds the other shapes the metric names (bs=32; one 4096x4096 layer at bs=1 / bs=32), the int3 / int2 stacks, bs=128 and the
+  prefill block; `quantize` times the other hot path; `end_to_end` the fused decode loop; `cpu_baseline` times the reference's per-call arithmetic
   (unpack -> (W_r - zero) * scale -> matmul, hqq/core/bitpack.py:31-38, quantize.py:183-199, :880-882) restated
   in torch eager on the host cores of this box.
   `--workload prefill` runs configs[2]: M tokens (default 8192 = 4 x 2048) through one block's seven linears.
@@ -86,9 +86,7 @@ def parse():
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, 70B strong scaling: skip timing the unsharded stack on rank 0 alone")
     ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
-    ap.add_argument("--engine", action="store_true", help="headline through the persistent decode engine (one launch per token) instead of 128 launches")
-    ap.add_argument("--chain", action="store_true", help="headline through chained launches (csrc/gemv_chain.hip): the same launches on two streams, each waiting in the kernel for its predecessor's outputs")
-    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (bs=32, single layer, engine)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (bs=32, single layer, int3 / int2, prefill, quantise, end to end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--random-codes", action="store_true", help="skip the solver: random packed codes + meta (faster setup)")
     ap.add_argument("--gemv-mode", default="exact", choices=["exact", "exact4", "factored"],
@@ -464,28 +462,6 @@ def main():
                 if world > 1 and bs_x is None:
                     exchange(grp)
 
-    # ---- the persistent engine on the same stack (one launch per token) ----
-    def make_plan():
-        stages = []
-        for blk in blocks:
-            for grp in EXCHANGE_GROUPS:
-                Ls = [blk[name] for name in grp]
-                stages.append((xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N, out_local[grp][j]) for j, L in enumerate(Ls)]))
-        allsc = all(L.opts & ops.OPT_META_SCALABLE for blk in blocks for L in blk.values())
-        return ops.DecodePlan(stages, nbits, opts=(ops.OPT_META_SCALABLE if (allsc and a.gemv_mode == "exact") else 0))
-
-    # ---- the same launches as a chain of overlapped launches (csrc/gemv_chain.hip): two streams, in-kernel waits ----
-    def make_chain(x_by_k=None, outs_by_grp=None):
-        X = xs if x_by_k is None else x_by_k
-        OL = out_local if outs_by_grp is None else outs_by_grp
-        stages, sopts = [], []
-        for blk in blocks:
-            for grp in EXCHANGE_GROUPS:
-                Ls = [blk[name] for name in grp]
-                stages.append((X[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N, OL[grp][j]) for j, L in enumerate(Ls)]))
-                sopts.append(group_opts(Ls))
-        return ops.LaunchChain(stages, nbits, opts=sopts)
-
     # auto: peer-memory stores (csrc/exchange.hip) when they validate against the collective, else coalesced per-slab gathers on RCCL, else
     # the shard-wide gather; peer / rows1 / gather force one
     xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")
@@ -548,21 +524,13 @@ def main():
                 xmode["rows1"], xmode["coalesced"] = True, coalesce
                 break
     use_graph = not a.no_graph and os.environ.get("HQQ_BENCH_GRAPH", "1") != "0" and (world == 1 or dist.get_backend() == "nccl")
-    engine = a.engine and decode and world == 1 and M == 1 and a.dtype == "f16" and nbits in (8, 4, 2) and a.gemv_mode != "factored"
-    chained = a.chain and not engine and decode and world == 1 and M <= 4 and a.dtype == "f16" and nbits in (8, 4, 2) and a.gemv_mode != "factored" and S == 1
-    plan = make_plan() if engine else None
-    chain = make_chain() if chained else None
-    run, graphed = _graphed(plan.run if engine else (chain.run if chained else step), use_graph, rank)
+    run, graphed = _graphed(step, use_graph, rank)
     mode_name = {"exact": "exact", "exact4": "exact (four-op rebuild forced)", "factored": "factored"}[a.gemv_mode]
 
     sec_per_step, dev_sec_per_step = _timed(run, a.steps, a.warmup, dist, dev)
-    if engine:
-        assert plan.status() == 0, f"decode engine: a hand-off timed out (status {plan.status()})"
-    if chained:
-        assert chain.status() == 0, f"chained launches: an in-kernel wait gave up (status {chain.status()})"
 
     # ---- accounting ----
-    launches_per_step = 1 if engine else nblocks * (len(EXCHANGE_GROUPS) if grouped else len(BLOCK))
+    launches_per_step = nblocks * (len(EXCHANGE_GROUPS) if grouped else len(BLOCK))
     stages_per_step = nblocks * len(EXCHANGE_GROUPS)
     bytes_per_step_rank = nblocks * sum(gemv_bytes(dimN[n], K, nbits, M) for n, _, K in BLOCK)
     flops_per_step_rank = nblocks * sum(2.0 * M * dimN[n] * K for n, _, K in BLOCK)
@@ -580,10 +548,7 @@ def main():
             "tok_s": round(M / sec_per_step, 2),
             "config": {"workload": f"{model} linear stack ({nblocks} blocks x q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, bs={M} decode, "
                                    f"{'bf16' if a.dtype == 'bf16' else 'fp16'}, " +
-                                   (f"persistent decode engine: 1 launch / {stages_per_step} dependent stages per step" if engine else
-                                    f"{launches_per_step} fused dequant-GEMV launches/step as a CHAIN on two streams: launch s+1 requests and rebuilds its first weight units while launch s "
-                                    f"streams, then waits in the kernel for launch s's arrival counters before it reads x (q|k|v, o, gate|up, down grouped)" if chained else
-                                    f"{launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})") +
+                                   f"{launches_per_step} fused dequant-GEMV launches/step ({'q|k|v, o, gate|up, down grouped' if grouped else 'one per layer'})" +
                                    (", hipGraph replay" if graphed else ", eager launches") + (f", {S} parallel branches (dependency chain NOT modelled)" if S > 1 else ""),
                        "global_batch": M,
                        "parallelism": "single-gpu" if world == 1 else
@@ -597,8 +562,8 @@ def main():
         ach = (bytes_per_step_rank / unit_launches) / avg_launch_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            # PMC traffic is committed for the configuration it was measured on only (7B, bs=1 fp16, exact mode)
-                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and a.gemv_mode != "factored" and not big and not engine and not chained) else None,
-                           "kernel": ("hqq::decode_engine_kernel" if engine else ("hqq::gemv_chain_kernel<%d, %d, three-op rebuild>" % (nbits, M)) if chained else _decode_kernel_name(nbits, M, a.dtype, a.gemv_mode)),
+                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and a.gemv_mode != "factored" and not big) else None,
+                           "kernel": _decode_kernel_name(nbits, M, a.dtype, a.gemv_mode),
                            "avg_launch_us": round(avg_launch_s * 1e6, 3),
                            "bytes_per_launch": bytes_per_step_rank // unit_launches,
                            "note": "avg launch = HIP-event time of the timed region / dependent stages (includes inter-kernel gaps"
@@ -687,30 +652,6 @@ def main():
             _decode_kernel_name(nbits, 1, a.dtype, a.gemv_mode))
         leg("4096x4096 bs=32 (one layer per launch)", lambda: single(xs32[4096], y32), len(qs) * gemv_bytes(4096, 4096, nbits, 32), 32, len(qs),
             _decode_kernel_name(nbits, 32, a.dtype, a.gemv_mode))
-        if a.gemv_mode != "factored":
-            try:
-                if chained:   # the headline ran chained: the stream-ordered launches of the same stack beside it
-                    leg("7b-stack bs=1, 128 stream-ordered launches (hqq_hip_gemv_grouped)", step, bytes_per_step_rank, 1, stages_per_step,
-                        _decode_kernel_name(nbits, 1, a.dtype, a.gemv_mode))
-                else:
-                    c2 = make_chain()
-                    leg("7b-stack bs=1, chained launches (two streams, in-kernel waits)", c2.run, bytes_per_step_rank, 1, stages_per_step,
-                        "hqq::gemv_chain_kernel")
-                    legs[-1]["status"] = c2.status()
-                c3 = ops.LaunchChain([(xs[4096], [(L.Wq, L.scale, L.zero, None, L.N, y1)]) for L in qs], nbits, opts=[group_opts([L]) for L in qs])
-                leg("4096x4096 bs=1, chained launches (one layer per link)", c3.run, len(qs) * gemv_bytes(4096, 4096, nbits, 1), 1, len(qs), "hqq::gemv_chain_kernel")
-                legs[-1]["status"] = c3.status()
-            except Exception as e:
-                legs.append({"name": "chained launches", "error": repr(e)})
-        if not engine and a.gemv_mode != "factored":
-            try:
-                p2 = make_plan()
-                leg("7b-stack bs=1, persistent decode engine (1 launch/token, stage hand-offs in-kernel)", p2.run, bytes_per_step_rank, 1, stages_per_step,
-                    "hqq::decode_engine_kernel")
-                legs[-1]["launches_per_step"] = 1
-                legs[-1]["status"] = p2.status()
-            except Exception as e:
-                legs.append({"name": "persistent decode engine", "error": repr(e)})
         # the other hot path: Quantizer.quantize = solver + packing, one HIP launch chain per layer
         try:
             qres = []

@@ -34,7 +34,6 @@ SYMBOLS = {
     "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
-    "hqq_hip_gemv_chained": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _vp, _vp]),
     "hqq_hip_exchange": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u32, _vp]),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_forward_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
@@ -42,10 +41,6 @@ SYMBOLS = {
     "hqq_hip_gemm_plan": (_i32, [_i32, _i64, _i64, _i64, _i64, _i32, _u32, _vp]),
     "hqq_hip_forward_prefers_fused": (_i32, [_i32, _i64, _i64, _i64, _i64, _i32]),
     "hqq_hip_forward": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
-    "hqq_hip_decode_plan_bytes": (_sz, [_i32]),
-    "hqq_hip_decode_plan_init": (_i32, [_vp, _sz, _i32, _i64, _i32, _i64, _u32, _vp, _i32, _i32]),
-    "hqq_hip_decode_run": (_i32, [_vp, _vp, _sz, _vp]),
-    "hqq_hip_decode_plan_status_offset": (_sz, [_vp]),
     "hqq_hip_quantize_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "hqq_hip_quantize": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

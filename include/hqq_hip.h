@@ -148,41 +148,6 @@ int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* con
                          int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                          void* stream);
 /* ---------------------------------------------------------------------------------------------
- * Chained decode launches (ABI 3): hqq_hip_gemv_grouped as a LINK of a chain of dependent launches that overlap.
- * In a decode step launch s + 1 reads what launch s wrote (q|k|v -> o -> gate|up -> down -> next block: the loop around
- * HQQLinear.forward, hqq/utils/generation_hf.py:117-540; forward itself: quantize.py:880-898).  Stream order makes that safe and
- * costs a kernel boundary + prologue + pipeline fill per launch (~3.4 us against 3.6 us of weight streaming at the 7B shapes).
- * A chained launch does everything that does not need x BEFORE x exists — it requests its first packed units and rebuilds them to
- * fp16 MFMA operands in registers — then waits IN the kernel for its predecessor's arrival counters, reads x and contracts.  The
- * caller puts consecutive links on TWO streams (even / odd) so that link s + 1 starts while link s streams; link s + 2 follows
- * link s in stream order, so at most two links are alive, and a link places at most half of what a compute unit admits: both are
- * fully resident whatever the dispatch order (a waiting workgroup never keeps a producing one off the chip).
- * Same arithmetic, same summation order, same bits as hqq_hip_gemv_grouped.  Covered: fp16, nbits in {8,4,2}, group_size 64,
- * 1 <= M <= 4, exact weights (opts 0 or HQQ_OPT_META_SCALABLE), K % 64 == 0; else HQQ_ERR_UNSUPPORTED.
- *   link->wait          the predecessor's arrival counters (HQQ_CHAIN_COUNTER_BYTES, 128-byte aligned), or NULL: x is complete when
- *                       the launch starts (the first link of a step; plain stream order)
- *   link->wait_arrivals what the predecessor's call returned in *arrivals
- *   link->signal        this launch's arrival counters, or NULL: no later launch waits for it
- *   link->status        one uint32, shared by the chain: a wait that gives up after spin_limit polls writes 1 + its workgroup index
- *                       there and runs on WITHOUT waiting (outputs undefined, reported, never a hang).  0 = every hand-off completed.
- *   link->spin_limit    polls before giving up (0 = 65536, roughly 50 ms)
- * The caller zeroes every counter block and the status word before the first link of a step (one memset node under graph capture)
- * and keeps outputs that a later link reads untouched until the chain has finished.  *arrivals receives the number of arrivals this
- * launch will add to link->signal.
- * ------------------------------------------------------------------------------------------- */
-#define HQQ_CHAIN_COUNTER_BYTES 4096
-typedef struct hqq_hip_chain_link {
-  const void* wait;
-  void* signal;
-  void* status;
-  uint32_t wait_arrivals;
-  uint32_t spin_limit;
-} hqq_hip_chain_link;
-int hqq_hip_gemv_chained(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
-                         const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
-                         int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, const hqq_hip_chain_link* link,
-                         uint32_t* arrivals, void* stream);
-/* ---------------------------------------------------------------------------------------------
  * One exchange point of a column-sharded decode step (ABI 4; csrc/exchange.hip), one activation row, without a collective library.
  * The reference has no multi-GPU path for HQQLinear.forward (quantize.py:880-898); the shard is SURVEY.md section 8e's: rank r holds the
  * packed-row block r of every layer and computes, per slab s, the output columns s N/per + [r n', (r + 1) n'), n' = N / (per P).
@@ -201,40 +166,6 @@ int hqq_hip_gemv_chained(int nbits, int n_layers, const void* x, const void* con
 #define HQQ_EXCHANGE_MAX_RANKS 16
 int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int nbits, int dtype, int world, int rank,
                      void* const* full, void* const* flags, void* status, uint32_t spin_limit, void* stream);
-/* ---------------------------------------------------------------------------------------------
- * The persistent decode engine: one launch walks a whole list of DEPENDENT stages, one activation row (bs = 1).
- * A stage is what one hqq_hip_gemv_grouped call computes — up to HQQ_GEMV_MAX_GROUP layers reading the same x[1,K] — and stage
- * s + 1 may read what stage s wrote: the engine publishes a stage's outputs device-wide before any workgroup reads the next x,
- * while the packed weights of the following stages are already streaming.  It replaces the per-layer launch sequence of a decode
- * step (the loop around HQQLinear.forward in hqq/utils/generation_hf.py:117-540; forward itself: quantize.py:880-898).
- * Covered: nbits in {8,4,2}, group_size 64, fp16, M = 1, N % (8/nbits) == 0, K % 64 == 0.
- *
- * The plan is a caller-owned blob of hqq_hip_decode_plan_bytes(n_stages) bytes: hqq_hip_decode_plan_init fills a HOST buffer
- * (descriptors of every stage + launch geometry for the current device); the caller copies it once to a 256-byte aligned
- * DEVICE buffer of the same size and passes both to hqq_hip_decode_run, which enqueues a clear of the plan's sync words and
- * the engine launch on `stream` (capturable).  The library keeps no pointer.  The word at
- * hqq_hip_decode_plan_status_offset() of the device buffer is 0 after a run in which every hand-off completed (else 1 + the
- * stage whose wait gave up: the outputs are then undefined).  One run of a given device plan at a time.
- * ------------------------------------------------------------------------------------------- */
-typedef struct hqq_hip_decode_stage {
-  const void* x;            /* [1, K] activations of this stage (may be an output buffer of an earlier stage) */
-  int64_t K;
-  int32_t n_layers;         /* 1..HQQ_GEMV_MAX_GROUP */
-  int32_t reserved;
-  const void* Wq[HQQ_GEMV_MAX_GROUP];
-  const void* scale[HQQ_GEMV_MAX_GROUP];
-  const void* zero[HQQ_GEMV_MAX_GROUP];
-  const void* bias[HQQ_GEMV_MAX_GROUP];   /* entries may be NULL */
-  void* y[HQQ_GEMV_MAX_GROUP];            /* [1, N[i]] */
-  int64_t N[HQQ_GEMV_MAX_GROUP];
-} hqq_hip_decode_stage;
-size_t hqq_hip_decode_plan_bytes(int n_stages);
-/* grid: workgroups to launch, 0 = one per compute unit of the current device (anything larger would not be co-resident) */
-int hqq_hip_decode_plan_init(void* plan_host, size_t plan_bytes, int nbits, int64_t group_size, int dtype, int64_t M, uint32_t opts,
-                             const hqq_hip_decode_stage* stages, int n_stages, int grid);
-int hqq_hip_decode_run(const void* plan_host, void* plan_dev, size_t plan_bytes, void* stream);
-size_t hqq_hip_decode_plan_status_offset(const void* plan_host);
-
 /* ---------------------------------------------------------------------------------------------
  * The steps either side of the GEMVs in a decode step (ABI 5; csrc/block.hip).  The reference's headline is the
  * tok/s of its generate loop (hqq/utils/generation_hf.py:117-540, Readme.md:153), whose decoder block around HQQLinear.forward is HF's

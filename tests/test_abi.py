@@ -62,8 +62,6 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(511), 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2      # 511 columns do not split into two slab runs
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 0, 2, 0, VP2, VP2, st, 0, None) == -3      # fp32 activations
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 1, 2, 2, VP2, VP2, st, 0, None) == -2      # rank 2 of 2
-    # the decode plan: sizes and argument checks on the host
-    assert L.hqq_hip_decode_plan_bytes(0) == 0 and L.hqq_hip_decode_plan_bytes(128) == 256 + 128 * 256 + 1280
 
 
 def test_the_library_owns_no_device_memory_and_reads_no_environment():
@@ -74,7 +72,7 @@ def test_the_library_owns_no_device_memory_and_reads_no_environment():
         _C.build()
     syms = subprocess.run(["nm", "-D", "--undefined-only", _C.LIB_PATH], capture_output=True, text=True).stdout
     for banned in (r"hipMalloc", r"hipFree", r"hipDeviceSynchronize", r"hipStreamSynchronize", r"getenv", r"hipMemset@", r"hipMemcpy"):
-        assert not re.search(r"\b" + banned, syms), banned   # (hipMemsetAsync — stream-ordered — is what the engine's sync words use)
+        assert not re.search(r"\b" + banned, syms), banned   # (hipMemsetAsync — stream-ordered — clears the meta check's counter)
 
 
 def test_ops_refuse_cpu_tensors():
