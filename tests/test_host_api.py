@@ -187,16 +187,10 @@ def test_set_gemv_mode_combines_with_a_layers_own_option_bits():
     finally:
         ops.set_gemv_mode(ops.GEMV_EXACT)
     assert ops.layer_opts(ops.OPT_META_SCALABLE) == ops.OPT_META_SCALABLE
-
-
-def test_chain_link_struct_matches_the_header():
-    """hqq_hip_chain_link (include/hqq_hip.h) as ctypes sees it: three pointers and two uint32 — 32 bytes, fields in the header's order"""
-    import ctypes
-    import re
-    from hqq_amd import ops
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hqq_hip.h")).read()
-    body = re.search(r"typedef struct hqq_hip_chain_link \{(.*?)\} hqq_hip_chain_link;", hdr, re.S).group(1)
-    names = re.findall(r"(\w+);", body)
-    assert names == ["wait", "signal", "status", "wait_arrivals", "spin_limit"]
-    assert [f[0] for f in ops._ChainLink._fields_] == names and ctypes.sizeof(ops._ChainLink) == 32
-    assert int(re.search(r"#define HQQ_CHAIN_COUNTER_BYTES (\d+)", hdr).group(1)) == ops.CHAIN_COUNTER_BYTES
+    # the 3-bit stream-layout bit describes the tensor, not the arithmetic: it travels in every mode
+    assert ops.layer_opts(ops.OPT_W3S | ops.OPT_META_SCALABLE) == ops.OPT_W3S | ops.OPT_META_SCALABLE
+    try:
+        ops.set_gemv_mode(ops.GEMV_FACTORED)
+        assert ops.layer_opts(ops.OPT_W3S | ops.OPT_META_SCALABLE) == ops.OPT_W3S | ops.OPT_FACTORED
+    finally:
+        ops.set_gemv_mode(ops.GEMV_EXACT)
