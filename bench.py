@@ -22,10 +22,11 @@ configs[4]: the Llama-2-70B linear shapes (q,o 8192x8192; k,v 1024x8192; gate,up
 nbits=4, every layer's output columns sharded over the N ranks (packed-row blocks of the reference layout,
 hqq_amd/shard.py) — STRONG scaling of fixed layers: x is replicated, every exchange point (after q|k|v, o,
 gate|up, down) completes the outputs in the reference's column order inside the timed region, and the exchange is
-also timed on its own.  At one activation row the exchange is, in order of preference: one small kernel storing the
-rank's slices into every rank's full rows over peer memory (csrc/exchange.hip; arenas mapped through IPC handles,
-validated against the collective at start-up), per-slab RCCL all-gathers in one coalesced launch, or the shard-wide
-all-gather + un-permute (HQQ_BENCH_EXCHANGE=peer|rows1|gather forces one; the JSON's `exchange` block says which ran).
+also timed on its own.  At one activation row the exchange is per-slab RCCL all-gathers in one coalesced launch (straight into
+the reference's column order) or, where the backend cannot coalesce, the shard-wide all-gather + un-permute; HQQ_BENCH_EXCHANGE=peer
+opts into one small kernel storing the rank's slices into every rank's full rows over peer memory (csrc/exchange.hip; fine-grained
+arenas mapped through IPC handles, validated against the collective at start-up; a wait that gives up fails the run) — opt-in until
+it has run over xGMI on a real node; rows1 / gather force a collective form; the JSON's `exchange` block says which ran.
 `--workload decode --gpus N` keeps round 1's weak-scaling variant (every rank streams a 7B-stack-sized shard).
 
 Prints ONE JSON line on rank 0.  `value` = algorithmic GB/s streamed by the whole job (SURVEY.md §8d bytes:
@@ -462,10 +463,11 @@ def main():
                 if world > 1 and bs_x is None:
                     exchange(grp)
 
-    # auto: peer-memory stores (csrc/exchange.hip) when they validate against the collective, else coalesced per-slab gathers on RCCL, else
-    # the shard-wide gather; peer / rows1 / gather force one
+    # auto (default): the collective — coalesced per-slab gathers on RCCL, else the shard-wide gather.  peer: the peer-memory kernel
+    # (csrc/exchange.hip) when it validates against the collective at start-up — opt-in until it has run over xGMI on a real node (advisor,
+    # round 3: nothing here has been measured on more than one GPU).  rows1 / gather force one collective form.
     xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")
-    if world > 1 and M == 1 and strong and xenv in ("auto", "peer"):
+    if world > 1 and M == 1 and strong and xenv == "peer":
         # Build the peer arenas (collective), then VALIDATE three rounds of every exchange point against the collective on fresh random
         # slices; every rank must agree, else the mode is dropped.  Waits are bounded: a peer that never delivers is reported, not hung on.
         from hqq_amd import shard as _shard
@@ -528,6 +530,9 @@ def main():
     mode_name = {"exact": "exact", "exact4": "exact (four-op rebuild forced)", "factored": "factored"}[a.gemv_mode]
 
     sec_per_step, dev_sec_per_step = _timed(run, a.steps, a.warmup, dist, dev)
+    if xmode.get("peer") is not None:   # a wait that gave up inside the timed region: the rows of that exchange were undefined — not a measurement
+        st_ = xmode["peer"].status()
+        assert st_ == 0, f"rank {rank}: the peer-memory exchange reported a wait that gave up (status {st_}) inside the timed region"
 
     # ---- accounting ----
     launches_per_step = nblocks * (len(EXCHANGE_GROUPS) if grouped else len(BLOCK))
@@ -580,6 +585,7 @@ def main():
                                         ("per-slab all-gathers straight into the reference's column order" + (", one coalesced RCCL launch per exchange point" if xmode["coalesced"] else ", issued one by one")) if rows1 else "one all-gather of the shard outputs per exchange point + un-permute copies"),
                                "exchange_kernels_per_step": stages_per_step if peer else 0,
                                "peer_status": xmode["peer"].status() if peer else None,
+                               "peer_memory": xmode["peer"].memory_kind if peer else None,
                                "collective_launches_per_step": 0 if peer else ((stages_per_step if xmode["coalesced"] else n_slab_gathers) if rows1 else stages_per_step),
                                "all_gathers_per_step": 0 if peer else (n_slab_gathers if rows1 else stages_per_step),
                                "unpermute_kernels_per_step": 0 if (rows1 or peer) else nblocks * len(BLOCK),

@@ -7,9 +7,13 @@
 // latency is several times the 4-8 us GEMV it follows.  Here every rank
 //   1. stores its slice straight into every peer's FULL output row, at the columns the reference order gives it: rank r's packed-row
 //      block yields, per slab s, the columns s N/per + [r n', (r + 1) n'), n' = N / (per P) — so nothing is permuted afterwards,
-//   2. makes those stores visible at system scope and raises its flag in that peer's flag block (a plain 4-byte store, the one thing
-//      that certainly works over xGMI — no remote atomics),
-//   3. waits, in the workgroup that served its own row, until all P flags of its own block are up, and lowers them again.
+//   2. makes those stores visible at system scope and writes the exchange's GENERATION into its flag word of that peer's flag block (a
+//      plain 4-byte store, the one thing that certainly works over xGMI — no remote atomics).  The generation is the number of times
+//      this point has been used, counted on the device (the kernel's workgroups draw tickets from a local counter: ticket / world), so
+//      it also counts under hipGraph replay; every rank issues the same sequence of points, so every rank counts the same,
+//   3. waits, in the workgroup that served its own row, until all P flag words of its own block have reached the generation.  Flags are
+//      never lowered: a flag that arrives late (after a wait gave up) is one generation behind the next use of the point and cannot
+//      satisfy it (round 3 lowered 0 / 1 flags: a late flag stayed raised and let the next exchange through before its data — advisor).
 // When the kernel has finished, this rank's full rows are complete: the next kernel in stream order may read them (kernel boundaries
 // order memory at device scope, as for any stream-ordered pair of kernels).
 //
@@ -17,8 +21,9 @@
 // can raise its flag for the next use of a point only after this rank has raised a flag for a LATER point, i.e. after this kernel has
 // finished here — flags are never raised onto a block that is still being waited on, and rows are never overwritten before the kernel
 // that reads them has run.  A decoder block has four points (q|k|v, o, gate|up, down).
-// A wait gives up after spin_limit polls: it writes 1 + the index of the missing rank to *status and returns (outputs undefined,
-// reported, never a hang).
+// A wait gives up after spin_limit polls: it writes 1 + the index of the missing rank to *status (sticky until the caller's collective
+// reset) and returns (outputs of that exchange undefined, reported, never a hang).
+// Flag block of a point (local memory of each rank): HQQ_EXCHANGE_MAX_RANKS flag words + the launch-ticket word.
 #include "hqq_common.h"
 
 namespace hqq {
@@ -37,7 +42,12 @@ struct XgArgs {
 };
 
 __global__ __launch_bounds__(256) void exchange_kernel(const XgArgs a) {
+  __shared__ uint32_t gen_s;
   const int tid = threadIdx.x;
+  // this launch's generation: its `world` workgroups draw tickets n world .. n world + world - 1 from the point's local counter (order-free)
+  if (tid == 0) gen_s = __hip_atomic_fetch_add(a.flags[a.rank] + XG_MAXP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / static_cast<uint32_t>(a.world) + 1u;
+  __syncthreads();
+  const uint32_t gen = gen_s;
   // workgroup b serves rank (rank + 1 + b) % world: neighbours first, this rank's own row last (its workgroup is the one that waits)
   const int p = (a.rank + 1 + static_cast<int>(blockIdx.x)) % a.world;
   for (int j = 0; j < a.n_layers; ++j) {
@@ -55,18 +65,17 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XgArgs a) {
   }
   __threadfence_system();   // this thread's stores are visible at system scope ...
   __syncthreads();          // ... for every thread of the workgroup, before the flag goes up
-  if (tid == 0) __hip_atomic_store(a.flags[p] + a.rank, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(a.flags[p] + a.rank, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (p != a.rank) return;
   if (tid < a.world) {
     const uint32_t limit = a.spin_limit ? a.spin_limit : (1u << 22);
     uint32_t n = 0;
-    while (__hip_atomic_load(a.flags[p] + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+    // (generations only grow; the signed difference tolerates the counter's wrap)
+    while (static_cast<int32_t>(__hip_atomic_load(a.flags[p] + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - gen) < 0) {
       if (++n >= limit) { __hip_atomic_store(a.status, 1u + static_cast<uint32_t>(tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       __builtin_amdgcn_s_sleep(8);
     }
   }
-  __syncthreads();          // every flag seen (or given up on) before any is lowered
-  if (tid < a.world) __hip_atomic_store(a.flags[p] + tid, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace hqq
@@ -74,6 +83,7 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XgArgs a) {
 extern "C" int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int nbits, int dtype, int world, int rank,
                                 void* const* full, void* const* flags, void* status, uint32_t spin_limit, void* stream) {
   using namespace hqq;
+  clear_stale_error();
   if (n_layers < 1 || n_layers > XG_MAXL || world < 1 || world > XG_MAXP || rank < 0 || rank >= world) {
     set_error("hqq_hip_exchange: 1..%d layers and 1..%d ranks per exchange point (got %d layers, rank %d of %d)", XG_MAXL, XG_MAXP, n_layers, rank, world);
     return HQQ_ERR_SHAPE;

@@ -114,6 +114,93 @@ class ShardedHQQForward:
     __call__ = forward
 
 
+# ---- fine-grained device memory for the peer-memory exchange ---------------------------------------------------------------------------
+# Peers store into an arena over xGMI while the owning GPU polls flags inside a running kernel and the next kernel reads rows whose
+# addresses repeat every token.  Ordinary (coarse-grained) device memory — what torch's caching allocator hands out — does not promise that
+# such writes become visible during a running kernel, or that the local L2 holds no stale copy; collective libraries allocate their
+# signal words and buffers uncached / fine-grained for this reason (advisor, round 3).  The arena therefore comes from
+# hipExtMallocWithFlags(hipDeviceMallocUncached, else hipDeviceMallocFinegrained) on the process's own HIP runtime (ctypes; the library
+# libhqq_hip.so itself never allocates), is exported with hipIpcGetMemHandle and wrapped as a tensor through __cuda_array_interface__.
+# Where that is not available the torch allocator serves it as before and `memory_kind` says so.
+_HIP_RT = None
+
+
+def _hip_runtime():
+    """the libamdhip64 this process already runs on (torch's), as a ctypes handle; None if it cannot be found"""
+    global _HIP_RT
+    if _HIP_RT is None:
+        import ctypes
+        path = None
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "libamdhip64" in line:
+                        path = line.split()[-1]
+                        break
+        except OSError:
+            pass
+        try:
+            _HIP_RT = ctypes.CDLL(path) if path else False
+        except OSError:
+            _HIP_RT = False
+    return _HIP_RT or None
+
+
+class _RawBuffer:
+    """device memory this module allocated itself, seen by torch through the CUDA array interface (zero-copy)"""
+
+    def __init__(self, ptr: int, nbytes: int, owner=None):
+        self.ptr, self.nbytes, self.owner = int(ptr), int(nbytes), owner
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+
+def _alloc_fine_grained(nbytes: int, device: torch.device):
+    """-> (tensor uint8 [nbytes], kind, raw pointer) from hipExtMallocWithFlags, or None"""
+    import ctypes
+    rt = _hip_runtime()
+    if rt is None or not hasattr(rt, "hipExtMallocWithFlags"):
+        return None
+    with torch.cuda.device(device):
+        for flag, kind in ((0x3, "uncached (hipDeviceMallocUncached)"), (0x1, "fine-grained (hipDeviceMallocFinegrained)")):
+            p = ctypes.c_void_p()
+            if rt.hipExtMallocWithFlags(ctypes.byref(p), ctypes.c_size_t(nbytes), ctypes.c_uint(flag)) == 0 and p.value:
+                try:
+                    t = torch.as_tensor(_RawBuffer(p.value, nbytes), device=device)
+                    t.zero_()
+                    torch.cuda.synchronize(device)
+                    return t, kind, int(p.value)
+                except Exception:   # noqa: BLE001  (no array-interface support in this build: give the memory back, use the allocator)
+                    rt.hipFree(p)
+                    return None
+    return None
+
+
+def _ipc_export(ptr: int) -> bytes | None:
+    import ctypes
+    rt = _hip_runtime()
+    h = ctypes.create_string_buffer(64)   # hipIpcMemHandle_t
+    if rt is None or rt.hipIpcGetMemHandle(h, ctypes.c_void_p(ptr)) != 0:
+        return None
+    return bytes(h.raw)
+
+
+def _ipc_open(handle: bytes, nbytes: int, device: torch.device):
+    import ctypes
+    rt = _hip_runtime()
+    p = ctypes.c_void_p()
+    hb = ctypes.create_string_buffer(handle, 64)
+
+    class _H(ctypes.Structure):
+        _fields_ = [("reserved", ctypes.c_char * 64)]
+    hv = _H.from_buffer_copy(hb.raw)
+    rt.hipIpcOpenMemHandle.argtypes = [ctypes.POINTER(ctypes.c_void_p), _H, ctypes.c_uint]
+    with torch.cuda.device(device):
+        rc = rt.hipIpcOpenMemHandle(ctypes.byref(p), hv, ctypes.c_uint(1))   # hipIpcMemLazyEnablePeerAccess
+    if rc != 0 or not p.value:
+        raise RuntimeError(f"hipIpcOpenMemHandle failed (rc={rc})")
+    return torch.as_tensor(_RawBuffer(p.value, nbytes), device=device)
+
+
 class PeerExchange:
     """The exchange points of a column-sharded decode step over PEER MEMORY (csrc/exchange.hip, hqq_hip_exchange) instead of a
     collective library: one small kernel per point stores this rank's slices straight into every rank's full rows — in the reference's
@@ -122,7 +209,10 @@ class PeerExchange:
     points: one list per exchange point with the FULL widths N of the layers exchanged together (a decoder block:
     [[Nq, Nk, Nv], [No], [Ngate, Nup], [Ndown]]).  Every rank builds the object with the same arguments; construction is collective
     (the arenas' IPC handles are all-gathered over `group`).  Consecutive run() calls must alternate between at least two points
-    (the kernel's re-use rule); run() enforces it.
+    (the kernel's re-use rule: it protects the ROWS — a captured graph holding an odd sequence of points must not be replayed back to
+    back; the flags carry generations and need no such care); run() enforces it for eager sequences.  The arena (flag lines, status, rows)
+    is fine-grained / uncached device memory where the runtime offers it (`memory_kind`).  status() / check() report a wait that gave up;
+    reset() (collective) clears it.
 
         px = PeerExchange(points, nbits, torch.float16, device)
         px.run(e, [y_q, y_k, y_v])      # y_*: this rank's [1, N/P] outputs of point e, local order
@@ -166,21 +256,45 @@ class PeerExchange:
         assert self.arena_bytes == self._layout_bytes(self.points, self.world)
         self.spin_limit = int(spin_limit)
         self._last = None
+        self._group = group
+        self._collective = _arenas is None and self.world > 1
+        self.memory_kind = "caller's tensors (single-process group)"
+        self._raw_ptr = None
         if _arenas is not None:      # single-process group (tests): the ranks' arenas are plain tensors of this process
             self._arenas = list(_arenas)
         else:
-            mine = torch.zeros(self.arena_bytes, dtype=torch.uint8, device=self.device)
+            raw = _alloc_fine_grained(self.arena_bytes, self.device)
+            use_raw = raw is not None
+            if self.world > 1:   # every rank must take the same route (the handles are of different kinds)
+                flags_ = [None] * self.world
+                dist.all_gather_object(flags_, use_raw, group=group)
+                use_raw = all(flags_)
+            if use_raw:
+                mine, self.memory_kind, self._raw_ptr = raw
+            else:
+                if raw is not None:
+                    _hip_runtime().hipFree(__import__("ctypes").c_void_p(raw[2]))
+                mine = torch.zeros(self.arena_bytes, dtype=torch.uint8, device=self.device)
+                self.memory_kind = "coarse-grained (torch caching allocator: hipExtMallocWithFlags unavailable on some rank)"
             torch.cuda.synchronize(self.device)
             if self.world == 1:
                 self._arenas = [mine]
             else:
-                from torch.multiprocessing.reductions import reduce_tensor
                 handles = [None] * self.world
-                dist.all_gather_object(handles, reduce_tensor(mine), group=group)
+                if use_raw:
+                    dist.all_gather_object(handles, _ipc_export(self._raw_ptr), group=group)
+                else:
+                    from torch.multiprocessing.reductions import reduce_tensor
+                    dist.all_gather_object(handles, reduce_tensor(mine), group=group)
                 # (a process cannot open its own handle; peers' arenas are mapped into this process: stores to them travel over xGMI)
                 err = None
                 try:
-                    self._arenas = [mine if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
+                    if use_raw:
+                        if any(h is None for h in handles):
+                            raise RuntimeError("hipIpcGetMemHandle failed on some rank")
+                        self._arenas = [mine if p == self.rank else _ipc_open(handles[p], self.arena_bytes, self.device) for p in range(self.world)]
+                    else:
+                        self._arenas = [mine if p == self.rank else handles[p][0](*handles[p][1]) for p in range(self.world)]
                 except Exception as e:   # noqa: BLE001  (IPC not available between these devices / processes)
                     err = e
                 # every rank reports; this is also the barrier: nobody stores into an arena before every rank has mapped all of them, and
@@ -226,6 +340,26 @@ class PeerExchange:
         """0, or 1 + the rank whose flag a wait gave up on (then the rows of that exchange are undefined)"""
         a = self._arenas[self.rank]
         return int(a[self._status_off:self._status_off + 4].view(torch.int32).item())
+
+    def check(self) -> None:
+        """raise if a wait of any earlier exchange gave up (synchronises); the rows of that exchange were undefined"""
+        st = self.status()
+        if st:
+            raise RuntimeError(f"hqq_amd: PeerExchange: a wait for rank {st - 1} gave up (status {st}); outputs of that exchange were undefined — reset() before going on")
+
+    def reset(self) -> None:
+        """collective: every rank clears its flag words, launch tickets and status between two barriers (after a reported time-out, or to
+        restart the generation count); no exchange may be in flight"""
+        torch.cuda.synchronize(self.device)
+        if self._collective:
+            import torch.distributed as dist
+            dist.barrier(group=self._group)
+        self._arenas[self.rank][:self._status_off + 128].zero_()
+        torch.cuda.synchronize(self.device)
+        if self._collective:
+            import torch.distributed as dist
+            dist.barrier(group=self._group)
+        self._last = None
 
     def run(self, e: int, y_loc) -> None:
         if self._last == e:

@@ -152,14 +152,18 @@ int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* con
  * The reference has no multi-GPU path for HQQLinear.forward (quantize.py:880-898); the shard is SURVEY.md section 8e's: rank r holds the
  * packed-row block r of every layer and computes, per slab s, the output columns s N/per + [r n', (r + 1) n'), n' = N / (per P).
  * This call stores the rank's slices y_loc[j] ([1, N_loc[j]], local slab-major order) straight into EVERY rank's full row of layer j
- * at those columns — peers' rows are device pointers the caller obtained with hipIpcOpenMemHandle (stores travel over xGMI) — raises
- * this rank's flag in every rank's flag block, waits until all `world` flags of its own block are up and lowers them.  When the
+ * at those columns — peers' rows are device pointers the caller obtained with hipIpcOpenMemHandle (stores travel over xGMI) — writes
+ * the exchange's generation (how often this point has been used: counted on the device, so it counts under graph replay too) into this rank's
+ * flag word of every rank's flag block and waits until all `world` flag words of its own block have reached it.  Flags only grow: one that
+ * arrives after a wait gave up cannot satisfy the next use of the point.  When the
  * kernel has finished, this rank's full rows are complete and in the reference's column order; the next kernel in stream order may
  * read them.  Capturable.  One launch, `world` workgroups.
  *   full    [world * n_layers] pointers: full[p * n_layers + j] = rank p's [1, N_loc[j] * world] row of layer j (p == rank: local)
- *   flags   [world] pointers: rank p's flag block of THIS point, `world` uint32 words, zero before the first use (p == rank: local)
+ *   flags   [world] pointers: rank p's flag block of THIS point: HQQ_EXCHANGE_MAX_RANKS + 1 uint32 words (a flag word per rank, then the
+ *           rank's own launch-ticket word), all zero before the first use and only reset collectively (every rank, between two barriers);
+ *           fine-grained / uncached device memory is the right kind for them and for the rows (peers write while a local kernel polls)
  *   status  one local uint32: a wait that gives up after spin_limit polls (0 = 4 Mi, seconds) writes 1 + the missing rank there
- *           and returns — outputs undefined, reported, never a hang
+ *           and returns — outputs of that exchange undefined, reported, never a hang; sticky until the caller clears it
  * Re-use rule: consecutive exchanges on a stream must alternate between at least two points (flag block + rows); a decoder block
  * has four.  Every rank must issue the same sequence of points.  dtype F16 / BF16; nbits picks `per` (3-bit shards: per = 1).
  * ------------------------------------------------------------------------------------------- */
