@@ -1,0 +1,255 @@
+// gemm_dense.hip — y[M,N] = x[M,K] . Wd[N,K]^T (+ bias): the dense contraction of HQQLinear.matmul (hqq/core/quantize.py:880-882,
+// torch.matmul(x, W.t())) on the matrix cores, fp16 / bf16, fp32 accumulation, gfx950.  The GEMM half of the prefill path: hqq_hip_dequantize
+// rebuilds the layer's weights ONCE (bit-identical to Quantizer.dequantize), this kernel contracts them with any number of tokens —
+// no library call on the hot path (round 3's long-prompt route was hqq_hip_dequantize + hipBLASLt through torch.matmul).
+//
+// Why not the fused kernel here (gemm_pipe.hip): it rebuilds every weight once per 256-token tile — 32 times at 8192 tokens, 1.4 VALU per
+// MFMA, B-fragment reads as long as the MFMAs — and measured 1.07-1.10 PFLOP/s where dequantise-once + a plain GEMM gives 1.22-1.24
+// (profiles/r03_pipe8k_ablation.txt).  Beyond ~1000 tokens rebuilding once and streaming fp16 weights wins; below, gemm_pipe.hip.
+//
+// Structure (the 256 x 256 x 64 tile of the CDNA guide, four phases per K tile, every byte by LDS-DMA, counted vmcnt, one raw barrier per phase):
+//   tile     256 tokens x 256 features x 64 k per workgroup; 8 waves as 2 (tokens) x 4 (features): a wave owns 128 tokens x 64 features =
+//            8 x 4 MFMA tiles of 16 x 16 (v_mfma_f32_16x16x32: A operand = 16 features, B operand = 16 tokens, so a lane ends up with 4
+//            consecutive features of one token), 128 accumulator registers.
+//   LDS      two K-tile buffers of [256 x rows | 256 Wd rows] x 128 bytes (64 KiB each).  A 1-KiB DMA piece = 8 rows x 128 bytes; the 16-byte
+//            chunk a position holds is XOR-ed with a function of the row (gemm_pipe.hip's map) on the SOURCE address, so that the fragment
+//            reads (lane (r, c): chunks 2c, 2c + 1 of row 16 j + r) are conflict-free.
+//   phases   a K tile's 64 MFMAs per wave go in four quadrants (token half x feature half of the wave's sub-tile), ordered so that the
+//            fragments a quadrant needs beyond its predecessor's are few and the last quadrant (X1, W1) leaves the registers of the next
+//            tile's first (X0, W0) free:   Q0 = (X0, W0)   Q1 = (X0, W1)   Q2 = (X1, W0)   Q3 = (X1, W1)
+//            phase q:  wait (the DMA pieces the NEXT quadrant reads have landed; this wave's previous reads have returned) -> barrier ->
+//                      issue the DMA pieces whose LDS rows the previous phase read last -> read the next quadrant's missing fragments ->
+//                      16 MFMAs of quadrant q (fragments read one phase ago).
+//            A staging unit = the rows all waves read in one phase (X0: tokens 128 wm + [0, 64); W0: features 64 wn + [0, 32); ...): 16
+//            pieces, 2 per wave.  Every unit is issued 7 phases (1.75 K tiles) before it is read; 10-12 pieces stay in flight across
+//            every barrier (s_waitcnt vmcnt(10 / 12), never 0 in the loop).
+//   order    workgroup -> tile through an XCD-aware bijection (a band of token tiles x all feature tiles per XCD: its L2 holds the band's
+//            x rows and one pass over Wd).
+#include "hqq_common.h"
+
+namespace hqq {
+namespace gd {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NWAVES = 8, NT = NWAVES * 64;
+constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, BUF = XBYTES + WBYTES;   // 32 KiB + 32 KiB per K tile
+
+struct Args {
+  const uint16_t* x;
+  const uint16_t* w;
+  const uint16_t* bias;
+  uint16_t* y;
+  int M, N, K, m_tiles, n_tiles;
+};
+
+typedef __attribute__((address_space(3))) void* lds_t;
+typedef const __attribute__((address_space(1))) void* glb_t;
+__device__ __forceinline__ void dma16(const void* src, uint8_t* lds_wave_base) { __builtin_amdgcn_global_load_lds((glb_t)src, (lds_t)lds_wave_base, 16, 0, 0); }
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+
+template <bool BF>
+__global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];   // [2 buffers][X tile | W tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r = lane & 15, c = lane >> 4;
+  // ---- XCD-aware tile order (workgroup b runs on XCD b % 8 — observed; a speed assumption only): XCD x gets a contiguous run of logical
+  //      tiles; logical tile L = token tile (L / n_tiles), feature tile (L % n_tiles).  Bijective for any grid size ----
+  int mt, nt;
+  {
+    const int nwg = static_cast<int>(gridDim.x), h = static_cast<int>(blockIdx.x), xcd = h & 7, idx = h >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    mt = L / a.n_tiles;
+    nt = L - mt * a.n_tiles;
+  }
+  const int M = a.M, N = a.N, K = a.K, nk = K / BK;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- DMA sources.  Staging unit u (0: X0, 1: W0, 2: W1, 3: X1), piece p (0, 1) of this wave: 8 rows x 128 bytes.
+  //      Unit rows (workgroup tile): X0: 128 g + [0, 64), X1: 128 g + [64, 128), g = 0, 1;  W0: 64 g + [0, 32), W1: 64 g + [32, 64), g = 0..3.
+  //      Piece q = 2 wave + p of a unit (0..15) covers 8 consecutive rows of it ----
+  const uint16_t* src[4][2];
+  int dst[4][2];   // byte offset inside a buffer
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int q = 2 * wave + p, rr = 8 * q + (lane >> 3);          // row 0..127 inside the unit
+      const bool is_x = (u == 0 || u == 3);
+      const int sub = (u == 0 || u == 1) ? 0 : 1;
+      int row;   // row inside the workgroup's X / W tile
+      if (is_x) row = (rr >> 6) * 128 + sub * 64 + (rr & 63);
+      else row = (rr >> 5) * 64 + sub * 32 + (rr & 31);
+      const int pos = lane & 7, ch = pos ^ swz(row);
+      int g = (is_x ? m0 : n0) + row;
+      const int lim = is_x ? M : N;
+      g = g < lim ? g : lim - 1;                                        // rows past the end repeat the last one (their outputs are never stored)
+      src[u][p] = (is_x ? a.x : a.w) + static_cast<int64_t>(g) * K + ch * 8;
+      // the piece's 8 rows are consecutive in the tile (8 q never straddles a 32- or 64-row boundary): wave-uniform LDS base
+      const int row0 = is_x ? (((8 * q) >> 6) * 128 + sub * 64 + ((8 * q) & 63)) : (((8 * q) >> 5) * 64 + sub * 32 + ((8 * q) & 31));
+      dst[u][p] = (is_x ? 0 : XBYTES) + row0 * 128;
+    }
+  auto stage = [&](int u, int kt) {   // unit u of K tile kt (kt < nk) into buffer kt & 1
+    uint8_t* base = lds + (kt & 1) * BUF;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) dma16(src[u][p] + static_cast<int64_t>(kt) * BK, base + dst[u][p]);
+  };
+
+  // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3; W (features, A operand): 4 tiles, sub-half = 2 ----
+  u32x4 xf[2][4][2], wf[2][2][2];   // [sub-half][tile][k half (chunks 2c, 2c + 1)]
+  auto read_x = [&](int s, int kt) {
+    const uint8_t* base = lds + (kt & 1) * BUF;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = wm * 128 + (4 * s + t) * 16 + r;
+      xf[s][t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
+      xf[s][t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
+    }
+  };
+  auto read_w = [&](int s, int kt) {
+    const uint8_t* base = lds + (kt & 1) * BUF + XBYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = wn * 64 + (2 * s + t) * 16 + r;
+      wf[s][t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
+      wf[s][t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
+    }
+  };
+  f32x4 acc[4][8];   // [feature tile][token tile]
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma = [&](const u32x4& A, const u32x4& B, f32x4 C) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, A), __builtin_bit_cast(b8, B), C, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A), __builtin_bit_cast(h8, B), C, 0, 0, 0);
+  };
+  auto quadrant = [&](int xs, int ws) {   // 16 MFMAs: 2 feature tiles x 4 token tiles x 2 k halves
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[xs][t][h], acc[2 * ws + f][4 * xs + t]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: the issue order of the steady state (a unit goes out 7 phases before it is read), K tiles 0 and 1 and the first units of tile 2 ----
+  // steady-state issue sequence per wave: ... e0(t): X0(t+2), W0(t+2) | e1(t): W1(t+2) | e2(t): X1(t+2) | e3(t): - ...
+  // (unit numbering: 0 = X0, 1 = W0, 2 = W1, 3 = X1)
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_x(0, 0);
+  read_w(0, 0);
+
+  // ---- main loop over K tiles.  Phase e_q(t): wait -> barrier -> stage -> read the next quadrant's missing fragments -> 16 MFMAs of Q_q(t).
+  //      reads:  e0: W1(t)   e1: X1(t)   e2: -   e3: X0(t + 1), W0(t + 1)
+  //      stage:  e0: X0, W0 (t + 2) [their rows were read in e3(t - 1)... of tile t, i.e. during the previous phase]   e1: W1(t + 2)   e2: X1(t + 2)
+  //      needs landed before its reads:  e0: W1(t) | e1: X1(t) | e3: X0, W0 (t + 1)
+  //      The counts below are the pieces this wave issued AFTER the ones it waits for (steady state); near the ends of the K range fewer
+  //      are behind them and the wait is for all (vmcnt(0)) ----
+  for (int t = 0; t < nk; ++t) {
+    const bool steady = t >= 2 && t + 2 < nk;   // (the first two tiles were drained in the prologue; the last two issue nothing new)
+    // e0
+    if (steady) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
+    read_w(1, t);
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // e1
+    if (steady) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) stage(2, t + 2);
+    read_x(1, t);
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // e2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) stage(3, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // e3
+    if (steady) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nk) { read_x(0, t + 1); read_w(0, t + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: lane (column r = token inside tile tt, rows 4 c + i = features inside tile ft): 4 consecutive features of one token ----
+  const bool bf = BF;
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const int n = n0 + wn * 64 + ft * 16 + 4 * c;
+    if (n >= N) continue;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int m = m0 + wm * 128 + tt * 16 + r;
+      if (m >= M) continue;
+      uint16_t o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acc[ft][tt][i];
+        if (bf) {
+          uint16_t h = f32_to_bf16(v);
+          if (a.bias && n + i < N) h = f32_to_bf16(bf16_to_f32(h) + bf16_to_f32(a.bias[n + i]));
+          o[i] = h;
+        } else {
+          half_t h = static_cast<half_t>(v);
+          if (a.bias && n + i < N) h = h + reinterpret_cast<const half_t*>(a.bias)[n + i];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
+          o[i] = __builtin_bit_cast(uint16_t, h);
+        }
+      }
+      uint16_t* dstp = a.y + static_cast<int64_t>(m) * N + n;
+      if (n + 3 < N) {
+        *reinterpret_cast<u32x2*>(dstp) = *reinterpret_cast<u32x2*>(o);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n + i < N) dstp[i] = o[i];
+      }
+    }
+  }
+}
+
+}  // namespace gd
+}  // namespace hqq
+
+using namespace hqq;
+
+// y[M, N] = x[M, K] . Wd[N, K]^T (+ bias[N]); fp16 / bf16, fp32 accumulation, one rounding (+ one for the bias add).  K % 64 == 0, N % 4 == 0.
+extern "C" int hqq_hip_gemm_dense(const void* x, const void* Wd, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  clear_stale_error();
+  if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemm_dense: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!x || !Wd || !y || M < 1 || N < 1 || K < gd::BK || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) { set_error("hqq_hip_gemm_dense: bad arguments"); return HQQ_ERR_SHAPE; }
+  if (K % gd::BK || N % 4) { set_error("hqq_hip_gemm_dense: needs K %% 64 == 0 and N %% 4 == 0 (got N=%lld K=%lld)", (long long)N, (long long)K); return HQQ_ERR_UNSUPPORTED; }
+  if (!aligned16(x) || !aligned16(Wd) || !aligned16(y)) { set_error("hqq_hip_gemm_dense: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  gd::Args a;
+  a.x = static_cast<const uint16_t*>(x); a.w = static_cast<const uint16_t*>(Wd); a.bias = static_cast<const uint16_t*>(bias); a.y = static_cast<uint16_t*>(y);
+  a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K);
+  a.m_tiles = static_cast<int>((M + gd::BM - 1) / gd::BM);
+  a.n_tiles = static_cast<int>((N + gd::BN - 1) / gd::BN);
+  const int64_t blocks = static_cast<int64_t>(a.m_tiles) * a.n_tiles;
+  if (blocks > INT32_MAX) { set_error("hqq_hip_gemm_dense: grid too large"); return HQQ_ERR_SHAPE; }
+  constexpr int lds_bytes = 2 * gd::BUF;
+  static LdsRaised raised[2];
+  const void* kern = dtype == HQQ_BF16 ? reinterpret_cast<const void*>(&gd::dense_gemm_kernel<true>) : reinterpret_cast<const void*>(&gd::dense_gemm_kernel<false>);
+  if (const int rc = raise_lds_limit(raised[dtype == HQQ_BF16 ? 1 : 0], kern, lds_bytes, "hqq_hip_gemm_dense")) return rc;
+  if (dtype == HQQ_BF16) hipLaunchKernelGGL(gd::dense_gemm_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(gd::NT), lds_bytes, as_stream(stream), a);
+  else hipLaunchKernelGGL(gd::dense_gemm_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(gd::NT), lds_bytes, as_stream(stream), a);
+  return check_launch("hqq_hip_gemm_dense");
+}

@@ -391,7 +391,40 @@ def decode_covers(dtype, M, N, K, group_size, nbits) -> bool:
     return dtype == torch.float16 and (M <= 4 or K % 64 == 0)
 
 
-def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None, opts=None) -> Tensor:
+def gemm_dense(x: Tensor, W: Tensor, bias=None, out: Tensor | None = None) -> Tensor:
+    """HQQLinear.matmul on dequantised weights: x [*, K] @ W[N, K].T (+ bias) on the in-tree MFMA GEMM (csrc/gemm_dense.hip), fp16 / bf16"""
+    _dev(x, W, bias)
+    N, K = W.shape
+    if x.shape[-1] != K or x.dtype != W.dtype or (bias is not None and bias.dtype != W.dtype):
+        raise TypeError("hqq_amd: gemm_dense takes x [*, K], W [N, K] and bias of one compute dtype")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M > 0:
+        with torch.cuda.device(x.device):
+            rc = _C.lib().hqq_hip_gemm_dense(_p(x2), _p(W.contiguous()), _p(bias), _p(out), M, N, K, _dt(x.dtype), _stream())
+        _C.check(rc, "hqq_hip_gemm_dense")
+    return out.reshape(*x.shape[:-1], N)
+
+
+def dense_covers(dtype, N, K) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and K % 64 == 0 and K >= 64 and N % 4 == 0
+
+
+def _compose(x, W, bias, out, N, K, library: bool) -> Tensor:
+    """the long-prompt route after the dequantise kernel: the in-tree MFMA GEMM, or (library=True, or a shape it does not cover) a library GEMM"""
+    if not library and dense_covers(x.dtype, N, K):
+        return gemm_dense(x, W, bias, out=None if out is None else out.reshape(-1, N))
+    y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
+    if bias is not None:
+        y += bias
+    return y.reshape(*x.shape[:-1], N)
+
+
+def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None, opts=None, library_gemm: bool = False) -> Tensor:
     """y = x @ dequantize(W_q)^T (+ bias).  M <= 16 (<= 64 where the skinny-GEMM kernel applies): weight-streaming decode kernels;
     larger M: fused MFMA dequant-GEMM, or — from LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.
     Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit beyond 4 rows,
@@ -406,10 +439,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
                 (fused is None and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(4, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):   # (asked as a 4-bit layer: same kernels, same plan)
             return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
         W = dequantize(w3s_unpack(W_q, N, K), scale.reshape(-1), zero.reshape(-1), N, K, group_size, 3, 1)
-        y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
-        if bias is not None:
-            y += bias
-        return y.reshape(*x.shape[:-1], N)
+        return _compose(x, W, bias, out, N, K, library_gemm)
     if fused is None:
         fused = skinny_covers(x.dtype, M, N, K, group_size, nbits) or \
             (decode_covers(x.dtype, M, N, K, group_size, nbits) and not (LIBRARY_GEMM_MIN_M and M >= LIBRARY_GEMM_MIN_M)) or \
@@ -418,10 +448,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
     if fused:
         return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
     W = dequantize(W_q, scale.reshape(-1), zero.reshape(-1), N, K, group_size, nbits, 1)
-    y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
-    if bias is not None:
-        y += bias
-    return y.reshape(*x.shape[:-1], N)
+    return _compose(x, W, bias, out, N, K, library_gemm)
 
 
 def quantize(W: Tensor, nbits=4, group_size: int = 64, round_zero: bool = False, optimize: bool = True,

@@ -199,6 +199,11 @@ int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, in
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* HQQLinear.matmul on already dequantised weights (quantize.py:880-882: torch.matmul(x, W.t())): y[M,N] = x[M,K] . Wd[N,K]^T (+ bias[N]),
+ * fp16 / bf16, fp32 accumulation, one rounding (+ one for the bias add).  The GEMM half of the long-prompt route: hqq_hip_dequantize rebuilds
+ * a layer's weights once, this contracts them with any number of tokens (csrc/gemm_dense.hip: 256 x 256 x 64 tiles, all operands by LDS-DMA,
+ * four phases per K tile).  K % 64 == 0, N % 4 == 0; no workspace. */
+int hqq_hip_gemm_dense(const void* x, const void* Wd, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
 /* hqq_hip_gemv for M it covers, hqq_hip_gemm otherwise; workspace: hqq_hip_forward_workspace_bytes with the same M */
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                     void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,

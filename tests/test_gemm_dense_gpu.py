@@ -1,0 +1,81 @@
+"""GPU tests of the in-tree dense MFMA GEMM (hqq_amd/csrc/gemm_dense.hip, hqq_hip_gemm_dense): HQQLinear.matmul on dequantised weights
+(hqq/core/quantize.py:880-882) without a library call — against the oracle's double-accumulated matmul and, bit for bit, against its own
+properties (row independence, one-hot probes), at ragged and full sizes, fp16 and bf16."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from hqq_amd import ops as o
+    assert o.is_available(), "libhqq_hip.so must load on the GPU box (no fallback)"
+    return o
+
+
+def raw16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (256, 256, 64), (300, 260, 128), (1000, 512, 4096), (2048, 4096, 1024), (257, 11008, 192), (8192, 256, 4096), (513, 1028, 2816)])
+def test_dense_gemm_vs_oracle(ops, oracle, dt, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(dt)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    bias = torch.randn(N, generator=g).to(dt) if M % 2 else None
+    code = 2 if dt == torch.bfloat16 else 1
+    if code == 2:
+        yo, _ = oracle.matmul(raw16(x), raw16(W), None if bias is None else raw16(bias), 2)
+        want = torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+    else:
+        yo, _ = oracle.matmul(x.numpy(), W.numpy(), None if bias is None else bias.numpy(), 1)
+        want = torch.from_numpy(yo.astype(np.float32))
+    y = ops.gemm_dense(x.cuda(), W.cuda(), None if bias is None else bias.cuda())
+    assert y.dtype == dt and tuple(y.shape) == (M, N)
+    if code == 2:
+        torch.testing.assert_close(y.float().cpu(), want, rtol=2.0 ** -7, atol=2e-3)
+    else:
+        torch.testing.assert_close(y.float().cpu(), want, rtol=1e-3, atol=1e-3)
+    # reproducible, and a row does not depend on the batch it is computed in (a tile's rows are independent)
+    assert torch.equal(y, ops.gemm_dense(x.cuda(), W.cuda(), None if bias is None else bias.cuda()))
+    k = min(M, 37)
+    assert torch.equal(y[:k], ops.gemm_dense(x[:k].cuda(), W.cuda(), None if bias is None else bias.cuda()))
+    # one-hot probes: y[m, :] = W[:, k] exactly (one product, no rounding before the output's)
+    ks = sorted({0, K - 1, (3 * K) // 7, 63, 64 % K, K // 2 + 5})
+    e = torch.zeros(len(ks), K, dtype=dt, device="cuda")
+    for r, kk in enumerate(ks): e[r, kk] = 1.0
+    ye = ops.gemm_dense(e, W.cuda())
+    for r, kk in enumerate(ks):
+        assert torch.equal(ye[r], W[:, kk].cuda()), f"column {kk}"
+
+
+@pytest.mark.parametrize("nbits", [4, 2, 8])
+def test_long_prompt_forward_takes_the_in_tree_gemm_and_matches_the_oracle(ops, oracle, nbits):
+    """ops.forward beyond the fused kernels' range: hqq_hip_dequantize + hqq_hip_gemm_dense (no torch.matmul) == the oracle on a row sample,
+    and within the forward tolerance of the library composition"""
+    N, K, M = 512, 1024, 2048
+    g = torch.Generator().manual_seed(nbits)
+    U = torch.randint(0, 2 ** nbits, (N * K // 64, 64), generator=g, dtype=torch.uint8)
+    s = (torch.rand(N * K // 64, 1, generator=g) * 0.004 + 0.001).half()
+    z = (torch.rand(N * K // 64, 1, generator=g) * (2 ** nbits - 1)).half()
+    P = oracle.pack(nbits, U.numpy())
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, 64, 1)
+    x = torch.randn(M, K, generator=g).half()
+    args = (torch.from_numpy(P).cuda(), s.cuda(), z.cuda(), None, N, K, 64, nbits)
+    real_matmul = torch.matmul
+    calls = []
+    torch.matmul = lambda *a, **k: (calls.append(1), real_matmul(*a, **k))[1]
+    try:
+        y = ops.forward(x.cuda(), *args)              # M = 2048: beyond gemm_pipe's preferred range -> dequantise + in-tree GEMM
+    finally:
+        torch.matmul = real_matmul
+    assert not calls, "ops.forward reached torch.matmul"
+    rows = [0, 1, 255, 256, 1000, 2047]
+    yo, _ = oracle.matmul(x[rows].numpy(), Wd, None, 1)
+    torch.testing.assert_close(y[rows].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3)
+    yl = ops.forward(x.cuda(), *args, library_gemm=True)
+    torch.testing.assert_close(y.float(), yl.float(), rtol=1e-3, atol=1e-3)
