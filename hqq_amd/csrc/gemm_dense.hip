@@ -16,13 +16,13 @@
 //            reads (lane (r, c): chunks 2c, 2c + 1 of row 16 j + r) are conflict-free.
 //   phases   a K tile's 64 MFMAs per wave go in four quadrants (token half x feature half of the wave's sub-tile), ordered so that the
 //            fragments a quadrant needs beyond its predecessor's are few and the last quadrant (X1, W1) leaves the registers of the next
-//            tile's first (X0, W0) free:   Q0 = (X0, W0)   Q1 = (X0, W1)   Q2 = (X1, W0)   Q3 = (X1, W1)
-//            phase q:  wait (the DMA pieces the NEXT quadrant reads have landed; this wave's previous reads have returned) -> barrier ->
-//                      issue the DMA pieces whose LDS rows the previous phase read last -> read the next quadrant's missing fragments ->
-//                      16 MFMAs of quadrant q (fragments read one phase ago).
+//            fragments a quadrant needs beyond its predecessor's are few:   Q0 = (X0, W0)   Q1 = (X0, W1)   Q2 = (X1, W1)   Q3 = (X1, W0)
+//            phase q:  LOAD part: wait (the DMA pieces the NEXT phase reads have landed) -> issue the DMA pieces whose LDS rows the
+//                      previous phase read -> read quadrant q's missing fragments -> reads returned | barrier | 16 MFMAs | barrier.
+//            The two waves of a SIMD run half a phase apart: one's LOAD part beside the other's MFMA part (the guide's ping-pong).
 //            A staging unit = the rows all waves read in one phase (X0: tokens 128 wm + [0, 64); W0: features 64 wn + [0, 32); ...): 16
-//            pieces, 2 per wave.  Every unit is issued 7 phases (1.75 K tiles) before it is read; 10-12 pieces stay in flight across
-//            every barrier (s_waitcnt vmcnt(10 / 12), never 0 in the loop).
+//            pieces, 2 per wave.  Every unit is issued 7 phases (1.75 K tiles) before it is read; 8-10 pieces stay in flight across
+//            every barrier (s_waitcnt vmcnt(8 / 10), never 0 in the loop).
 //   order    workgroup -> tile through an XCD-aware bijection (a band of token tiles x all feature tiles per XCD: its L2 holds the band's
 //            x rows and one pass over Wd).
 #include "hqq_common.h"
@@ -100,15 +100,16 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
     for (int p = 0; p < 2; ++p) dma16(src[u][p] + static_cast<int64_t>(kt) * BK, base + dst[u][p]);
   };
 
-  // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3; W (features, A operand): 4 tiles, sub-half = 2 ----
-  u32x4 xf[2][4][2], wf[2][2][2];   // [sub-half][tile][k half (chunks 2c, 2c + 1)]
+  // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3 — ONE register set, X1 replaces X0;
+  //      W (features, A operand): 4 tiles, sub-half = 2, both sub-halves live for the whole K tile ----
+  u32x4 xf[4][2], wf[2][2][2];   // [tile][k half (chunks 2c, 2c + 1)] ; [sub-half][tile][k half]
   auto read_x = [&](int s, int kt) {
     const uint8_t* base = lds + (kt & 1) * BUF;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int row = wm * 128 + (4 * s + t) * 16 + r;
-      xf[s][t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
-      xf[s][t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
+      xf[t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
+      xf[t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
     }
   };
   auto read_w = [&](int s, int kt) {
@@ -136,59 +137,70 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[xs][t][h], acc[2 * ws + f][4 * xs + t]);
+        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[t][h], acc[2 * ws + f][4 * xs + t]);
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: the issue order of the steady state (a unit goes out 7 phases before it is read), K tiles 0 and 1 and the first units of tile 2 ----
-  // steady-state issue sequence per wave: ... e0(t): X0(t+2), W0(t+2) | e1(t): W1(t+2) | e2(t): X1(t+2) | e3(t): - ...
+  // ---- prologue: K tiles 0 and 1 whole, drained once ----
   // (unit numbering: 0 = X0, 1 = W0, 2 = W1, 3 = X1)
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  read_x(0, 0);
-  read_w(0, 0);
 
-  // ---- main loop over K tiles.  Phase e_q(t): wait -> barrier -> stage -> read the next quadrant's missing fragments -> 16 MFMAs of Q_q(t).
-  //      reads:  e0: W1(t)   e1: X1(t)   e2: -   e3: X0(t + 1), W0(t + 1)
-  //      stage:  e0: X0, W0 (t + 2) [their rows were read in e3(t - 1)... of tile t, i.e. during the previous phase]   e1: W1(t + 2)   e2: X1(t + 2)
-  //      needs landed before its reads:  e0: W1(t) | e1: X1(t) | e3: X0, W0 (t + 1)
-  //      The counts below are the pieces this wave issued AFTER the ones it waits for (steady state); near the ends of the K range fewer
-  //      are behind them and the wait is for all (vmcnt(0)) ----
+  // ---- main loop.  A phase = a LOAD part (wait, stage, fragment reads, reads returned) | barrier | an MFMA part (16 MFMAs of the quadrant just
+  //      read) | barrier; quadrants  Q0 = (X0, W0)  Q1 = (X0, W1)  Q2 = (X1, W1)  Q3 = (X1, W0).
+  //        load part of phase:  0: reads X0, W0 (t)        1: stages X0, W0 (t + 2), reads W1 (t)     2: stages W1 (t + 2), reads X1 (t)     3: stages X1 (t + 2)
+  //      (a unit is staged in the phase after the one that read its rows: every wave's reads of a phase have returned before the barrier that
+  //       ends its load part.)  The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half
+  //      takes one barrier more up front, the other one more at the end): one's load part (100+ cycles per DMA piece, the LDS round trip)
+  //      sits beside the other's MFMA part instead of both idling the matrix pipe together.
+  //      Waits: a unit must have landed for EVERY wave before ANY wave reads it, and the other half reads half a phase away from this wave's
+  //      own wait — so a wave waits for a unit one phase BEFORE the phase that reads it (the guide's rule for staggered wave groups):
+  //        phase 3 waits X0, W0 (t + 1)   phase 0 waits W1 (t)   phase 1 waits X1 (t).   Counts = pieces this wave issued after the unit
+  //      (steady state; near the ends of the K range the wait is for everything).  Issue order: phase 1: 4 pieces, phase 2: 2, phase 3: 2 ----
+  if (wm == 1) __builtin_amdgcn_s_barrier();
   for (int t = 0; t < nk; ++t) {
-    const bool steady = t >= 2 && t + 2 < nk;   // (the first two tiles were drained in the prologue; the last two issue nothing new)
-    // e0
-    if (steady) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
-    read_w(1, t);
+    const bool steady = t >= 2 && t + 2 < nk;
+    // phase 0
+    if (steady) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1(t): read in phase 1
+    read_x(0, t);
+    read_w(0, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
     quadrant(0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    // e1
-    if (steady) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) stage(2, t + 2);
-    read_x(1, t);
+    // phase 1
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // X1(t): read in phase 2
+    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
+    read_w(1, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
     quadrant(0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    // e2
+    __builtin_amdgcn_s_barrier();
+    // phase 2
+    if (t + 2 < nk) stage(2, t + 2);
+    read_x(1, t);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) stage(3, t + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    quadrant(1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // e3
-    if (steady) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (t + 1 < nk) { read_x(0, t + 1); read_w(0, t + 1); }
-    __builtin_amdgcn_sched_barrier(0);
     quadrant(1, 1);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // phase 3
+    if (steady) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X0, W0 (t + 1): read in the next phase 0
+    if (t + 2 < nk) stage(3, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    quadrant(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: lane (column r = token inside tile tt, rows 4 c + i = features inside tile ft): 4 consecutive features of one token ----
   const bool bf = BF;
