@@ -17,12 +17,12 @@
 //   phases   a K tile's 64 MFMAs per wave go in four quadrants (token half x feature half of the wave's sub-tile), ordered so that the
 //            fragments a quadrant needs beyond its predecessor's are few and the last quadrant (X1, W1) leaves the registers of the next
 //            fragments a quadrant needs beyond its predecessor's are few:   Q0 = (X0, W0)   Q1 = (X0, W1)   Q2 = (X1, W1)   Q3 = (X1, W0)
-//            phase q:  LOAD part: wait (the DMA pieces the NEXT phase reads have landed) -> issue the DMA pieces whose LDS rows the
-//                      previous phase read -> read quadrant q's missing fragments -> reads returned | barrier | 16 MFMAs | barrier.
+//            phase q:  LOAD part: wait (the DMA pieces the NEXT phase reads have landed) -> issue the DMA pieces whose LDS rows were read two
+//                      phases ago -> issue the reads of quadrant q's missing fragments | barrier | reads returned, 16 MFMAs | barrier.
 //            The two waves of a SIMD run half a phase apart: one's LOAD part beside the other's MFMA part (the guide's ping-pong).
 //            A staging unit = the rows all waves read in one phase (X0: tokens 128 wm + [0, 64); W0: features 64 wn + [0, 32); ...): 16
-//            pieces, 2 per wave.  Every unit is issued 7 phases (1.75 K tiles) before it is read; 8-10 pieces stay in flight across
-//            every barrier (s_waitcnt vmcnt(8 / 10), never 0 in the loop).
+//            pieces, 2 per wave.  Every unit is issued 6-8 phases (1.5-2 K tiles) before it is read; 8 pieces stay in flight across
+//            every barrier (s_waitcnt vmcnt(8), never 0 in the loop).
 //   order    workgroup -> tile through an XCD-aware bijection (a band of token tiles x all feature tiles per XCD: its L2 holds the band's
 //            x rows and one pass over Wd).
 #include "hqq_common.h"
@@ -141,59 +141,65 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: K tiles 0 and 1 whole, drained once ----
+  // ---- prologue: K tile 0 whole and tile 1 without its X1 (staged in the loop's first phase), drained once ----
   // (unit numbering: 0 = X0, 1 = W0, 2 = W1, 3 = X1)
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-  if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1); }
+  if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // ---- main loop.  A phase = a LOAD part (wait, stage, fragment reads, reads returned) | barrier | an MFMA part (16 MFMAs of the quadrant just
-  //      read) | barrier; quadrants  Q0 = (X0, W0)  Q1 = (X0, W1)  Q2 = (X1, W1)  Q3 = (X1, W0).
-  //        load part of phase:  0: reads X0, W0 (t)        1: stages X0, W0 (t + 2), reads W1 (t)     2: stages W1 (t + 2), reads X1 (t)     3: stages X1 (t + 2)
-  //      (a unit is staged in the phase after the one that read its rows: every wave's reads of a phase have returned before the barrier that
-  //       ends its load part.)  The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half
-  //      takes one barrier more up front, the other one more at the end): one's load part (100+ cycles per DMA piece, the LDS round trip)
-  //      sits beside the other's MFMA part instead of both idling the matrix pipe together.
-  //      Waits: a unit must have landed for EVERY wave before ANY wave reads it, and the other half reads half a phase away from this wave's
-  //      own wait — so a wave waits for a unit one phase BEFORE the phase that reads it (the guide's rule for staggered wave groups):
-  //        phase 3 waits X0, W0 (t + 1)   phase 0 waits W1 (t)   phase 1 waits X1 (t).   Counts = pieces this wave issued after the unit
-  //      (steady state; near the ends of the K range the wait is for everything).  Issue order: phase 1: 4 pieces, phase 2: 2, phase 3: 2 ----
+  // ---- main loop.  A phase = a LOAD part (wait, stage, issue the fragment reads) | barrier | an MFMA part (reads returned, 16 MFMAs of the
+  //      quadrant just read) | barrier; quadrants  Q0 = (X0, W0)  Q1 = (X0, W1)  Q2 = (X1, W1)  Q3 = (X1, W0).
+  //        load part of phase:  0: stages X1 (t + 1), reads X0, W0 (t)    1: reads W1 (t)    2: stages X0, W0 (t + 2), reads X1 (t)    3: stages W1 (t + 2)
+  //      The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half takes one barrier more
+  //      up front, the other one more at the end): one's load part (60-185 cycles per DMA piece, the read issue) and the LDS round trip of its
+  //      reads sit beside the other's MFMA part instead of both idling the matrix pipe together (the guide's ping-pong).
+  //      Hazards with the halves half a phase apart:
+  //        write after read   a phase's reads have returned, for BOTH halves, two barriers after the later half issued them: a unit is staged
+  //                           TWO phases after the phase that read its rows (X0, W0: read in 0, staged in 2; W1: 1 -> 3; X1: 2 -> 0 of the next tile);
+  //        read after write   a unit must have landed for EVERY wave before ANY wave reads it, and the other half reads half a phase away from
+  //                           this wave's own wait: a wave waits for a unit one phase BEFORE the phase that reads it
+  //                           (phase 3: X0, W0 (t + 1); phase 0: W1 (t); phase 1: X1 (t)).
+  //      Counts = pieces this wave issued after the awaited unit (8 in every case, steady state; near the ends of the K range: everything).
+  //      Issue order per wave: phase 0: 2 pieces, phase 2: 4, phase 3: 2; a unit is issued 6-8 phases before it is read ----
   if (wm == 1) __builtin_amdgcn_s_barrier();
   for (int t = 0; t < nk; ++t) {
     const bool steady = t >= 2 && t + 2 < nk;
     // phase 0
-    if (steady) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1(t): read in phase 1
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1(t): read in phase 1
+    if (t + 1 < nk) stage(3, t + 1);
     read_x(0, t);
     read_w(0, t);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     quadrant(0, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // phase 1
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // X1(t): read in phase 2
-    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1(t): read in phase 2
     read_w(1, t);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     quadrant(0, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // phase 2
-    if (t + 2 < nk) stage(2, t + 2);
+    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
     read_x(1, t);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     quadrant(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // phase 3
-    if (steady) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X0, W0 (t + 1): read in the next phase 0
-    if (t + 2 < nk) stage(3, t + 2);
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X0, W0 (t + 1): read in the next phase 0
+    if (t + 2 < nk) stage(2, t + 2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     quadrant(1, 0);
