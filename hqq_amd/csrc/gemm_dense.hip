@@ -208,37 +208,68 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
-  // ---- epilogue: lane (column r = token inside tile tt, rows 4 c + i = features inside tile ft): 4 consecutive features of one token ----
+  // ---- epilogue.  A lane (r, c) ends with 4 consecutive features (16 ft + 4 c + i) of token r of every tile: 8 bytes, 32 contiguous bytes per
+  //      token over the four c lanes.  The 4 x 4 transpose (feature tile ft <-> lane group c) through v_permlane32_swap / v_permlane16_swap
+  //      gives the lane 16 consecutive features (16 c + 4 j + i) of its token: two 16-byte stores, 128 contiguous bytes per token row and
+  //      half as many store instructions (the store tail is issue-bound) ----
   const bool bf = BF;
+  const bool wide = (N & 7) == 0;
 #pragma unroll
-  for (int ft = 0; ft < 4; ++ft) {
-    const int n = n0 + wn * 64 + ft * 16 + 4 * c;
-    if (n >= N) continue;
+  for (int tt = 0; tt < 8; ++tt) {
+    const int m = m0 + wm * 128 + tt * 16 + r;
+    uint32_t o[4][2];   // [feature tile][features 4 c + {0, 1} | {2, 3}]
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const int m = m0 + wm * 128 + tt * 16 + r;
-      if (m >= M) continue;
-      uint16_t o[4];
+    for (int ft = 0; ft < 4; ++ft) {
+      const int n = n0 + wn * 64 + ft * 16 + 4 * c;
+      uint16_t e[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float v = acc[ft][tt][i];
         if (bf) {
           uint16_t h = f32_to_bf16(v);
           if (a.bias && n + i < N) h = f32_to_bf16(bf16_to_f32(h) + bf16_to_f32(a.bias[n + i]));
-          o[i] = h;
+          e[i] = h;
         } else {
           half_t h = static_cast<half_t>(v);
           if (a.bias && n + i < N) h = h + reinterpret_cast<const half_t*>(a.bias)[n + i];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-          o[i] = __builtin_bit_cast(uint16_t, h);
+          e[i] = __builtin_bit_cast(uint16_t, h);
         }
       }
-      uint16_t* dstp = a.y + static_cast<int64_t>(m) * N + n;
-      if (n + 3 < N) {
-        *reinterpret_cast<u32x2*>(dstp) = *reinterpret_cast<u32x2*>(o);
-      } else {
+      o[ft][0] = static_cast<uint32_t>(e[0]) | (static_cast<uint32_t>(e[1]) << 16);
+      o[ft][1] = static_cast<uint32_t>(e[2]) | (static_cast<uint32_t>(e[3]) << 16);
+    }
+    if (wide) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (n + i < N) dstp[i] = o[i];
+      for (int d = 0; d < 2; ++d) {
+#pragma unroll
+        for (int f0 = 0; f0 < 2; ++f0) {   // bit 1 of the tile index <-> bit 1 of the lane group
+          const auto sw = __builtin_amdgcn_permlane32_swap(o[f0][d], o[2 + f0][d], false, false);
+          o[f0][d] = sw[0]; o[2 + f0][d] = sw[1];
+        }
+#pragma unroll
+        for (int f1 = 0; f1 < 2; ++f1) {   // bit 0 <-> bit 0
+          const auto sw = __builtin_amdgcn_permlane16_swap(o[2 * f1][d], o[2 * f1 + 1][d], false, false);
+          o[2 * f1][d] = sw[0]; o[2 * f1 + 1][d] = sw[1];
+        }
+      }
+      // o[j][.] = features 16 c + 4 j + {0..3} of token r
+      const int n = n0 + wn * 64 + 16 * c;
+      if (m < M && n < N) {
+        uint16_t* dstp = a.y + static_cast<int64_t>(m) * N + n;
+        if (n + 15 < N) {
+          __builtin_nontemporal_store(u32x4{o[0][0], o[0][1], o[1][0], o[1][1]}, reinterpret_cast<u32x4*>(dstp));
+          __builtin_nontemporal_store(u32x4{o[2][0], o[2][1], o[3][0], o[3][1]}, reinterpret_cast<u32x4*>(dstp + 8));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + 4 * j + 3 < N) *reinterpret_cast<u32x2*>(dstp + 4 * j) = u32x2{o[j][0], o[j][1]};
+        }
+      }
+    } else if (m < M) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const int n = n0 + wn * 64 + ft * 16 + 4 * c;
+        if (n + 3 < N) *reinterpret_cast<u32x2*>(a.y + static_cast<int64_t>(m) * N + n) = u32x2{o[ft][0], o[ft][1]};   // N % 4 == 0: whole or nothing
       }
     }
   }

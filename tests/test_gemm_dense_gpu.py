@@ -21,7 +21,7 @@ def raw16(t):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (256, 256, 64), (300, 260, 128), (1000, 512, 4096), (2048, 4096, 1024), (257, 11008, 192), (8192, 256, 4096), (513, 1028, 2816)])
+@pytest.mark.parametrize("M,N,K", [(1, 4, 64), (256, 256, 64), (300, 260, 128), (1000, 512, 4096), (2048, 4096, 1024), (257, 11008, 192), (8192, 256, 4096), (513, 1028, 2816), (130, 264, 64), (64, 24, 128)])
 def test_dense_gemm_vs_oracle(ops, oracle, dt, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).to(dt)
