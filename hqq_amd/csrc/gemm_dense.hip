@@ -25,6 +25,8 @@
 //            every barrier (s_waitcnt vmcnt(8), never 0 in the loop).
 //   order    workgroup -> tile through an XCD-aware bijection (a band of token tiles x all feature tiles per XCD: its L2 holds the band's
 //            x rows and one pass over Wd).
+#include <type_traits>
+
 #include "hqq_common.h"
 
 namespace hqq {
@@ -72,53 +74,56 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
 
   // ---- DMA sources.  Staging unit u (0: X0, 1: W0, 2: W1, 3: X1), piece p (0, 1) of this wave: 8 rows x 128 bytes.
   //      Unit rows (workgroup tile): X0: 128 g + [0, 64), X1: 128 g + [64, 128), g = 0, 1;  W0: 64 g + [0, 32), W1: 64 g + [32, 64), g = 0..3.
-  //      Piece q = 2 wave + p of a unit (0..15) covers 8 consecutive rows of it ----
-  const uint16_t* src[4][2];
-  int dst[4][2];   // byte offset inside a buffer
+  //      Piece q = 2 wave + p of a unit (0..15) covers 8 consecutive rows of it, first row row0 (bit 3 of row0 = p in every unit).
+  //      Buffer loads: one descriptor per operand over the tile's valid rows (rows past the end of x / Wd read as zeros: no clamping, their
+  //      outputs are never stored), a per-lane offset that depends on p only (row inside the piece, swizzled chunk) and a wave-uniform
+  //      offset per (unit, piece) + 128 bytes per K tile ----
+  const int xrows = M - m0 < BM ? M - m0 : BM, wrows = N - n0 < BN ? N - n0 : BN;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x + static_cast<int64_t>(m0) * K), 0, xrows * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w + static_cast<int64_t>(n0) * K), 0, wrows * K * 2, 0x00020000);
+  int voff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) voff[p] = (lane >> 3) * K * 2 + (((lane & 7) ^ (((lane >> 4) & 1) | (p << 2))) << 4);   // chunk ^ swz(row0 + (lane >> 3))
+  int soff[4][2], dst[4][2];   // wave-uniform: byte offset of the piece's first row in the operand / inside an LDS buffer
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int q = 2 * wave + p, rr = 8 * q + (lane >> 3);          // row 0..127 inside the unit
+      const int q = 2 * wave + p;
       const bool is_x = (u == 0 || u == 3);
       const int sub = (u == 0 || u == 1) ? 0 : 1;
-      int row;   // row inside the workgroup's X / W tile
-      if (is_x) row = (rr >> 6) * 128 + sub * 64 + (rr & 63);
-      else row = (rr >> 5) * 64 + sub * 32 + (rr & 31);
-      const int pos = lane & 7, ch = pos ^ swz(row);
-      int g = (is_x ? m0 : n0) + row;
-      const int lim = is_x ? M : N;
-      g = g < lim ? g : lim - 1;                                        // rows past the end repeat the last one (their outputs are never stored)
-      src[u][p] = (is_x ? a.x : a.w) + static_cast<int64_t>(g) * K + ch * 8;
-      // the piece's 8 rows are consecutive in the tile (8 q never straddles a 32- or 64-row boundary): wave-uniform LDS base
       const int row0 = is_x ? (((8 * q) >> 6) * 128 + sub * 64 + ((8 * q) & 63)) : (((8 * q) >> 5) * 64 + sub * 32 + ((8 * q) & 31));
+      soff[u][p] = row0 * K * 2;
       dst[u][p] = (is_x ? 0 : XBYTES) + row0 * 128;
     }
   auto stage = [&](int u, int kt) {   // unit u of K tile kt (kt < nk) into buffer kt & 1
     uint8_t* base = lds + (kt & 1) * BUF;
+    const bool is_x = (u == 0 || u == 3);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) dma16(src[u][p] + static_cast<int64_t>(kt) * BK, base + dst[u][p]);
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_x ? rx : rw, (lds_t)(base + dst[u][p]), 16, voff[p], soff[u][p] + kt * (BK * 2), 0, 0);
   };
 
-  // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3 — ONE register set, X1 replaces X0;
-  //      W (features, A operand): 4 tiles, sub-half = 2, both sub-halves live for the whole K tile ----
-  u32x4 xf[4][2], wf[2][2][2];   // [tile][k half (chunks 2c, 2c + 1)] ; [sub-half][tile][k half]
+  // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3;
+  //      W (features, A operand): 4 tiles, sub-half = 2.  Both sub-halves of both operands have their own registers (96): the reads of a
+  //      quadrant are issued one phase ahead, under the MFMAs of the quadrant before it ----
+  u32x4 xf[2][4][2], wf[2][2][2];   // [sub-half][tile][k half (chunks 2c, 2c + 1)]
+  const int xrd = (wm * 128 + r) * 128, wrd = XBYTES + (wn * 64 + r) * 128;   // swz(row) = swz(r): tile bases are multiples of 16 rows
+  const int ch0 = ((2 * c) ^ swz(r)) << 4, ch1 = ((2 * c + 1) ^ swz(r)) << 4;
   auto read_x = [&](int s, int kt) {
-    const uint8_t* base = lds + (kt & 1) * BUF;
+    const uint8_t* base = lds + (kt & 1) * BUF + xrd;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int row = wm * 128 + (4 * s + t) * 16 + r;
-      xf[t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
-      xf[t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
+      xf[s][t][0] = *reinterpret_cast<const u32x4*>(base + (4 * s + t) * 2048 + ch0);
+      xf[s][t][1] = *reinterpret_cast<const u32x4*>(base + (4 * s + t) * 2048 + ch1);
     }
   };
   auto read_w = [&](int s, int kt) {
-    const uint8_t* base = lds + (kt & 1) * BUF + XBYTES;
+    const uint8_t* base = lds + (kt & 1) * BUF + wrd;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int row = wn * 64 + (2 * s + t) * 16 + r;
-      wf[s][t][0] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c) ^ swz(row)) << 4));
-      wf[s][t][1] = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * c + 1) ^ swz(row)) << 4));
+      wf[s][t][0] = *reinterpret_cast<const u32x4*>(base + (2 * s + t) * 2048 + ch0);
+      wf[s][t][1] = *reinterpret_cast<const u32x4*>(base + (2 * s + t) * 2048 + ch1);
     }
   };
   f32x4 acc[4][8];   // [feature tile][token tile]
@@ -137,74 +142,87 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[t][h], acc[2 * ws + f][4 * xs + t]);
+        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[xs][t][h], acc[2 * ws + f][4 * xs + t]);
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: K tile 0 whole and tile 1 without its X1 (staged in the loop's first phase), drained once ----
+  // ---- prologue: K tiles 0 and 1 whole, drained once; the fragments of the first quadrant ----
   // (unit numbering: 0 = X0, 1 = W0, 2 = W1, 3 = X1)
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-  if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); }
+  if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  read_x(0, 0);
+  read_w(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
-  // ---- main loop.  A phase = a LOAD part (wait, stage, issue the fragment reads) | barrier | an MFMA part (reads returned, 16 MFMAs of the
-  //      quadrant just read) | barrier; quadrants  Q0 = (X0, W0)  Q1 = (X0, W1)  Q2 = (X1, W1)  Q3 = (X1, W0).
-  //        load part of phase:  0: stages X1 (t + 1), reads X0, W0 (t)    1: reads W1 (t)    2: stages X0, W0 (t + 2), reads X1 (t)    3: stages W1 (t + 2)
-  //      The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half takes one barrier more
-  //      up front, the other one more at the end): one's load part (60-185 cycles per DMA piece, the read issue) and the LDS round trip of its
-  //      reads sit beside the other's MFMA part instead of both idling the matrix pipe together (the guide's ping-pong).
+  // ---- main loop.  A phase = a LOAD part (wait, stage one unit, issue the fragment reads of the NEXT quadrant) | barrier | an MFMA part
+  //      (16 MFMAs of this phase's quadrant, whose fragments were read a phase ago; then: this phase's reads have returned) | barrier.
+  //      Quadrants of K tile t, with A = t & 1 the W sub-half the tile starts with and B = 1 - A:
+  //            Q0 = (X0, W_A)   Q1 = (X0, W_B)   Q2 = (X1, W_B)   Q3 = (X1, W_A)           (the next tile starts with the sub-half this one ends
+  //      with being idle: consecutive quadrants share one operand, and the fragments a load part reads are never those its own MFMA part uses)
+  //        load part of phase   0: stages X0 (t + 2),  reads W_B (t)        1: stages W_A (t + 2), reads X1 (t)
+  //                             2: stages W_B (t + 2), reads X0 (t + 1)     3: stages X1 (t + 2),  reads W_B (t + 1)
+  //      The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half takes one barrier
+  //      more up front, the other one more at the end): one's load part (60-185 cycles per DMA piece, the read issue) sits beside the
+  //      other's MFMA part (the guide's ping-pong), and no wave waits for an LDS round trip: reads are issued a phase before their use.
   //      Hazards with the halves half a phase apart:
-  //        write after read   a phase's reads have returned, for BOTH halves, two barriers after the later half issued them: a unit is staged
-  //                           TWO phases after the phase that read its rows (X0, W0: read in 0, staged in 2; W1: 1 -> 3; X1: 2 -> 0 of the next tile);
+  //        write after read   a load part's reads have returned when its phase ends (the lgkmcnt(0) after the MFMAs: free, the reads are
+  //                           ~300 cycles old by then); the later half's phase ends one barrier after the earlier half's next load part
+  //                           begins: a unit is staged TWO phases after the phase that read its rows (every unit above is);
   //        read after write   a unit must have landed for EVERY wave before ANY wave reads it, and the other half reads half a phase away from
-  //                           this wave's own wait: a wave waits for a unit one phase BEFORE the phase that reads it
-  //                           (phase 3: X0, W0 (t + 1); phase 0: W1 (t); phase 1: X1 (t)).
-  //      Counts = pieces this wave issued after the awaited unit (8 in every case, steady state; near the ends of the K range: everything).
-  //      Issue order per wave: phase 0: 2 pieces, phase 2: 4, phase 3: 2; a unit is issued 6-8 phases before it is read ----
-  if (wm == 1) __builtin_amdgcn_s_barrier();
-  for (int t = 0; t < nk; ++t) {
-    const bool steady = t >= 2 && t + 2 < nk;
+  //                           this wave's own wait: a wave waits, in a load part, for the unit the NEXT load part reads.
+  //      Every unit is issued 6 phases (1.5 K tiles) before it is read and 5 before its wait: 4 load parts x 2 pieces issued in between,
+  //      s_waitcnt vmcnt(8) in every load part (before its own stage), never 0 in the steady loop ----
+  auto tile = [&](auto parity, int t) {
+    constexpr int A = decltype(parity)::value, B = 1 - A;
+    const bool st = t + 2 < nk, nx = t + 1 < nk;
     // phase 0
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W1(t): read in phase 1
-    if (t + 1 < nk) stage(3, t + 1);
-    read_x(0, t);
-    read_w(0, t);
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(0, t + 2);
+    read_w(B, t);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    quadrant(0, A);
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    quadrant(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // phase 1
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X1(t): read in phase 2
-    read_w(1, t);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    quadrant(0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    // phase 2
-    if (t + 2 < nk) { stage(0, t + 2); stage(1, t + 2); }
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(1 + A, t + 2);
     read_x(1, t);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    quadrant(0, B);
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // phase 2
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(1 + B, t + 2);
+    if (nx) read_x(0, t + 1);
     __builtin_amdgcn_sched_barrier(0);
-    quadrant(1, 1);
+    __builtin_amdgcn_s_barrier();
+    quadrant(1, B);
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // phase 3
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X0, W0 (t + 1): read in the next phase 0
-    if (t + 2 < nk) stage(2, t + 2);
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(3, t + 2);
+    if (nx) read_w(B, t + 1);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-    quadrant(1, 0);
+    quadrant(1, A);
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  };
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nk; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
