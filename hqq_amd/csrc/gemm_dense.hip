@@ -96,12 +96,16 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
       soff[u][p] = row0 * K * 2;
       dst[u][p] = (is_x ? 0 : XBYTES) + row0 * 128;
     }
-  auto stage_piece = [&](int u, int kt, int p) {   // piece p of unit u of K tile kt (kt < nk) into buffer kt & 1
+  auto stage = [&](int u, int kt) {   // unit u of K tile kt (kt < nk) into buffer kt & 1
     uint8_t* base = lds + (kt & 1) * BUF;
     const bool is_x = (u == 0 || u == 3);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_x ? rx : rw, (lds_t)(base + dst[u][p]), 16, voff[p], soff[u][p] + kt * (BK * 2), 0, 0);
+#ifdef GD_LAB_SKIP_DMA   // lab (wrong results): 1 = no W pieces after the prologue, 2 = no pieces at all — what the memory path costs the loop
+    if (kt >= 2 && (GD_LAB_SKIP_DMA == 2 || !is_x)) return;
+#endif
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_x ? rx : rw, (lds_t)(base + dst[u][p]), 16, voff[p], soff[u][p] + kt * (BK * 2), 0, 0);
   };
-  auto stage = [&](int u, int kt) { stage_piece(u, kt, 0); stage_piece(u, kt, 1); };
 
   // ---- fragments: X (tokens, the MFMA's B operand): 8 tiles of 16 tokens, sub-half s = tiles 4 s .. 4 s + 3;
   //      W (features, A operand): 4 tiles, sub-half = 2.  Both sub-halves of both operands have their own registers (96): the reads of a
@@ -109,21 +113,27 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
   u32x4 xf[2][4][2], wf[2][2][2];   // [sub-half][tile][k half (chunks 2c, 2c + 1)]
   const int xrd = (wm * 128 + r) * 128, wrd = XBYTES + (wn * 64 + r) * 128;   // swz(row) = swz(r): tile bases are multiples of 16 rows
   const int ch0 = ((2 * c) ^ swz(r)) << 4, ch1 = ((2 * c + 1) ^ swz(r)) << 4;
-  auto read_x1 = [&](int s, int kt, int i) {   // read i (0..7) of X sub-half s: tile i / 2, k half i % 2
-    const uint8_t* base = lds + (kt & 1) * BUF + xrd;
-    xf[s][i >> 1][i & 1] = *reinterpret_cast<const u32x4*>(base + (4 * s + (i >> 1)) * 2048 + ((i & 1) ? ch1 : ch0));
-  };
-  auto read_w1 = [&](int s, int kt, int i) {   // read i (0..3) of W sub-half s
-    const uint8_t* base = lds + (kt & 1) * BUF + wrd;
-    wf[s][i >> 1][i & 1] = *reinterpret_cast<const u32x4*>(base + (2 * s + (i >> 1)) * 2048 + ((i & 1) ? ch1 : ch0));
-  };
   auto read_x = [&](int s, int kt) {
+#ifdef GD_LAB_SKIP_READS   // lab (wrong results): no fragment reads after the first tile
+    if (kt >= 1) return;
+#endif
+    const uint8_t* base = lds + (kt & 1) * BUF + xrd;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) read_x1(s, kt, i);
+    for (int t = 0; t < 4; ++t) {
+      xf[s][t][0] = *reinterpret_cast<const u32x4*>(base + (4 * s + t) * 2048 + ch0);
+      xf[s][t][1] = *reinterpret_cast<const u32x4*>(base + (4 * s + t) * 2048 + ch1);
+    }
   };
   auto read_w = [&](int s, int kt) {
+#ifdef GD_LAB_SKIP_READS
+    if (kt >= 1) return;
+#endif
+    const uint8_t* base = lds + (kt & 1) * BUF + wrd;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) read_w1(s, kt, i);
+    for (int t = 0; t < 2; ++t) {
+      wf[s][t][0] = *reinterpret_cast<const u32x4*>(base + (2 * s + t) * 2048 + ch0);
+      wf[s][t][1] = *reinterpret_cast<const u32x4*>(base + (2 * s + t) * 2048 + ch1);
+    }
   };
   f32x4 acc[4][8];   // [feature tile][token tile]
 #pragma unroll
@@ -134,12 +144,18 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
     if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, A), __builtin_bit_cast(b8, B), C, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A), __builtin_bit_cast(h8, B), C, 0, 0, 0);
   };
-  auto quad_mfma = [&](int xs, int ws, int j) {   // MFMA j (0..15) of a quadrant: k half j / 8, feature tile (j / 4) % 2, token tile j % 4 — an accumulator returns after 8
-    const int h = j >> 3, f = (j >> 2) & 1, t = j & 3;
-    acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[xs][t][h], acc[2 * ws + f][4 * xs + t]);
+  auto quadrant = [&](int xs, int ws) {   // 16 MFMAs: 2 feature tiles x 4 token tiles x 2 k halves
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[2 * ws + f][4 * xs + t] = mfma(wf[ws][f][h], xf[xs][t][h], acc[2 * ws + f][4 * xs + t]);
+    __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: K tiles 0 and 1 whole, drained once; the fragments of the first quadrant; X0 of tile 2 over the rows just read ----
+  // ---- prologue: K tiles 0 and 1 whole, drained once; the fragments of the first quadrant ----
   // (unit numbering: 0 = X0, 1 = W0, 2 = W1, 3 = X1)
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   if (nk > 1) { stage(0, 1); stage(1, 1); stage(2, 1); stage(3, 1); }
@@ -149,60 +165,75 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
   read_w(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (nk > 2) stage(0, 2);
 
-  // ---- main loop: four phases per K tile, ONE barrier per phase.  A phase = the 16 MFMAs of its quadrant, and woven between them (one
-  //      instruction per MFMA, pinned in source order: the matrix pipe takes 16 cycles per MFMA, the wave's issue slots in between are free)
-  //      the fragment reads of the NEXT quadrant and one staged unit; then: reads returned, the unit the next phase reads has landed | barrier.
-  //      No wave ever waits for an LDS round trip or sits in a load-only stretch: the two waves of a SIMD share the matrix pipe and each
-  //      fills the other's gaps (a DMA piece holds its wave's issue for ~60 cycles, four MFMAs of the other wave).
+  // ---- main loop.  A phase = a LOAD part (wait, stage one unit, issue the fragment reads of the NEXT quadrant) | barrier | an MFMA part
+  //      (16 MFMAs of this phase's quadrant, whose fragments were read a phase ago; then: this phase's reads have returned) | barrier.
   //      Quadrants of K tile t, with A = t & 1 the W sub-half the tile starts with and B = 1 - A:
-  //            Q0 = (X0, W_A)   Q1 = (X0, W_B)   Q2 = (X1, W_B)   Q3 = (X1, W_A)
-  //      (consecutive quadrants share one operand — also across tiles, the next tile starts with the sub-half this one ends with — and
-  //      the fragments a phase reads are never those its own MFMAs use)
-  //        phase   0: stages W_A (t + 2), reads W_B (t)        1: stages W_B (t + 2), reads X1 (t)
-  //                2: stages X1 (t + 2),  reads X0 (t + 1)     3: stages X0 (t + 3),  reads W_B (t + 1)
-  //      Hazards:
-  //        write after read   a phase's reads have returned before its barrier (lgkmcnt(0): free, they are a quadrant old): a unit is staged
-  //                           in the phase AFTER the one that read its rows (every unit above is);
-  //        read after write   a unit must have landed for EVERY wave before ANY wave reads it: a wave waits, before a phase's barrier, for
-  //                           the unit the NEXT phase reads.
-  //      Every unit is issued 7 phases (1.75 K tiles) before it is read; 6 phases x 2 pieces are issued between a unit and its wait:
-  //      s_waitcnt vmcnt(12) at the end of every phase, never 0 in the steady loop ----
-  // a phase: MFMA j, then (pinned behind it) read j of the next quadrant's fragments while there are any; the two DMA pieces in this wave's slots
-  auto phase = [&](auto steady, int xs, int ws, bool is_x, int rs, int rkt, bool rd, int u, int skt, bool sg) {
-    constexpr bool SD = decltype(steady)::value;
-    const int nr = is_x ? 8 : 4;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      quad_mfma(xs, ws, j);
-      if (j < nr && (SD || rd)) { if (is_x) read_x1(rs, rkt, j); else read_w1(rs, rkt, j); }
-      // the workgroup's 16 pieces of a phase, one per MFMA slot: wave w issues behind MFMAs w and w + 8 — the address path takes a piece per
-      // 16 cycles, a slot lasts 32 (two waves share the matrix pipe): no piece queues behind another (issued together they cost 60-185 cycles each)
-      if ((SD || sg) && (j & 7) == wave) stage_piece(u, skt, j >> 3);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (SD) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto tile = [&](auto parity, auto steady, int t) {   // steady: t + 3 < nk — everything below happens, branch-free
+  //            Q0 = (X0, W_A)   Q1 = (X0, W_B)   Q2 = (X1, W_B)   Q3 = (X1, W_A)           (the next tile starts with the sub-half this one ends
+  //      with being idle: consecutive quadrants share one operand, and the fragments a load part reads are never those its own MFMA part uses)
+  //        load part of phase   0: stages X0 (t + 2),  reads W_B (t)        1: stages W_A (t + 2), reads X1 (t)
+  //                             2: stages W_B (t + 2), reads X0 (t + 1)     3: stages X1 (t + 2),  reads W_B (t + 1)
+  //      The two waves of a SIMD — wave w and w + 4, token halves wm = 0 / 1 — run half a phase apart (the wm = 1 half takes one barrier
+  //      more up front, the other one more at the end): one's load part (60-185 cycles per DMA piece, the read issue) sits beside the
+  //      other's MFMA part (the guide's ping-pong), and no wave waits for an LDS round trip: reads are issued a phase before their use.
+  //      Hazards with the halves half a phase apart:
+  //        write after read   a load part's reads have returned when its phase ends (the lgkmcnt(0) after the MFMAs: free, the reads are
+  //                           ~300 cycles old by then); the later half's phase ends one barrier after the earlier half's next load part
+  //                           begins: a unit is staged TWO phases after the phase that read its rows (every unit above is);
+  //        read after write   a unit must have landed for EVERY wave before ANY wave reads it, and the other half reads half a phase away from
+  //                           this wave's own wait: a wave waits, in a load part, for the unit the NEXT load part reads.
+  //      Every unit is issued 6 phases (1.5 K tiles) before it is read and 5 before its wait: 4 load parts x 2 pieces issued in between,
+  //      s_waitcnt vmcnt(8) in every load part (before its own stage), never 0 in the steady loop ----
+  auto tile = [&](auto parity, int t) {
     constexpr int A = decltype(parity)::value, B = 1 - A;
-    const bool st = t + 2 < nk, st3 = t + 3 < nk, nx = t + 1 < nk;
-    phase(steady, 0, A, false, B, t, true, 1 + A, t + 2, st);
-    phase(steady, 0, B, true, 1, t, true, 1 + B, t + 2, st);
-    phase(steady, 1, B, true, 0, t + 1, nx, 3, t + 2, st);
-    phase(steady, 1, A, false, B, t + 1, nx, 0, t + 3, st3);
+    const bool st = t + 2 < nk, nx = t + 1 < nk;
+    // phase 0
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(0, t + 2);
+    read_w(B, t);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    quadrant(0, A);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // phase 1
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(1 + A, t + 2);
+    read_x(1, t);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    quadrant(0, B);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // phase 2
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(1 + B, t + 2);
+    if (nx) read_x(0, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    quadrant(1, B);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // phase 3
+    if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st) stage(3, t + 2);
+    if (nx) read_w(B, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    quadrant(1, A);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   };
-  int t = 0;
-  for (; t + 4 < nk; t += 2) {
-    tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
-    tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  for (int t = 0; t < nk; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
   }
-  for (; t < nk; t += 2) {
-    tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
-    if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
-  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue.  A lane (r, c) ends with 4 consecutive features (16 ft + 4 c + i) of token r of every tile: 8 bytes, 32 contiguous bytes per
   //      token over the four c lanes.  The 4 x 4 transpose (feature tile ft <-> lane group c) through v_permlane32_swap / v_permlane16_swap
@@ -298,4 +329,3 @@ extern "C" int hqq_hip_gemm_dense(const void* x, const void* Wd, const void* bia
   else hipLaunchKernelGGL(gd::dense_gemm_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(gd::NT), lds_bytes, as_stream(stream), a);
   return check_launch("hqq_hip_gemm_dense");
 }
-
