@@ -33,6 +33,9 @@ namespace hqq {
 namespace gd {
 
 constexpr int BM = 256, BN = 256, BK = 64;
+#ifndef GD_BAND
+#define GD_BAND 4
+#endif
 constexpr int NWAVES = 8, NT = NWAVES * 64;
 constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, BUF = XBYTES + WBYTES;   // 32 KiB + 32 KiB per K tile
 
@@ -66,8 +69,12 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
     const int nwg = static_cast<int>(gridDim.x), h = static_cast<int>(blockIdx.x), xcd = h & 7, idx = h >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    mt = L / a.n_tiles;
-    nt = L - mt * a.n_tiles;
+    // inside the run: bands of GD_BAND token tiles, walked down the band first — the 32 workgroups an XCD runs at a time cover 4 token tiles x 8
+    // feature tiles (12 operand slices per K tile through its L2) rather than 2 x 16 (18): +2-5 % (profiles/r04_dense_gemm_lab.txt)
+    const int band = L / (GD_BAND * a.n_tiles), idxb = L - band * GD_BAND * a.n_tiles;
+    const int gm = a.m_tiles - band * GD_BAND < GD_BAND ? a.m_tiles - band * GD_BAND : GD_BAND;
+    nt = idxb / gm;
+    mt = band * GD_BAND + (idxb - nt * gm);
   }
   const int M = a.M, N = a.N, K = a.K, nk = K / BK;
   const int m0 = mt * BM, n0 = nt * BN;
