@@ -327,7 +327,7 @@ extern "C" int hqq_hip_gemm_dense(const void* x, const void* Wd, const void* bia
   a.m_tiles = static_cast<int>((M + gd::BM - 1) / gd::BM);
   a.n_tiles = static_cast<int>((N + gd::BN - 1) / gd::BN);
   const int64_t blocks = static_cast<int64_t>(a.m_tiles) * a.n_tiles;
-  if (blocks > INT32_MAX) { set_error("hqq_hip_gemm_dense: grid too large"); return HQQ_ERR_SHAPE; }
+  if (blocks > INT32_MAX || K > (1 << 21)) { set_error("hqq_hip_gemm_dense: problem too large (tiles %lld, K %lld; the 32-bit buffer offsets hold 256 rows of K <= 2^21)", (long long)blocks, (long long)K); return HQQ_ERR_SHAPE; }
   constexpr int lds_bytes = 2 * gd::BUF;
   static LdsRaised raised[2];
   const void* kern = dtype == HQQ_BF16 ? reinterpret_cast<const void*>(&gd::dense_gemm_kernel<true>) : reinterpret_cast<const void*>(&gd::dense_gemm_kernel<false>);
