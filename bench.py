@@ -85,7 +85,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, 70B strong scaling: skip timing the unsharded stack on rank 0 alone")
-    ap.add_argument("--library-gemm", action="store_true", help="prefill: dequantise kernel + hipBLASLt GEMM instead of the fused MFMA kernel")
+    ap.add_argument("--prefill-route", default="auto", choices=["auto", "fused", "dense", "library"],
+                    help="prefill: auto = ops.forward's own choice per layer (the product path); fused = the fused MFMA dequant-GEMM (gemm_pipe.hip); "
+                         "dense = dequantise kernel + the in-tree MFMA GEMM (gemm_dense.hip); library = dequantise kernel + hipBLASLt (comparison only)")
+    ap.add_argument("--library-gemm", action="store_true", help="prefill: same as --prefill-route library")
+    ap.add_argument("--prefill-chunk", type=int, default=0, help="prefill: tokens per forward call (0 = all of them in one call: the weights are rebuilt once)")
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (bs=32, single layer, int3 / int2, prefill, quantise, end to end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -430,6 +434,10 @@ def main():
     if S > 1:
         out_local_s = [{g: [torch.empty_like(t) for t in ts] for g, ts in out_local.items()} for _ in range(S)]
 
+    route = "library" if a.library_gemm else a.prefill_route
+    PREFILL_CHUNK = a.prefill_chunk if a.prefill_chunk > 0 else max(M, 1)
+    route_kw = {"auto": {"fused": None}, "fused": {"fused": True}, "dense": {"fused": False}, "library": {"fused": False, "library_gemm": True}}[route]
+
     def step(bs_x=None, outs_by_grp=None, only_exchange=False):
         X = xs if bs_x is None else bs_x
         OL = out_local if outs_by_grp is None else outs_by_grp
@@ -457,9 +465,10 @@ def main():
                         ops.gemv_grouped(X[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits,
                                          outs=OL[grp], opts=group_opts(Ls))
                     else:
-                        for j, L in enumerate(Ls):
-                            ops.forward(X[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=OL[grp][j], fused=(not a.library_gemm),
-                                        opts=group_opts([L]))
+                        for j, L in enumerate(Ls):   # prefill: chunks of PREFILL_CHUNK tokens (configs[2]: 65,536 tokens = 8 x 8192)
+                            for c0 in range(0, M, PREFILL_CHUNK):
+                                ops.forward(X[L.K][c0:c0 + PREFILL_CHUNK], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=OL[grp][j][c0:c0 + PREFILL_CHUNK],
+                                            opts=group_opts([L]), **route_kw)
                 if world > 1 and bs_x is None:
                     exchange(grp)
 
@@ -621,16 +630,26 @@ def main():
                 if rank == 0:
                     out["single_gpu"] = single
     else:
+        Mc = min(M, PREFILL_CHUNK)
+        took_fused = [bool(ops._C.lib().hqq_hip_forward_prefers_fused(nbits, Mc, N_, K_, 64, 1)) for _, N_, K_ in BLOCK] if route == "auto" else []
+        route_txt, route_kernel = {
+            "fused": ("fused MFMA dequant-GEMM (hqq_hip_gemm: pipelined kernel)", "hqq::gemm_pipe_f16_kernel (LDS-DMA rings, weights rebuilt into MFMA fragments)"),
+            "dense": ("dequantise kernel + in-tree MFMA GEMM (hqq_hip_dequantize + hqq_hip_gemm_dense)", "hqq::gd::dense_gemm_kernel + hqq::dequantize"),
+            "library": ("dequantise kernel + library GEMM (comparison, not a product path)", "hqq::dequantize + hipBLASLt"),
+            "auto": (f"ops.forward's own route: {sum(took_fused)}/{len(BLOCK)} layers on the fused MFMA dequant-GEMM, the rest dequantise kernel + in-tree MFMA GEMM "
+                     "(no library call)", "hqq::gd::dense_gemm_kernel + hqq::dequantize" if not all(took_fused) else "hqq::gemm_pipe_f16_kernel"),
+        }[route]
         tfl = world * flops_per_step_rank / sec_per_step / 1e12
         out.update({
             "metric": f"int{nbits} gs=64 dequant-GEMM prefill throughput, Llama-2-7B block M={M} (tok/s; TFLOP/s alongside)",
             "value": round(M / sec_per_step, 2), "unit": "tok/s (one block's 7 linears)", "tflops": round(tfl, 2),
-            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens, fp16 " + ("dequantise kernel + library GEMM" if a.library_gemm else "fused MFMA dequant-GEMM (hqq_hip_gemm: pipelined kernel)"),
+            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens"
+                                   + (f" as {-(-M // PREFILL_CHUNK)} chunks of {PREFILL_CHUNK}" if M > PREFILL_CHUNK else "") + f", fp16, {route_txt}",
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather"},
         })
         ach = flops_per_step_rank / dev_sec_per_step / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "kernel": "hqq::dequantize + hipBLASLt" if a.library_gemm else "hqq::gemm_pipe_f16_kernel (LDS-DMA rings, weights rebuilt into MFMA fragments)"}
+                           "traffic": None, "kernel": route_kernel}
 
     # ---- the other shapes the metric names, same resident weights (N = 1, default decode only) ----
     if decode and world == 1 and not a.no_legs and not big and M == 1 and a.dtype == "f16" and S == 1 and nbits in (4, 2, 8):
@@ -742,12 +761,15 @@ def main():
                 yp = {N_: torch.empty(Mp, N_, device=dev, dtype=cd) for N_ in sorted({L.N for L in blocks[0].values()})}
                 flops_p = 2.0 * Mp * sum(N * K for _, N, K in BLOCK)
 
-                def block_prefill(fused):
+                def block_prefill(kw):
                     for L in blocks[0].values():
-                        ops.forward(xsp[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=yp[L.N], fused=fused, opts=group_opts([L]))
-                for nm, fused, kern in ((f"prefill: one 7B block, M={Mp}, fused MFMA dequant-GEMM (gemm_pipe.hip)", True, "hqq::gemm_pipe_f16_kernel"),
-                                        (f"prefill: one 7B block, M={Mp}, dequantise kernel + library GEMM (the composition)", False, "hqq::dequantize + hipBLASLt")):
-                    leg(nm, lambda f=fused: block_prefill(f), sum(gemv_bytes(N, K, nbits, Mp) for _, N, K in BLOCK), Mp, len(BLOCK), kern)
+                        ops.forward(xsp[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=yp[L.N], opts=group_opts([L]), **kw)
+                for nm, kw, kern in ((f"prefill: one 7B block, M={Mp}, fused MFMA dequant-GEMM (gemm_pipe.hip)", {"fused": True}, "hqq::gemm_pipe_f16_kernel"),
+                                     (f"prefill: one 7B block, M={Mp}, dequantise kernel + in-tree MFMA GEMM (gemm_dense.hip; ops.forward's route at this M)",
+                                      {"fused": None}, "hqq::dequantize + hqq::gd::dense_gemm_kernel"),
+                                     (f"prefill: one 7B block, M={Mp}, dequantise kernel + library GEMM (comparison only: no product path calls it)",
+                                      {"fused": False, "library_gemm": True}, "hqq::dequantize + hipBLASLt")):
+                    leg(nm, lambda k=kw: block_prefill(k), sum(gemv_bytes(N, K, nbits, Mp) for _, N, K in BLOCK), Mp, len(BLOCK), kern)
                     legs[-1]["bound"] = "mfma"
                     legs[-1]["tflops"] = round(flops_p / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
                     legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
