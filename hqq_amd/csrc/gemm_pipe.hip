@@ -652,12 +652,12 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
 // 640 rows everywhere (1.04-2.6x; below 512 the dequantise pass is as long as the GEMM), and up to 1024 rows when the plan fills the
 // chip in one round (192..256 workgroups: o, down 1.0-1.15x; the other shapes are within +-6 % there and go to the library).  Beyond,
 // the library's tile scheduler and hand-tuned loop are ahead (1.13-1.21 PFLOP/s here at 8192 rows against 1.23-1.45 for the composition).
+// Against the other prefill route, hqq_hip_dequantize + hqq_hip_gemm_dense (rebuild the weights once, stream them as fp16): this kernel rebuilds
+// every weight once per 256-token tile and is ahead while that is a few times — to ~2000 tokens on the 7B shapes, level at 3072, behind from
+// 4096 (profiles/r04_prefill_routes_int4.txt; the dense kernel's 256 x 256 tiles also leave CUs idle below ~2000 tokens)
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
-  if (M <= 640) return true;
-  if (M > 1024) return false;
-  const GpPlan p = gp_plan(nbits, M, N, K, 0);
-  const int64_t wgs = (static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full) * p.KS;   // (the last round of a hybrid plan)
-  return wgs >= 192 && wgs <= 256;
+  (void)nbits; (void)N; (void)K;
+  return M <= 2560;
 }
 
 void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]) {

@@ -357,13 +357,14 @@ def gemm(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, opts=None
     return _fwd("hqq_hip_gemm", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
 
 
-# Which path `forward` takes by the number of activation rows M (measured on MI355X, tools/sweep_prefill.py -> profiles/):
+# Which path `forward` takes by the number of activation rows M (measured on MI355X, tools/prefill_routes.py -> profiles/r04_prefill_routes_int4.txt):
 #   M <= 16 (<= 64 where skinny_covers): the weight-streaming decode kernels;
-#   65 <= M <= 640, to 1024 when the plan fills the chip in one round (hqq_hip_forward_prefers_fused): the pipelined split-K fused GEMM —
-#       1.0-2.6x the composition below, whose dequantise pass (11-36 us per layer) is as long as its GEMM at these sizes;
-#   otherwise: the HIP dequantise kernel + a plain library GEMM (hipBLASLt through torch.matmul) — one extra write + read of the
-#       fp16 weights (11-36 us), then 1.23-1.45 PFLOP/s at M = 8192 against 1.13-1.21 for the fused kernel.
-# `fused=True` forces the fused kernels for every M.  LIBRARY_GEMM_MIN_M applies to the decode-sized cases the skinny kernel does not cover.
+#   65 <= M <= 2560 (hqq_hip_forward_prefers_fused): the pipelined split-K fused MFMA dequant-GEMM (gemm_pipe.hip);
+#   beyond: the HIP dequantise kernel + the in-tree dense MFMA GEMM (hqq_hip_gemm_dense, gemm_dense.hip) — one extra write + read of the
+#       fp16 weights (11-36 us), then the weights are rebuilt once, not once per 256-token tile: 1.0-1.2 PFLOP/s at M = 8192 against
+#       0.87-0.95 for the fused kernel.  No library GEMM on any product path (`library_gemm=True` is the bench's comparison leg).
+# `fused=True` forces the fused kernels for every M.  LIBRARY_GEMM_MIN_M (a historical name: the composition's GEMM is the in-tree one) applies to
+# the decode-sized cases the skinny kernel does not cover.
 LIBRARY_GEMM_MIN_M = 17
 
 

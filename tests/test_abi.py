@@ -53,7 +53,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_gemm_workspace_bytes(4, 8192, 4096, 4096, 64, 1, 0) == 0
     assert L.hqq_hip_forward_workspace_bytes(4, 1, 4096, 4096, 64, 1, 0) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 1) == 1 and L.hqq_hip_forward_prefers_fused(4, 512, 4096, 4096, 64, 2) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 1025, 4096, 4096, 64, 1) == 0 and L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 32, 1) == 0
+    assert L.hqq_hip_forward_prefers_fused(4, 4096, 4096, 4096, 64, 1) == 0 and L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 32, 1) == 0
     assert L.hqq_hip_forward_prefers_fused(4, 32, 4096, 4096, 64, 1) == 1
     # the peer-memory exchange validates its arguments before it launches anything
     VP1, VP2 = (ctypes.c_void_p * 1)(16), (ctypes.c_void_p * 2)(16, 16)

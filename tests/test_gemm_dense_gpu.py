@@ -62,7 +62,7 @@ def test_dense_gemm_vs_oracle(ops, oracle, dt, M, N, K):
 def test_long_prompt_forward_takes_the_in_tree_gemm_and_matches_the_oracle(ops, oracle, nbits):
     """ops.forward beyond the fused kernels' range: hqq_hip_dequantize + hqq_hip_gemm_dense (no torch.matmul) == the oracle on a row sample,
     and within the forward tolerance of the library composition"""
-    N, K, M = 512, 1024, 2048
+    N, K, M = 512, 1024, 3072
     g = torch.Generator().manual_seed(nbits)
     U = torch.randint(0, 2 ** nbits, (N * K // 64, 64), generator=g, dtype=torch.uint8)
     s = (torch.rand(N * K // 64, 1, generator=g) * 0.004 + 0.001).half()
@@ -75,12 +75,35 @@ def test_long_prompt_forward_takes_the_in_tree_gemm_and_matches_the_oracle(ops, 
     calls = []
     torch.matmul = lambda *a, **k: (calls.append(1), real_matmul(*a, **k))[1]
     try:
-        y = ops.forward(x.cuda(), *args)              # M = 2048: beyond gemm_pipe's preferred range -> dequantise + in-tree GEMM
+        y = ops.forward(x.cuda(), *args)              # M = 3072: beyond gemm_pipe's preferred range -> dequantise + in-tree GEMM
     finally:
         torch.matmul = real_matmul
     assert not calls, "ops.forward reached torch.matmul"
-    rows = [0, 1, 255, 256, 1000, 2047]
+    assert not ops._C.lib().hqq_hip_forward_prefers_fused(nbits, M, N, K, 64, 1)
+    rows = [0, 1, 255, 256, 1000, 2047, 3071]
     yo, _ = oracle.matmul(x[rows].numpy(), Wd, None, 1)
     torch.testing.assert_close(y[rows].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3)
     yl = ops.forward(x.cuda(), *args, library_gemm=True)
     torch.testing.assert_close(y.float(), yl.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_configs2_prompt_of_65536_tokens_whole_and_in_chunks(ops, oracle):
+    """BASELINE.json configs[2]: 65,536 prefill tokens through a 4-bit 4096 x 4096 layer — in one forward call (weights rebuilt once) and as
+    8 chunks of 8192: identical bit for bit (rows are independent), and equal to the oracle on a row sample"""
+    N, K, M, nbits = 4096, 4096, 65536, 4
+    g = torch.Generator().manual_seed(65536)
+    U = torch.randint(0, 16, (N * K // 64, 64), generator=g, dtype=torch.uint8)
+    s = (torch.rand(N * K // 64, 1, generator=g) * 0.004 + 0.001).half()
+    z = (torch.rand(N * K // 64, 1, generator=g) * 15).half()
+    P = oracle.pack(nbits, U.numpy())
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, 64, 1)
+    x = torch.randn(M, K, generator=g).half().cuda()
+    args = (torch.from_numpy(P).cuda(), s.cuda(), z.cuda(), None, N, K, 64, nbits)
+    y = ops.forward(x, *args)
+    yc = torch.empty_like(y)
+    for c0 in range(0, M, 8192):
+        ops.forward(x[c0:c0 + 8192], *args, out=yc[c0:c0 + 8192])
+    assert torch.equal(y, yc)
+    rows = [0, 255, 256, 8191, 8192, 30000, 32767, 32768, 50001, 65279, 65280, 65535]
+    yo, _ = oracle.matmul(x[rows].cpu().numpy(), Wd, None, 1)
+    torch.testing.assert_close(y[rows].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=1e-3)

@@ -63,6 +63,32 @@ def test_pipelined_gemm_vs_oracle(ops, oracle, nbits, M, N, K, round_zero):
         assert torch.equal(Y, ops.gemm(e, Pd, sd, zd, None, N, K, 64, nbits, opts=0))
 
 
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+@pytest.mark.parametrize("N,K", [(11008, 4096), (4096, 11008)])
+def test_pipelined_gemm_8192_rows_full_size_layers_vs_oracle(ops, oracle, nbits, N, K):
+    """the kernel at BASELINE.json configs[2]'s chunk size (8192 tokens: full rounds of 256-token tiles, no split) on the 7B MLP shapes,
+    against the oracle on a row sample (the oracle's matmul over all 8192 rows would take minutes; rows are independent); one-hot rows:
+    single weight columns, exactly"""
+    M = 8192
+    U, s, z = _layer(N, K, nbits, N + K + nbits, True)
+    P = oracle.pack(nbits, U.numpy())
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, 64, 1)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(3)).half()
+    hot = [5, 4097, 8190]
+    hot_k = [0, K // 2 + 3, K - 1]
+    for r_, k_ in zip(hot, hot_k):
+        x[r_] = 0
+        x[r_, k_] = 1.0
+    sd, zd, Pd = s.cuda(), z.cuda(), dev(P)
+    opts = ops.OPT_META_SCALABLE if ops.meta_scalable(sd, zd, N, K, 64, nbits) else 0
+    y = ops.gemm(x.cuda(), Pd, sd, zd, None, N, K, 64, nbits, opts=opts)
+    rows = [0, 1, 127, 128, 255, 256, 2048, 4095, 4096, 6000, 8191]
+    yo, _ = oracle.matmul(x[rows].numpy(), Wd, None, 1)
+    torch.testing.assert_close(y[rows].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=2e-3)
+    for r_, k_ in zip(hot, hot_k):
+        assert np.array_equal(y[r_].cpu().numpy().view(np.uint16), np.ascontiguousarray(Wd[:, k_]).view(np.uint16)), f"row {r_}: column {k_} of W"
+
+
 @pytest.mark.parametrize("nbits", [4, 2, 8])
 def test_split_k_is_reproducible_and_order_is_fixed(ops, nbits):
     """K = 11008 (172 steps: uneven splits, every forced split count), bias, one-hot exactness for every split count; two runs of the
@@ -203,9 +229,9 @@ def test_routing_workspace_and_variants(ops):
     L = _C.lib()
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 64, 1) == 1
     assert L.hqq_hip_forward_prefers_fused(4, 640, 22016, 4096, 64, 1) == 1
-    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 1     # 256 workgroups: one full round
-    assert L.hqq_hip_forward_prefers_fused(4, 768, 11008, 4096, 64, 1) == 0     # 129 workgroups: half the chip idle, the library is ahead
-    assert L.hqq_hip_forward_prefers_fused(4, 1025, 4096, 4096, 64, 1) == 0     # long prompts: the composition is ahead
+    assert L.hqq_hip_forward_prefers_fused(4, 1024, 4096, 4096, 64, 1) == 1
+    assert L.hqq_hip_forward_prefers_fused(4, 2048, 11008, 4096, 64, 1) == 1    # ahead of dequantise + in-tree GEMM to ~2000 tokens
+    assert L.hqq_hip_forward_prefers_fused(4, 4096, 4096, 4096, 64, 1) == 0     # long prompts: rebuild the weights once, stream them as fp16
     assert L.hqq_hip_forward_prefers_fused(4, 128, 4096, 4096, 128, 1) == 0     # group_size 128: not this kernel
     assert L.hqq_hip_forward_prefers_fused(3, 128, 4096, 4096, 64, 1) == 0
     assert L.hqq_hip_forward_workspace_bytes(4, 128, 4096, 4096, 64, 1, 0) > 0 and L.hqq_hip_forward_workspace_bytes(4, 8192, 12288, 4096, 64, 1, 0) == 0

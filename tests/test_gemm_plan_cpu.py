@@ -58,4 +58,4 @@ def test_routing_hint_and_unsupported_shapes(L):
         assert L.hqq_hip_forward_prefers_fused(4, M, 4096, 4096, 64, 1) == 1
     assert L.hqq_hip_forward_prefers_fused(4, 32, 4096, 384, 64, 1) == 1        # 17..64 rows outside the skinny kernel: the pipelined GEMM
     assert L.hqq_hip_forward_prefers_fused(4, 32, 4096, 4096 + 64, 64, 1) == 0   # ... which needs K % 128 == 0
-    assert L.hqq_hip_forward_prefers_fused(4, 2048, 4096, 4096, 64, 1) == 0
+    assert L.hqq_hip_forward_prefers_fused(4, 2048, 4096, 4096, 64, 1) == 1 and L.hqq_hip_forward_prefers_fused(4, 3072, 4096, 4096, 64, 1) == 0
