@@ -681,22 +681,24 @@ def main():
         try:
             qres = []
             sv = _solver_valu()
-            for nm, N_, K_ in (("4096x4096", 4096, 4096), ("11008x4096", 11008, 4096), ("4096x11008", 4096, 11008)):
-                Wsrc = (torch.randn(N_, K_, device=dev, generator=gx) * 0.02).half()
-                ops.quantize(Wsrc, nbits=nbits, group_size=64, round_zero=(nbits == 4))
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    _, _, _, info = ops.quantize(Wsrc, nbits=nbits, group_size=64, round_zero=(nbits == 4), return_info=True)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 3
-                its = int(info[0].item())
-                qres.append({"layer": nm, "ms": round(ms, 3), "iters_run": its, "G_element_iters_per_s": round(N_ * K_ * 20 / (ms * 1e-3) / 1e9, 1),
-                             "hbm_floor_ms": round((2 + nbits / 8) * N_ * K_ / (HBM_PEAK_GBS * 1e9) * 1e3, 4)})
-                if sv:   # the bound, stated: VALU issue (tools/solver_valu_count.py reads the instruction count off the ISA of this build)
-                    qres[-1]["valu_frac"] = round(qres[-1]["G_element_iters_per_s"] / sv["peak_G_element_iters_per_s"], 4)
+            for nb_q in [nbits] + [w for w in (4, 3, 2) if w != nbits]:   # the run's width first, then the other widths of BASELINE.json configs[3]
+                for nm, N_, K_ in (("4096x4096", 4096, 4096), ("11008x4096", 11008, 4096), ("4096x11008", 4096, 11008)):
+                    Wsrc = (torch.randn(N_, K_, device=dev, generator=gx) * 0.02).half()
+                    ops.quantize(Wsrc, nbits=nb_q, group_size=64, round_zero=(nb_q == 4))
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        _, _, _, info = ops.quantize(Wsrc, nbits=nb_q, group_size=64, round_zero=(nb_q == 4), return_info=True)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 3
+                    its = int(info[0].item())
+                    qres.append({"nbits": nb_q, "layer": nm, "ms": round(ms, 3), "iters_run": its, "G_element_iters_per_s": round(N_ * K_ * 20 / (ms * 1e-3) / 1e9, 1),
+                                 "hbm_floor_ms": round((2 + (4 if nb_q == 3 else nb_q) / 8) * N_ * K_ / (HBM_PEAK_GBS * 1e9) * 1e3, 4)})
+                    if sv:   # the bound, stated: VALU issue (tools/solver_valu_count.py reads the instruction count off the ISA of this build)
+                        qres[-1]["valu_frac"] = round(qres[-1]["G_element_iters_per_s"] / sv["peak_G_element_iters_per_s"], 4)
+                    del Wsrc
             out["quantize"] = {"layers": qres,
                                "roofline": None if not sv else {"bound": "valu", "unit": "G element-iterations/s", "peak": sv["peak_G_element_iters_per_s"],
                                                                 "valu_instr_per_element_iteration": sv["valu_instr_per_element_iteration"],

@@ -108,9 +108,11 @@ def _ws_serialise(key: int) -> None:
     may run concurrently: a call from another stream than the previous workspace user first waits for everything that stream has
     enqueued.  (Outside stream capture; inside a capture the launches of one capture are ordered by the capture itself unless the
     caller forks streams — then give each branch its own buffer through the C ABI.)"""
+    if torch.cuda.is_current_stream_capturing():
+        return   # nothing runs during a capture, and a capture stream must not become the "last user" an eager call later waits on
     cur = torch.cuda.current_stream(key)
     last = _ws_last_stream.get(key)
-    if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+    if last is not None and last != cur:
         cur.wait_stream(last)
     _ws_last_stream[key] = cur
 

@@ -171,20 +171,6 @@ def test_forward_golden(ops, name):
     want = cd_tensor(g["y_f16"], "f16").float()
     y = ops.gemv(x, Wq, s, z, b, N, K, gs, nbits)       # default mode: exact weights on the MFMA path
     torch.testing.assert_close(y.float(), want, rtol=1e-3, atol=1e-3)
-    ops.set_gemv_mode(ops.GEMV_FACTORED)
-    try:
-        yf = ops.gemv(x, Wq, s, z, b, N, K, gs, nbits)
-    finally:
-        ops.set_gemv_mode(ops.GEMV_EXACT)
-    if "edge" in name:
-        # adversarial fixture (|W| up to 40, K = 128, constant groups): the sum is carried by a handful of terms, so the
-        # two fp16 roundings the reference applies to every weight show up un-averaged.  The factored mode keeps
-        # (q - z) * s in fp32; both are correct evaluations of the same layer and differ by at most 2^-10 * sum_k |x_k w_k|.
-        Wd = cd_tensor(g["Wdeq_f16"], "f16").float()
-        bound = 2.0 ** -10 * (x.float().abs() @ Wd.abs().t()) + 1e-3 + 1e-3 * want.abs()
-        assert bool(((yf.float() - want).abs() <= bound).all())
-    else:
-        assert_forward_parity(yf, want, name + " (factored)")
     if (N // ops.PER[nbits]) % 4 == 0 and K % 64 == 0:
         y2 = ops.gemm(x, Wq, s, z, b, N, K, gs, nbits)
         torch.testing.assert_close(y2.float(), want, rtol=1e-3, atol=1e-3)
@@ -220,16 +206,6 @@ def test_gemv_vs_oracle(ops, oracle, nbits, M, NK):
     col = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0]
     Wdev = ops.dequantize(dev(P), s.cuda().reshape(-1), z.cuda().reshape(-1), N, K, gs, nbits)
     assert torch.equal(col, Wdev[:, k])
-    if M <= 8:
-        # factored mode (fp32 affine map, no per-weight fp16 rounding): stated tolerance + 1 ulp on the one-hot probe
-        ops.set_gemv_mode(ops.GEMV_FACTORED)
-        try:
-            yf = ops.gemv(x.cuda(), dev(P), s.cuda(), z.cuda(), None if bias is None else bias.cuda(), N, K, gs, nbits)
-            colf = ops.gemv(e, dev(P), s.cuda(), z.cuda(), None, N, K, gs, nbits)[0]
-        finally:
-            ops.set_gemv_mode(ops.GEMV_EXACT)
-        assert_forward_parity(yf, torch.from_numpy(yo.astype(np.float32)), "factored gemv vs oracle", slack=2.0)
-        assert max_ulp_f16(colf, Wdev[:, k]) <= 1
 
 
 @pytest.mark.parametrize("nbits", [8, 1])
@@ -517,8 +493,7 @@ def test_gemv_bf16_vs_oracle(ops, oracle, nbits, M, NK):
 
 
 @pytest.mark.parametrize("nbits", [4, 2])
-@pytest.mark.parametrize("mode", ["exact", "factored"])
-def test_gemv_grouped_equals_single_launches(ops, nbits, mode):
+def test_gemv_grouped_equals_single_launches(ops, nbits):
     """q|k|v-style horizontal fusion: one launch over layers of different N sharing x == the per-layer launches, bit for bit"""
     K, gs, M = 1024, 64, 3
     Ns = [512, 96, 40, 1024]
@@ -528,13 +503,9 @@ def test_gemv_grouped_equals_single_launches(ops, nbits, mode):
         b = torch.randn(N, generator=torch.Generator().manual_seed(i)).half().cuda() if i % 2 else None
         layers.append((ops.pack(nbits, U.cuda()), s.cuda(), z.cuda(), b, N))
     x = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).half().cuda()
-    ops.set_gemv_mode(ops.GEMV_FACTORED if mode == "factored" else ops.GEMV_EXACT)
-    try:
-        ys = ops.gemv_grouped(x, layers, K, gs, nbits)
-        for (Wq, s, z, b, N), y in zip(layers, ys):
-            assert torch.equal(y, ops.gemv(x, Wq, s, z, b, N, K, gs, nbits))
-    finally:
-        ops.set_gemv_mode(ops.GEMV_EXACT)
+    ys = ops.gemv_grouped(x, layers, K, gs, nbits)
+    for (Wq, s, z, b, N), y in zip(layers, ys):
+        assert torch.equal(y, ops.gemv(x, Wq, s, z, b, N, K, gs, nbits))
     with pytest.raises(ValueError):
         ops.gemv_grouped(x, layers + layers, K, gs, nbits)
 
