@@ -722,9 +722,10 @@ def main():
                 def stack128(fused):
                     for blk in blocks:
                         for L in blk.values():
-                            ops.forward(xs128[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=y128[L.N], fused=fused, opts=group_opts([L]))
+                            ops.forward(xs128[L.K], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=y128[L.N], fused=fused, opts=group_opts([L]),
+                                        library_gemm=not fused)
                 for nm, fused, kern in (("7b-stack bs=128, fused dequant-GEMM (one launch + split-K reduce per layer)", True, "hqq::gemm_pipe_f16_kernel"),
-                                        ("7b-stack bs=128, dequantise kernel + library GEMM (the composition)", False, "hqq::dequantize + hipBLASLt")):
+                                        ("7b-stack bs=128, dequantise kernel + library GEMM (comparison only: no product path calls it)", False, "hqq::dequantize + hipBLASLt")):
                     leg(nm, lambda f=fused: stack128(f), nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * len(BLOCK), kern)
                     legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
                     legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""The fused decode loop on a random Llama-shaped model with NB decoder blocks, T tokens, for rocprofv3 --kernel-trace (development aid; needs
+an MI355X): the kernel count per token / per decoder block comes from two runs that differ in T and in NB.   python tools/e2e_kernels.py NB T"""
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from transformers import LlamaConfig, LlamaForCausalLM  # noqa: E402
+
+from hqq_amd.core.quantize import BaseQuantizeConfig  # noqa: E402
+from hqq_amd.utils.generation import GraphedGreedyDecoder  # noqa: E402
+from hqq_amd.utils.model import quantize_model  # noqa: E402
+from hqq_amd.utils.patching import prepare_for_inference  # noqa: E402
+
+NB, T = int(sys.argv[1]), int(sys.argv[2])
+torch.manual_seed(0)
+cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=NB, num_attention_heads=32, num_key_value_heads=32, vocab_size=32000,
+                  max_position_embeddings=512, torch_dtype=torch.float16)
+model = LlamaForCausalLM(cfg).half().eval()
+quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+prepare_for_inference(model, backend="hip")
+dec = GraphedGreedyDecoder(model, max_cache_len=128)
+ids = torch.randint(0, 32000, (1, 16), device="cuda")
+out = dec.generate(ids, max_new_tokens=T)
+torch.cuda.synchronize()
+print("fused:", dec.fused, "tokens:", out.shape)
