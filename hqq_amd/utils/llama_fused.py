@@ -91,8 +91,12 @@ class FusedLlamaStep:
         self.h = torch.empty(1, self.H, dtype=torch.float16, device=dev)       # the residual stream
         self.xn = torch.empty(1, self.H, dtype=torch.float16, device=dev)      # its normalised copy, input of the next linears
         self.delta = torch.empty(1, self.H, dtype=torch.float16, device=dev)   # output of o / down, added by the next add_rmsnorm
-        self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.bool, device=dev)
+        # the causal mask of one query over the static cache, in the additive form SDPA turns a boolean mask into on every call
+        # (where(mask, 0, -inf) in the query dtype): built once per token here instead of once per decoder block inside the attention function
+        self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.float16, device=dev)
         self.ar = torch.arange(max_cache_len, device=dev)
+        self.zero = torch.zeros((), dtype=torch.float16, device=dev)
+        self.ninf = torch.full((), float("-inf"), dtype=torch.float16, device=dev)
 
     @staticmethod
     def _gopts(Ls) -> int:
@@ -107,7 +111,7 @@ class FusedLlamaStep:
         h.copy_(inner.embed_tokens(tok).view(1, self.H))
         cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))       # [1, 1, hd] each, the model's own rotary module
         cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
-        torch.le(self.ar, pos, out=self.mask.view(-1))                          # the causal mask of one query at `pos` over the static cache
+        torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
         delta = None
         for b in self.blocks:
             at = b["attn"]

@@ -18,11 +18,10 @@ def load(nb, t):
     return c
 a, b, d = load(2, 8), load(2, 24), load(4, 24)
 per_tok_2 = {k: (b[k] - a[k]) / 16 for k in b if b[k] != a[k]}
-per_tok_4 = {k: (d[k] - load(2, 24)[k]) for k in d}
-tot2 = sum(per_tok_2.values())
-print("kernels per decoded token, 2 decoder blocks:", tot2)
+per_tok_4 = {k: (d[k] - b[k]) / 24 for k in d if d[k] != b[k]}   # 2 more blocks: prefill + 24 tokens each pass through them (prefill: HF's own modules, counted in: upper bound)
+print("kernels per decoded token, 2 decoder blocks + embedding, final norm, lm_head, argmax:", sum(per_tok_2.values()))
 for k, v in sorted(per_tok_2.items(), key=lambda kv: -kv[1]): print(f"   {v:6.2f}  {k}")
-# per block: (4-block run - 2-block run) over 24 decode tokens (+ the prefill and warm-up passes, which the T difference above removes)
-tok4 = sum(d.values()); tok2 = sum(b.values())
-print("dispatches: 2 blocks x 24 tokens", tok2, "  4 blocks x 24 tokens", tok4)
+blk = {k: v / 2 for k, v in per_tok_4.items()}
+print("kernels per decoder block per token (4-block run minus 2-block run, / 2 blocks / 24 tokens; the prefill pass through the extra blocks is in: an upper bound):", round(sum(blk.values()), 2))
+for k, v in sorted(blk.items(), key=lambda kv: -kv[1]): print(f"   {v:6.2f}  {k}")
 PY
