@@ -711,6 +711,39 @@ def main():
                                "where it can matter), hbm_floor = one read of W + one write of W_q"}
         except Exception as e:
             out["quantize"] = {"error": repr(e)}
+        # the stand-alone bit-packing kernels (rows a5, a9, a10, a13), HBM-bound: 11008 x 4096 levels at every width
+        try:
+            bp = []
+            Nb, Kb = 11008, 4096
+            Rb = Nb * Kb // 64
+            for nb_q in (4, 3, 2):
+                U = torch.randint(0, 2 ** nb_q, (Rb, 64), device=dev, dtype=torch.uint8, generator=gx)
+                P = ops.pack(nb_q, U)
+                sc = (torch.rand(Rb, 1, device=dev, generator=gx) * 0.004 + 0.001).to(cd)
+                zc = (torch.rand(Rb, 1, device=dev, generator=gx) * (2 ** nb_q - 1)).to(cd)
+                pbytes = P.numel() * P.element_size()
+
+                def tm(fn, n=10):
+                    fn()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / n * 1e-3
+                for nm, fn, by in (("pack (uint8 levels -> reference container)", lambda: ops.pack(nb_q, U), Rb * 64 + pbytes),
+                                   ("unpack (-> uint8 levels)", lambda: ops.unpack(nb_q, P), pbytes + (P.shape[0] * ops.PER[nb_q]) * 64),
+                                   ("dequantize (-> fp16 [N, K])", lambda: ops.dequantize(P, sc.reshape(-1), zc.reshape(-1), Nb, Kb, 64, nb_q), pbytes + 4 * Rb + 2 * Nb * Kb)):
+                    sec = tm(fn)
+                    bp.append({"nbits": nb_q, "op": nm, "us": round(sec * 1e6, 1), "GB_s": round(by / sec / 1e9, 1), "roofline_frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4)})
+                del U, P, sc, zc
+            out["bitpack"] = {"layer": f"{Nb}x{Kb}, gs=64 ({Rb} groups)", "ops": bp,
+                              "note": "bytes = what the op must read + write once (output allocation by torch's caching allocator inside the timed call)"}
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["bitpack"] = {"error": repr(e)}
         # 128 rows through every layer of the stack (batched decode / speculative verification / short prompts): the pipelined split-K
         # fused GEMM (csrc/gemm_pipe.hip) against the alternative a caller has — dequantise kernel + library GEMM on the result
         if nbits in (8, 4, 2):

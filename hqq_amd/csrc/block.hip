@@ -8,6 +8,11 @@
 //   rope_cache    apply_rotary_pos_emb: (q * cos) + (rotate_half(q) * sin) with three fp16 roundings, k likewise, and the StaticCache
 //                 update (k_rot / v written at cache_position, read from device memory: graph-replay safe)
 //   silu_mul      LlamaMLP: act_fn(gate) * up — silu in fp32 (x / (1 + exp(-x))), rounded to fp16, then the fp16 product
+// and one that does NOT restate a kernel bit for bit (opt-in, FusedLlamaStep(attention="hip")):
+//   attn_decode   softmax(q K^T * scaling) V for ONE query per head over the static KV cache's first pos + 1 positions, fp32 scores / softmax /
+//                 accumulation, one fp16 rounding of the output: what F.scaled_dot_product_attention computes for a decode step, within
+//                 rounding of it (SDPA's flash kernel blocks the keys and rounds P to fp16; this one does neither) — 3-4 us instead of the
+//                 12-15 us the library's prefill-shaped kernel takes for a single query (profiles/r04_e2e_kernel_times.txt)
 // Compiled with -ffp-contract=off: a fused multiply-add would remove a rounding HF's separate ops make.
 #include "hqq_common.h"
 
@@ -108,6 +113,99 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict_
   *reinterpret_cast<u32x4*>(out + i) = ov;
 }
 
+// ---- decode attention: one workgroup of 512 threads per query head.  Phase 1: a LANE per key (its 2 HD bytes in 16-byte loads, q broadcast
+//      from LDS, v_dot2_f32_f16 into fp32), scores into LDS, workgroup maximum.  Phase 2: exp(s - max) in place, workgroup sum.  Phase 3: a wave
+//      per key (keys dealt round-robin to the 8 waves), a lane per pair of dims: o += p V[j]; the 8 partial vectors are added in wave order.
+//      Deterministic: no atomics, fixed orders.  Keys beyond pos are never read ----
+template <int HD>
+__global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc, const half_t* __restrict__ vc,
+                                                          const int64_t* __restrict__ pos, half_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [16] reduction scratch
+  half_t* qs = reinterpret_cast<half_t*>(smem + 64);            // [HD]
+  float* part = reinterpret_cast<float*>(smem + 64 + HD * 2);   // [8][HD]
+  float* sc = part + 8 * HD;                                    // [n] scores, then probabilities
+  const int h = blockIdx.x, kvh = h / (n_heads / n_kv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = static_cast<int>(pos[0]) + 1;
+  const half_t* K = kc + static_cast<int64_t>(kvh) * L * HD;
+  const half_t* V = vc + static_cast<int64_t>(kvh) * L * HD;
+  if (tid < HD / 8) reinterpret_cast<u32x4*>(qs)[tid] = reinterpret_cast<const u32x4*>(q + static_cast<int64_t>(h) * HD)[tid];
+  __syncthreads();
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  // phase 1
+  float mx = -INFINITY;
+  for (int j = tid; j < n; j += 512) {
+    const u32x4* kr = reinterpret_cast<const u32x4*>(K + static_cast<int64_t>(j) * HD);
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const u32x4 kv = kr[c];
+      const u32x4 qv = reinterpret_cast<const u32x4*>(qs)[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qv[e]), __builtin_bit_cast(h2, kv[e]), acc, false);
+    }
+    const float sv = acc * scaling;
+    sc[j] = sv;
+    mx = fmaxf(mx, sv);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) mx = fmaxf(mx, red[w]);
+  // phase 2
+  float sum = 0.f;
+  for (int j = tid; j < n; j += 512) {
+    const float pj = __expf(sc[j] - mx);
+    sc[j] = pj;
+    sum += pj;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) red[8 + wave] = sum;
+  __syncthreads();
+  sum = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  // phase 3: lane -> dims [DPL lane, DPL lane + DPL), DPL = HD / 64
+  constexpr int DPL = HD / 64;
+  float o[DPL];
+#pragma unroll
+  for (int d = 0; d < DPL; ++d) o[d] = 0.f;
+  int j = wave;
+  for (; j + 24 < n; j += 32) {   // four keys of this wave in flight
+    half_t v4[4][DPL];
+    float p4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const half_t* vr = V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) v4[u][d] = vr[d];
+      p4[u] = sc[j + 8 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], static_cast<float>(v4[u][d]), o[d]);
+  }
+  for (; j < n; j += 8) {
+    const half_t* vr = V + static_cast<int64_t>(j) * HD + DPL * lane;
+    const float pj = sc[j];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, static_cast<float>(vr[d]), o[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < DPL; ++d) part[wave * HD + DPL * lane + d] = o[d];
+  __syncthreads();
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += part[w * HD + tid];
+    out[static_cast<int64_t>(h) * HD + tid] = static_cast<half_t>(t / sum);
+  }
+}
+
 }  // namespace hqq
 
 using namespace hqq;
@@ -146,6 +244,36 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
   hipLaunchKernelGGL(silu_mul_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(gate),
                      static_cast<const half_t*>(up), static_cast<half_t*>(out), n);
   return check_launch("hqq_hip_silu_mul");
+}
+
+int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
+                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
+  clear_stale_error();
+  if (dtype != HQQ_F16) { set_error("hqq_hip_attn_decode: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!q || !k_cache || !v_cache || !pos_dev || !out || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads || cache_len < 1 || cache_len > 30000 || n_heads > INT32_MAX) {
+    set_error("hqq_hip_attn_decode: bad arguments (cache_len <= 30000, n_heads a multiple of n_kv_heads)");
+    return HQQ_ERR_SHAPE;
+  }
+  if (head_dim != 64 && head_dim != 128 && head_dim != 256) { set_error("hqq_hip_attn_decode: head_dim %lld not covered (64 / 128 / 256)", (long long)head_dim); return HQQ_ERR_UNSUPPORTED; }
+  if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) { set_error("hqq_hip_attn_decode: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  const int HD = static_cast<int>(head_dim);
+  const int lds = 64 + HD * 2 + 8 * HD * 4 + static_cast<int>(cache_len) * 4;
+  const dim3 grid(static_cast<unsigned>(n_heads)), block(512);
+  static LdsRaised raised[3];
+  constexpr int LDS_MAX = 64 + 256 * 2 + 8 * 256 * 4 + 30000 * 4;
+#define HQQ_ATTN_GO(HDV, IDX)                                                                                                              \
+  do {                                                                                                                                     \
+    if (lds > 48 * 1024)                                                                                                                   \
+      if (const int rc = raise_lds_limit(raised[IDX], reinterpret_cast<const void*>(&attn_decode_kernel<HDV>), LDS_MAX, "hqq_hip_attn_decode")) return rc; \
+    hipLaunchKernelGGL(attn_decode_kernel<HDV>, grid, block, lds, as_stream(stream), static_cast<const half_t*>(q), static_cast<const half_t*>(k_cache), \
+                       static_cast<const half_t*>(v_cache), pos_dev, static_cast<half_t*>(out), static_cast<int>(n_heads), static_cast<int>(n_kv_heads), \
+                       static_cast<int>(cache_len), scaling);                                                                              \
+  } while (0)
+  if (HD == 64) HQQ_ATTN_GO(64, 0);
+  else if (HD == 128) HQQ_ATTN_GO(128, 1);
+  else HQQ_ATTN_GO(256, 2);
+#undef HQQ_ATTN_GO
+  return check_launch("hqq_hip_attn_decode");
 }
 
 }  // extern "C"

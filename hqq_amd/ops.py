@@ -575,6 +575,18 @@ def rope_cache(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: T
     return q_out
 
 
+def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, pos: Tensor, out: Tensor, scaling: float) -> Tensor:
+    """one query per head against the static KV cache's first pos + 1 positions (fp16; within rounding of SDPA, not bit-identical):
+    q [n_heads, hd] (any view of n_heads * hd contiguous values), k_cache / v_cache [n_kv, cache_len, hd], pos int64[1] on the device, out [n_heads * hd]"""
+    _dev(q, k_cache, v_cache, pos, out)
+    n_kv, L, hd = k_cache.shape
+    n_heads = q.numel() // hd
+    with torch.cuda.device(q.device):
+        rc = _C.lib().hqq_hip_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(pos), _p(out), n_heads, n_kv, hd, L, float(scaling), _dt(q.dtype), _stream())
+    _C.check(rc, "hqq_hip_attn_decode")
+    return out
+
+
 def silu_mul(gate: Tensor, up: Tensor, out: Tensor | None = None) -> Tensor:
     """LlamaMLP's act_fn(gate) * up in one kernel (fp16)"""
     _dev(gate, up)

@@ -15,12 +15,13 @@ class GraphedGreedyDecoder:
     RMSNorm (+ the residual adds), rotary + KV-cache write and SiLU * up as one HIP kernel each around the grouped GEMVs, HF's own attention
     function on HF's cache: the same tokens in a third of the launches.  Any other model, or fused=False: the model's own forward."""
 
-    def __init__(self, model, max_cache_len: int = 512, fused: bool = True):
+    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa"):
         from transformers import StaticCache
         from . import llama_fused
         self.model = model.eval()
         self.fused = bool(fused) and llama_fused.supports(model)
         self._fused_mod = llama_fused
+        self.attention = attention   # "sdpa": HF's attention function (token-identical to model(...)); "hip": the decode-attention kernel (faster, within rounding)
         self.step = None
         self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
         self.max_cache_len = max_cache_len
@@ -47,7 +48,7 @@ class GraphedGreedyDecoder:
         self.tok = out.logits[:, -1].argmax(-1, keepdim=True)
         self.next_tok = torch.empty_like(self.tok)
         self.pos = torch.tensor([T], device=self.device)
-        self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len) if self.fused else None
+        self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention) if self.fused else None
         toks = [self.tok.clone()]
         self.graph = None
         for i in range(max_new_tokens - 1):

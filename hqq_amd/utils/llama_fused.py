@@ -54,7 +54,10 @@ def supports(model) -> bool:
 class FusedLlamaStep:
     """decode step t -> logits of token t + 1, on the model's own weights and an HF StaticCache that a prefill has filled"""
 
-    def __init__(self, model, cache, max_cache_len: int):
+    def __init__(self, model, cache, max_cache_len: int, attention: str = "sdpa"):
+        """attention: "sdpa" — HF's own attention function on the cache tensors (the step then emits the tokens `model(...)` would);
+        "hip" — csrc/block.hip's decode-attention kernel (one query per head, fp32 softmax): within rounding of SDPA, not bit-identical,
+        3-4 us instead of 12-15 per block"""
         from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
         from transformers.models.llama.modeling_llama import eager_attention_forward
         self.model = model
@@ -68,6 +71,12 @@ class FusedLlamaStep:
         self.H = cfg.hidden_size
         self.L = max_cache_len
         self.attn_fn = ALL_ATTENTION_FUNCTIONS.get_interface(cfg._attn_implementation, eager_attention_forward)
+        if attention not in ("sdpa", "hip"):
+            raise ValueError("attention: 'sdpa' or 'hip'")
+        if attention == "hip" and (self.hd not in (64, 128, 256) or getattr(cfg, "sliding_window", None) or getattr(cfg, "attn_logit_softcapping", None)
+                                   or max_cache_len > 30000):
+            raise ValueError("hqq_amd: the decode-attention kernel covers plain softmax attention with head_dim 64 / 128 / 256 and caches of <= 30000 positions")
+        self.attention = attention
         self.blocks = []
         dev = self.device
         for li, blk in enumerate(inner.layers):
@@ -91,6 +100,7 @@ class FusedLlamaStep:
         self.h = torch.empty(1, self.H, dtype=torch.float16, device=dev)       # the residual stream
         self.xn = torch.empty(1, self.H, dtype=torch.float16, device=dev)      # its normalised copy, input of the next linears
         self.delta = torch.empty(1, self.H, dtype=torch.float16, device=dev)   # output of o / down, added by the next add_rmsnorm
+        self.att = torch.empty(1, self.n_heads * self.hd, dtype=torch.float16, device=dev)   # attention output (attention="hip")
         # the causal mask of one query over the static cache, in the additive form SDPA turns a boolean mask into on every call
         # (where(mask, 0, -inf) in the query dtype): built once per token here instead of once per decoder block inside the attention function
         self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.float16, device=dev)
@@ -119,7 +129,10 @@ class FusedLlamaStep:
             K = self.H
             ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
             ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
-            att, _ = self.attn_fn(at, b["qr"], b["kc"].unsqueeze(0), b["vc"].unsqueeze(0), self.mask, dropout=0.0, scaling=at.scaling)
+            if self.attention == "hip":
+                att = ops.attn_decode(b["qr"], b["kc"], b["vc"], pos, self.att, at.scaling)
+            else:
+                att, _ = self.attn_fn(at, b["qr"], b["kc"].unsqueeze(0), b["vc"].unsqueeze(0), self.mask, dropout=0.0, scaling=at.scaling)
             o = b["o"]
             ops.gemv(att.reshape(1, -1), o.W_q, o.scale, o.zero, None, o.out_features, o.in_features, o.group_size, o.nbits, out=self.delta,
                      opts=ops.layer_opts(o.opts))

@@ -185,6 +185,16 @@ int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* 
                        void* v_cache, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, int dtype, void* stream);
 int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
 
+/* Decode attention for ONE query per head over a static KV cache (opt-in: hqq_amd.utils.llama_fused.FusedLlamaStep(attention="hip")).
+ * Replaces, in the reference's generate loop (hqq/utils/generation_hf.py:117-540), HF's call of F.scaled_dot_product_attention for a decode step:
+ *   out[h, :] = softmax_j(q[h, :] . k_cache[h / (n_heads / n_kv_heads), j, :] * scaling) . v_cache[..., j, :]   over j = 0 .. pos_dev[0]
+ * fp32 scores, softmax and accumulation, one fp16 rounding of the output: WITHIN ROUNDING of SDPA's result, not bit-identical to it (its flash
+ * kernel blocks the keys and rounds the probabilities to fp16) — which is why the default decode step keeps HF's attention function.
+ * q [n_heads, head_dim] (rotary already applied), k_cache / v_cache [n_kv_heads, cache_len, head_dim], out [n_heads, head_dim]; fp16;
+ * head_dim 64 / 128 / 256; cache_len <= 30000; pos_dev: the query's position in device memory (graph-replay safe). */
+int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
+                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
+
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */
 size_t hqq_hip_forward_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts);

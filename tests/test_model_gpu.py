@@ -207,3 +207,81 @@ def test_fused_decoder_emits_the_tokens_of_the_pytorch_backend(nbits):
     with torch.no_grad():
         hip_logits = model(want[:, :-1]).logits.float()
     torch.testing.assert_close(hip_logits, ref_logits, rtol=5e-3, atol=5e-3)
+
+
+def _toy_llama_hip(nbits):
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    model = _tiny_llama()
+    quantize_model(model, BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    return model
+
+
+@pytest.mark.parametrize("n_heads,n_kv,hd,L,pos", [(32, 32, 128, 256, 0), (32, 32, 128, 256, 17), (32, 32, 128, 256, 255), (32, 8, 128, 1024, 700),
+                                                  (16, 4, 64, 512, 511), (8, 8, 256, 300, 123), (64, 8, 128, 4096, 4000)])
+def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads, n_kv, hd, L, pos):
+    """hqq_hip_attn_decode (opt-in replacement of the SDPA call of a decode step): one query per head over the first pos + 1 cache positions —
+    against softmax attention in float64 on the same fp16 inputs (1e-3 + one fp16 ulp of the output) and against torch's SDPA with the additive
+    mask the fused step builds (2e-3: SDPA itself rounds the probabilities to fp16); positions beyond pos are NaN-poisoned and must not be read"""
+    from hqq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(n_heads * 1000 + pos)
+    q = torch.randn(n_heads, hd, device="cuda", generator=g).half()
+    kc = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    vc = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    kc[:, pos + 1:] = float("nan")
+    vc[:, pos + 1:] = float("nan")
+    p = torch.tensor([pos], device="cuda")
+    out = torch.full((n_heads * hd,), float("nan"), dtype=torch.float16, device="cuda")
+    scaling = hd ** -0.5
+    ops.attn_decode(q, kc, vc, p, out, scaling)
+    rep = n_heads // n_kv
+    kk = kc[:, :pos + 1].repeat_interleave(rep, 0).double()
+    vv = vc[:, :pos + 1].repeat_interleave(rep, 0).double()
+    sc = torch.einsum("hd,hjd->hj", q.double(), kk) * scaling
+    want = torch.einsum("hj,hjd->hd", torch.softmax(sc, -1), vv)
+    got = out.view(n_heads, hd).double()
+    assert torch.isfinite(got).all()
+    tol = 1e-3 + 1e-3 * want.abs() + want.abs() * 2.0 ** -10
+    assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+    mask = torch.zeros(1, 1, 1, L, dtype=torch.float16, device="cuda")
+    mask[..., pos + 1:] = float("-inf")
+    ks = torch.nan_to_num(kc, nan=0.0).unsqueeze(0)
+    vs = torch.nan_to_num(vc, nan=0.0).unsqueeze(0)
+    sd = torch.nn.functional.scaled_dot_product_attention(q.view(1, n_heads, 1, hd), ks, vs, attn_mask=mask, scale=scaling, enable_gqa=(rep > 1))
+    torch.testing.assert_close(out.view(n_heads, hd).float(), sd.view(n_heads, hd).float(), rtol=2e-3, atol=2e-3)
+    again = torch.empty_like(out)
+    ops.attn_decode(q, kc, vc, p, again, scaling)
+    assert torch.equal(out, again)
+
+
+def test_fused_decoder_with_the_decode_attention_kernel_stays_within_the_logit_tolerance():
+    """attention="hip": the step is no longer bit-chained to HF's SDPA — teacher-forced logits within 5e-3 of the sdpa step's, and on this seed
+    the 32 greedy tokens are the same"""
+    model = _toy_llama_hip(nbits=4)
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    ids = torch.randint(0, model.config.vocab_size, (1, 12), generator=torch.Generator().manual_seed(5)).cuda()
+    a = GraphedGreedyDecoder(model, max_cache_len=64, attention="sdpa").generate(ids, 32)
+    dec = GraphedGreedyDecoder(model, max_cache_len=64, attention="hip")
+    b = dec.generate(ids, 32)
+    assert dec.fused and dec.step.attention == "hip"
+    agree = int((a == b).all(dim=0).cumprod(0).sum())
+    assert agree >= ids.shape[1] + 8, f"only {agree - ids.shape[1]} decoded tokens agree"
+    # teacher forcing: the same token sequence through both steps, logits compared position by position
+    from transformers import StaticCache
+    from hqq_amd.utils.llama_fused import FusedLlamaStep
+    logits = {}
+    for mode in ("sdpa", "hip"):
+        cache = StaticCache(config=model.config, max_cache_len=64)
+        with torch.no_grad():
+            model(ids, past_key_values=cache, cache_position=torch.arange(ids.shape[1], device="cuda"), use_cache=True)
+        step = FusedLlamaStep(model, cache, 64, attention=mode)
+        rows = []
+        for t in range(16):
+            pos = torch.tensor([ids.shape[1] + t], device="cuda")
+            rows.append(step(a[:, ids.shape[1] + t:ids.shape[1] + t + 1], pos).float().clone())
+        logits[mode] = torch.cat(rows)
+    torch.testing.assert_close(logits["hip"], logits["sdpa"], rtol=5e-3, atol=5e-3)
