@@ -143,7 +143,10 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
       const u32x4 kv = kr[c];
       const u32x4 qv = reinterpret_cast<const u32x4*>(qs)[c];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qv[e]), __builtin_bit_cast(h2, kv[e]), acc, false);
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t qe = qv[e], ke = kv[e];   // (a bit_cast of an ext-vector ELEMENT reads element 0: copy to a scalar first)
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qe), __builtin_bit_cast(h2, ke), acc, false);
+      }
     }
     const float sv = acc * scaling;
     sc[j] = sv;
