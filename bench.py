@@ -854,6 +854,17 @@ def main():
                                              "rope_cache -> HF's attention function on the static cache -> o -> add_rmsnorm (residual add inside) -> gate|up (grouped GEMV) -> silu_mul -> down; "
                                              "csrc/block.hip restates the HF modules rounding for rounding; one captured hipGraph per token, argmax fed back on the device",
                                      "fused_step": bool(dec.fused)}
+                # the same loop with the decode-attention kernel in place of HF's SDPA call (opt-in: within rounding of SDPA, not bit-identical to it)
+                try:
+                    dec2 = GraphedGreedyDecoder(model, max_cache_len=256, attention="hip")
+                    r2 = dec2.benchmark(ids, new_tokens=64, warmup=8)
+                    out["end_to_end"]["with_decode_attention_kernel"] = {
+                        "tok_s": round(r2["tok_s"], 2), "ms_per_token": round(r2["ms_per_token"], 4), "linear_stack_share": round(lin_ms / r2["ms_per_token"], 3),
+                        "note": "GraphedGreedyDecoder(attention='hip'): hqq_hip_attn_decode (csrc/block.hip) instead of F.scaled_dot_product_attention in every block; "
+                                "teacher-forced logits within 5e-3 of the default step's (tests/test_model_gpu.py); the headline tok_s above is the token-identical default"}
+                    del dec2
+                except Exception as e:
+                    out["end_to_end"]["with_decode_attention_kernel"] = {"error": repr(e)}
                 del model, dec
                 torch.cuda.empty_cache()
             except Exception as e:
