@@ -117,30 +117,66 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict_
 //      from LDS, v_dot2_f32_f16 into fp32), scores into LDS, workgroup maximum.  Phase 2: exp(s - max) in place, workgroup sum.  Phase 3: a wave
 //      per key (keys dealt round-robin to the 8 waves), a lane per pair of dims: o += p V[j]; the 8 partial vectors are added in wave order.
 //      Deterministic: no atomics, fixed orders.  Keys beyond pos are never read ----
-template <int HD>
-__global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc, const half_t* __restrict__ vc,
-                                                          const int64_t* __restrict__ pos, half_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling) {
+//      ROPE = true (hqq_hip_rope_attn_decode): q, k, v are the RAW projections; the workgroup applies the rotary embedding to its query and to its
+//      KV head's new key itself (rope_cache_kernel's arithmetic, rounding for rounding), uses the new key / value from LDS for position pos — the
+//      cache is only read below pos, so no workgroup depends on another's write — and the first query head of each KV head writes them to the cache
+template <int HD, bool ROPE>
+__global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc_in, const half_t* __restrict__ vc_in,
+                                                          const int64_t* __restrict__ pos, half_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling,
+                                                          const half_t* __restrict__ k_raw, const half_t* __restrict__ v_raw, const half_t* __restrict__ cosv,
+                                                          const half_t* __restrict__ sinv, half_t* __restrict__ kc_out, half_t* __restrict__ vc_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [16] reduction scratch
-  half_t* qs = reinterpret_cast<half_t*>(smem + 64);            // [HD]
-  float* part = reinterpret_cast<float*>(smem + 64 + HD * 2);   // [8][HD]
+  half_t* qs = reinterpret_cast<half_t*>(smem + 64);            // [HD] the query; ROPE: + [HD] the new key, [HD] the new value
+  float* part = reinterpret_cast<float*>(smem + 64 + HD * 6);   // [8][HD]
   float* sc = part + 8 * HD;                                    // [n] scores, then probabilities
-  const int h = blockIdx.x, kvh = h / (n_heads / n_kv);
+  half_t* knew = qs + HD;
+  half_t* vnew = qs + 2 * HD;
+  const int h = blockIdx.x, rep = n_heads / n_kv, kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = static_cast<int>(pos[0]) + 1;
-  const half_t* K = kc + static_cast<int64_t>(kvh) * L * HD;
-  const half_t* V = vc + static_cast<int64_t>(kvh) * L * HD;
-  if (tid < HD / 8) reinterpret_cast<u32x4*>(qs)[tid] = reinterpret_cast<const u32x4*>(q + static_cast<int64_t>(h) * HD)[tid];
+  const int p0 = static_cast<int>(pos[0]);
+  const int n = p0 + 1;
+  const half_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
+  const half_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
+  if constexpr (ROPE) {
+    // thread t < HD / 2: elements t and t + HD / 2 of the query; HD / 2 <= t < HD: of the new key; HD <= t < HD + HD / 8: a 16-byte chunk of the new value
+    constexpr int half = HD / 2;
+    if (tid < HD) {
+      const bool is_k = tid >= half;
+      const int i = is_k ? tid - half : tid;
+      const half_t* src = is_k ? k_raw + static_cast<int64_t>(kvh) * HD : q + static_cast<int64_t>(h) * HD;
+      const half_t x1 = src[i], x2 = src[i + half];
+      const half_t c1 = cosv[i], c2 = cosv[i + half], s1 = sinv[i], s2 = sinv[i + half];
+      const half_t o1 = (x1 * c1) + ((-x2) * s1);   // (q * cos) + (rotate_half(q) * sin): three fp16 roundings per element, as apply_rotary_pos_emb
+      const half_t o2 = (x2 * c2) + (x1 * s2);
+      half_t* dst = is_k ? knew : qs;
+      dst[i] = o1;
+      dst[i + half] = o2;
+      if (is_k && h % rep == 0) {
+        half_t* kd = kc_out + (static_cast<int64_t>(kvh) * L + p0) * HD;
+        kd[i] = o1;
+        kd[i + half] = o2;
+      }
+    } else if (tid < HD + HD / 8) {
+      const int c = tid - HD;
+      const u32x4 vv = reinterpret_cast<const u32x4*>(v_raw + static_cast<int64_t>(kvh) * HD)[c];
+      reinterpret_cast<u32x4*>(vnew)[c] = vv;
+      if (h % rep == 0) reinterpret_cast<u32x4*>(vc_out + (static_cast<int64_t>(kvh) * L + p0) * HD)[c] = vv;
+    }
+  } else {
+    if (tid < HD / 8) reinterpret_cast<u32x4*>(qs)[tid] = reinterpret_cast<const u32x4*>(q + static_cast<int64_t>(h) * HD)[tid];
+  }
   __syncthreads();
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   // phase 1
   float mx = -INFINITY;
   for (int j = tid; j < n; j += 512) {
     const u32x4* kr = reinterpret_cast<const u32x4*>(K + static_cast<int64_t>(j) * HD);
+    const bool fresh = ROPE && j == p0;   // the new key: from LDS, the cache row is being written by another workgroup
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < HD / 8; ++c) {
-      const u32x4 kv = kr[c];
+      const u32x4 kv = fresh ? reinterpret_cast<const u32x4*>(knew)[c] : kr[c];
       const u32x4 qv = reinterpret_cast<const u32x4*>(qs)[c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
     float p4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const half_t* vr = V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
+      const half_t* vr = (ROPE && j + 8 * u == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
 #pragma unroll
       for (int d = 0; d < DPL; ++d) v4[u][d] = vr[d];
       p4[u] = sc[j + 8 * u];
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
       for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], static_cast<float>(v4[u][d]), o[d]);
   }
   for (; j < n; j += 8) {
-    const half_t* vr = V + static_cast<int64_t>(j) * HD + DPL * lane;
+    const half_t* vr = (ROPE && j == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j) * HD + DPL * lane;
     const float pj = sc[j];
 #pragma unroll
     for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, static_cast<float>(vr[d]), o[d]);
@@ -249,34 +285,57 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
   return check_launch("hqq_hip_silu_mul");
 }
 
-int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
-                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
+static int attn_decode_run(const char* who, bool rope, const void* q, const void* k_raw, const void* v_raw, const void* cosv, const void* sinv, const int64_t* pos_dev,
+                           void* k_cache, void* v_cache, void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype,
+                           void* stream) {
   clear_stale_error();
-  if (dtype != HQQ_F16) { set_error("hqq_hip_attn_decode: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
-  if (!q || !k_cache || !v_cache || !pos_dev || !out || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads || cache_len < 1 || cache_len > 30000 || n_heads > INT32_MAX) {
-    set_error("hqq_hip_attn_decode: bad arguments (cache_len <= 30000, n_heads a multiple of n_kv_heads)");
+  if (dtype != HQQ_F16) { set_error("%s: fp16 only (dtype %d)", who, dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!q || !k_cache || !v_cache || !pos_dev || !out || (rope && (!k_raw || !v_raw || !cosv || !sinv)) || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads ||
+      cache_len < 1 || cache_len > 30000 || n_heads > INT32_MAX) {
+    set_error("%s: bad arguments (cache_len <= 30000, n_heads a multiple of n_kv_heads)", who);
     return HQQ_ERR_SHAPE;
   }
-  if (head_dim != 64 && head_dim != 128 && head_dim != 256) { set_error("hqq_hip_attn_decode: head_dim %lld not covered (64 / 128 / 256)", (long long)head_dim); return HQQ_ERR_UNSUPPORTED; }
-  if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out)) { set_error("hqq_hip_attn_decode: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  if (head_dim != 64 && head_dim != 128 && head_dim != 256) { set_error("%s: head_dim %lld not covered (64 / 128 / 256)", who, (long long)head_dim); return HQQ_ERR_UNSUPPORTED; }
+  if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out) || (rope && (!aligned16(k_raw) || !aligned16(v_raw)))) {
+    set_error("%s: pointers must be 16-byte aligned", who);
+    return HQQ_ERR_ALIGN;
+  }
   const int HD = static_cast<int>(head_dim);
-  const int lds = 64 + HD * 2 + 8 * HD * 4 + static_cast<int>(cache_len) * 4;
+  const int lds = 64 + HD * 6 + 8 * HD * 4 + static_cast<int>(cache_len) * 4;
   const dim3 grid(static_cast<unsigned>(n_heads)), block(512);
-  static LdsRaised raised[3];
-  constexpr int LDS_MAX = 64 + 256 * 2 + 8 * 256 * 4 + 30000 * 4;
-#define HQQ_ATTN_GO(HDV, IDX)                                                                                                              \
+  static LdsRaised raised[6];
+  constexpr int LDS_MAX = 64 + 256 * 6 + 8 * 256 * 4 + 30000 * 4;
+#define HQQ_ATTN_GO(HDV, RP, IDX)                                                                                                          \
   do {                                                                                                                                     \
     if (lds > 48 * 1024)                                                                                                                   \
-      if (const int rc = raise_lds_limit(raised[IDX], reinterpret_cast<const void*>(&attn_decode_kernel<HDV>), LDS_MAX, "hqq_hip_attn_decode")) return rc; \
-    hipLaunchKernelGGL(attn_decode_kernel<HDV>, grid, block, lds, as_stream(stream), static_cast<const half_t*>(q), static_cast<const half_t*>(k_cache), \
+      if (const int rc = raise_lds_limit(raised[IDX], reinterpret_cast<const void*>(&attn_decode_kernel<HDV, RP>), LDS_MAX, who)) return rc; \
+    hipLaunchKernelGGL((attn_decode_kernel<HDV, RP>), grid, block, lds, as_stream(stream), static_cast<const half_t*>(q), static_cast<const half_t*>(k_cache), \
                        static_cast<const half_t*>(v_cache), pos_dev, static_cast<half_t*>(out), static_cast<int>(n_heads), static_cast<int>(n_kv_heads), \
-                       static_cast<int>(cache_len), scaling);                                                                              \
+                       static_cast<int>(cache_len), scaling, static_cast<const half_t*>(k_raw), static_cast<const half_t*>(v_raw),          \
+                       static_cast<const half_t*>(cosv), static_cast<const half_t*>(sinv), static_cast<half_t*>(k_cache), static_cast<half_t*>(v_cache)); \
   } while (0)
-  if (HD == 64) HQQ_ATTN_GO(64, 0);
-  else if (HD == 128) HQQ_ATTN_GO(128, 1);
-  else HQQ_ATTN_GO(256, 2);
+  if (rope) {
+    if (HD == 64) HQQ_ATTN_GO(64, true, 0);
+    else if (HD == 128) HQQ_ATTN_GO(128, true, 1);
+    else HQQ_ATTN_GO(256, true, 2);
+  } else {
+    if (HD == 64) HQQ_ATTN_GO(64, false, 3);
+    else if (HD == 128) HQQ_ATTN_GO(128, false, 4);
+    else HQQ_ATTN_GO(256, false, 5);
+  }
 #undef HQQ_ATTN_GO
-  return check_launch("hqq_hip_attn_decode");
+  return check_launch(who);
+}
+
+int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
+                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
+  return attn_decode_run("hqq_hip_attn_decode", false, q, nullptr, nullptr, nullptr, nullptr, pos_dev, const_cast<void*>(k_cache), const_cast<void*>(v_cache), out,
+                         n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, stream);
+}
+
+int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache, void* out,
+                             int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
+  return attn_decode_run("hqq_hip_rope_attn_decode", true, q, k, v, cos, sin, pos_dev, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, stream);
 }
 
 }  // extern "C"

@@ -587,6 +587,19 @@ def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, pos: Tensor, out: T
     return out
 
 
+def rope_attn_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: Tensor, k_cache: Tensor, v_cache: Tensor, out: Tensor, scaling: float) -> Tensor:
+    """rope_cache + attn_decode in one launch: raw q / k / v projections in, rotary applied in the kernel, the new key / value used from on-chip
+    memory and written to the cache at `pos` for the following steps (the cache ends up bit-identical to rope_cache's)"""
+    _dev(q, k, v, cos, sin, pos, k_cache, v_cache, out)
+    n_kv, L, hd = k_cache.shape
+    n_heads = q.numel() // hd
+    with torch.cuda.device(q.device):
+        rc = _C.lib().hqq_hip_rope_attn_decode(_p(q), _p(k), _p(v), _p(cos), _p(sin), _p(pos), _p(k_cache), _p(v_cache), _p(out), n_heads, n_kv, hd, L,
+                                                float(scaling), _dt(q.dtype), _stream())
+    _C.check(rc, "hqq_hip_rope_attn_decode")
+    return out
+
+
 def silu_mul(gate: Tensor, up: Tensor, out: Tensor | None = None) -> Tensor:
     """LlamaMLP's act_fn(gate) * up in one kernel (fp16)"""
     _dev(gate, up)

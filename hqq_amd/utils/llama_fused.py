@@ -128,10 +128,10 @@ class FusedLlamaStep:
             ops.add_rmsnorm(h, delta, b["n1"].weight, b["n1"].variance_epsilon, out=self.xn)
             K = self.H
             ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
-            ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
-            if self.attention == "hip":
-                att = ops.attn_decode(b["qr"], b["kc"], b["vc"], pos, self.att, at.scaling)
+            if self.attention == "hip":   # rotary + cache write + attention: one launch
+                att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling)
             else:
+                ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
                 att, _ = self.attn_fn(at, b["qr"], b["kc"].unsqueeze(0), b["vc"].unsqueeze(0), self.mask, dropout=0.0, scaling=at.scaling)
             o = b["o"]
             ops.gemv(att.reshape(1, -1), o.W_q, o.scale, o.zero, None, o.out_features, o.in_features, o.group_size, o.nbits, out=self.delta,

@@ -194,6 +194,12 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
  * head_dim 64 / 128 / 256; cache_len <= 30000; pos_dev: the query's position in device memory (graph-replay safe). */
 int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
                         int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
+/* The same with hqq_hip_rope_cache folded in: q / k / v are the RAW projections ([n_heads, head_dim], [n_kv_heads, head_dim] twice), cos / sin
+ * [head_dim]; every workgroup rotates its query and its KV head's new key (hqq_hip_rope_cache's arithmetic, rounding for rounding), takes the new
+ * key / value from on-chip memory for position pos and reads the cache only below it; the new key / value are written to the cache (by one workgroup
+ * per KV head) for the following steps: the cache ends up bit-identical to what hqq_hip_rope_cache writes. */
+int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache,
+                             void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
 
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */

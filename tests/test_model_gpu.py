@@ -258,6 +258,37 @@ def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("n_heads,n_kv,hd,L,pos", [(32, 32, 128, 256, 0), (32, 32, 128, 256, 100), (32, 8, 128, 512, 511), (8, 2, 64, 128, 31), (4, 4, 256, 64, 9)])
+def test_rope_attn_decode_equals_rope_cache_then_attn_decode(n_heads, n_kv, hd, L, pos):
+    """the one-launch form (rotary + cache write + attention) against the two launches it replaces: output and both caches bit for bit"""
+    from hqq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(pos + hd)
+    q = torch.randn(1, n_heads * hd, device="cuda", generator=g).half()
+    k = torch.randn(1, n_kv * hd, device="cuda", generator=g).half()
+    v = torch.randn(1, n_kv * hd, device="cuda", generator=g).half()
+    ang = torch.rand(hd // 2, device="cuda", generator=g) * 6.28
+    cos = torch.cat([ang.cos(), ang.cos()]).half()
+    sin = torch.cat([ang.sin(), ang.sin()]).half()
+    kc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    vc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    kc0[:, pos:] = float("nan")   # position pos is written by the call; beyond it nothing may be read
+    vc0[:, pos:] = float("nan")
+    p = torch.tensor([pos], device="cuda")
+    scaling = hd ** -0.5
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    qr = torch.empty(1, n_heads, 1, hd, dtype=torch.float16, device="cuda")
+    ops.rope_cache(q, k, v, cos, sin, p, kc1, vc1, qr)
+    want = torch.empty(n_heads * hd, dtype=torch.float16, device="cuda")
+    ops.attn_decode(qr, kc1, vc1, p, want, scaling)
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    got = torch.empty_like(want)
+    ops.rope_attn_decode(q, k, v, cos, sin, p, kc2, vc2, got, scaling)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
+    assert torch.equal(kc2[:, :pos + 1], kc1[:, :pos + 1]) and torch.equal(vc2[:, :pos + 1], vc1[:, :pos + 1])
+    assert torch.isnan(kc2[:, pos + 1:]).all() and torch.isnan(vc2[:, pos + 1:]).all()
+
+
 def test_fused_decoder_with_the_decode_attention_kernel_stays_within_the_logit_tolerance():
     """attention="hip": the step is no longer bit-chained to HF's SDPA — teacher-forced logits within 5e-3 of the sdpa step's, and on this seed
     the 32 greedy tokens are the same"""
