@@ -860,7 +860,8 @@ def main():
                     r2 = dec2.benchmark(ids, new_tokens=64, warmup=8)
                     out["end_to_end"]["with_decode_attention_kernel"] = {
                         "tok_s": round(r2["tok_s"], 2), "ms_per_token": round(r2["ms_per_token"], 4), "linear_stack_share": round(lin_ms / r2["ms_per_token"], 3),
-                        "note": "GraphedGreedyDecoder(attention='hip'): hqq_hip_attn_decode (csrc/block.hip) instead of F.scaled_dot_product_attention in every block; "
+                        "note": "GraphedGreedyDecoder(attention='hip'): hqq_hip_rope_attn_decode (csrc/block.hip: rotary + cache write + one-query attention in one launch) instead of "
+                                "rope_cache + F.scaled_dot_product_attention in every block; "
                                 "teacher-forced logits within 5e-3 of the default step's (tests/test_model_gpu.py); the headline tok_s above is the token-identical default"}
                     del dec2
                 except Exception as e:

@@ -18,46 +18,94 @@
 
 namespace hqq {
 
-// ---- h (+= delta), xn = weight * fp16(float(h) * rsqrt(mean(float(h)^2) + eps)): one workgroup of 256 threads per row ----
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(half_t* __restrict__ h, const half_t* __restrict__ delta, const half_t* __restrict__ weight, float eps,
+// ---- h (+= delta), xn = weight * fp16(float(h) * rsqrt(mean(float(h)^2) + eps)): one workgroup of 512 threads per row.
+//      Rows of up to 512 * 8 * RPT elements stay in registers between the two passes (every load is issued before the reduction: the kernel is
+//      one memory round trip + one barrier long); longer rows take the generic two-pass path ----
+template <int RPT>   // 16-byte chunks per thread held in registers; 0: re-read
+__global__ __launch_bounds__(512) void add_rmsnorm_kernel(half_t* __restrict__ h, const half_t* __restrict__ delta, const half_t* __restrict__ weight, float eps,
                                                           half_t* __restrict__ xn, int H) {
-  __shared__ float part[4];
+  __shared__ float part[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   half_t* hr = h + static_cast<int64_t>(blockIdx.x) * H;
   const half_t* dr = delta ? delta + static_cast<int64_t>(blockIdx.x) * H : nullptr;
   half_t* xr = xn + static_cast<int64_t>(blockIdx.x) * H;
-  // 8 consecutive elements per thread and pass (16-byte accesses); H % 8 == 0
+  constexpr int NR = RPT > 0 ? RPT : 1;
+  u32x4 hv[NR], wv[NR];
   float sum = 0.f;
-  for (int i = tid * 8; i < H; i += 256 * 8) {
-    u32x4 hv = *reinterpret_cast<const u32x4*>(hr + i);
-    half_t* hp = reinterpret_cast<half_t*>(&hv);
-    if (dr) {
-      const u32x4 dv = *reinterpret_cast<const u32x4*>(dr + i);
-      const half_t* dp = reinterpret_cast<const half_t*>(&dv);
+  if constexpr (RPT > 0) {
+    u32x4 dv[NR];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hp[j] = hp[j] + dp[j];   // residual + hidden_states, one fp16 rounding
-      *reinterpret_cast<u32x4*>(hr + i) = hv;
+    for (int c = 0; c < NR; ++c) {
+      const int i = (c * 512 + tid) * 8;
+      if (i < H) {
+        hv[c] = *reinterpret_cast<const u32x4*>(hr + i);
+        if (dr) dv[c] = *reinterpret_cast<const u32x4*>(dr + i);
+        wv[c] = *reinterpret_cast<const u32x4*>(weight + i);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = static_cast<float>(hp[j]); sum += f * f; }
+    for (int c = 0; c < NR; ++c) {
+      const int i = (c * 512 + tid) * 8;
+      if (i < H) {
+        half_t* hp = reinterpret_cast<half_t*>(&hv[c]);
+        if (dr) {
+          const half_t* dp = reinterpret_cast<const half_t*>(&dv[c]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hp[j] = hp[j] + dp[j];   // residual + hidden_states, one fp16 rounding
+          *reinterpret_cast<u32x4*>(hr + i) = hv[c];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = static_cast<float>(hp[j]); sum += f * f; }
+      }
+    }
+  } else {
+    for (int i = tid * 8; i < H; i += 512 * 8) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(hr + i);
+      half_t* hp = reinterpret_cast<half_t*>(&v);
+      if (dr) {
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(dr + i);
+        const half_t* dp = reinterpret_cast<const half_t*>(&dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hp[j] = hp[j] + dp[j];
+        *reinterpret_cast<u32x4*>(hr + i) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = static_cast<float>(hp[j]); sum += f * f; }
+    }
   }
-  // wave sum (DPP-free: shuffles), then the four waves through LDS, fixed order
+  // wave sum (shuffles), then the eight waves through LDS, fixed order
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if (lane == 0) part[wave] = sum;
   __syncthreads();
-  const float total = (part[0] + part[1]) + (part[2] + part[3]);
+  const float total = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
   const float r = rsqrtf(total / static_cast<float>(H) + eps);
-  for (int i = tid * 8; i < H; i += 256 * 8) {
-    const u32x4 hv = *reinterpret_cast<const u32x4*>(hr + i);
-    const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + i);
-    const half_t* hp = reinterpret_cast<const half_t*>(&hv);
-    const half_t* wp = reinterpret_cast<const half_t*>(&wv);
-    u32x4 ov;
-    half_t* op = reinterpret_cast<half_t*>(&ov);
+  if constexpr (RPT > 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) op[j] = wp[j] * static_cast<half_t>(static_cast<float>(hp[j]) * r);
-    *reinterpret_cast<u32x4*>(xr + i) = ov;
+    for (int c = 0; c < NR; ++c) {
+      const int i = (c * 512 + tid) * 8;
+      if (i < H) {
+        const half_t* hp = reinterpret_cast<const half_t*>(&hv[c]);
+        const half_t* wp = reinterpret_cast<const half_t*>(&wv[c]);
+        u32x4 ov;
+        half_t* op = reinterpret_cast<half_t*>(&ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) op[j] = wp[j] * static_cast<half_t>(static_cast<float>(hp[j]) * r);
+        *reinterpret_cast<u32x4*>(xr + i) = ov;
+      }
+    }
+  } else {
+    for (int i = tid * 8; i < H; i += 512 * 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(hr + i);
+      const u32x4 w = *reinterpret_cast<const u32x4*>(weight + i);
+      const half_t* hp = reinterpret_cast<const half_t*>(&v);
+      const half_t* wp = reinterpret_cast<const half_t*>(&w);
+      u32x4 ov;
+      half_t* op = reinterpret_cast<half_t*>(&ov);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) op[j] = wp[j] * static_cast<half_t>(static_cast<float>(hp[j]) * r);
+      *reinterpret_cast<u32x4*>(xr + i) = ov;
+    }
   }
 }
 
@@ -256,8 +304,13 @@ int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float ep
   if (dtype != HQQ_F16) { set_error("hqq_hip_add_rmsnorm: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
   if (!h || !weight || !xn_out || rows < 1 || H < 8 || H % 8 || rows > INT32_MAX || H > INT32_MAX) { set_error("hqq_hip_add_rmsnorm: bad arguments (H must be a multiple of 8)"); return HQQ_ERR_SHAPE; }
   if (!aligned16(h) || !aligned16(weight) || !aligned16(xn_out) || (delta && !aligned16(delta))) { set_error("hqq_hip_add_rmsnorm: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, as_stream(stream), static_cast<half_t*>(h), static_cast<const half_t*>(delta),
-                     static_cast<const half_t*>(weight), eps, static_cast<half_t*>(xn_out), static_cast<int>(H));
+#define HQQ_NORM_GO(RPTV)                                                                                                                         \
+  hipLaunchKernelGGL(add_rmsnorm_kernel<RPTV>, dim3(static_cast<unsigned>(rows)), dim3(512), 0, as_stream(stream), static_cast<half_t*>(h), static_cast<const half_t*>(delta), \
+                     static_cast<const half_t*>(weight), eps, static_cast<half_t*>(xn_out), static_cast<int>(H))
+  if (H <= 512 * 8) HQQ_NORM_GO(1);
+  else if (H <= 512 * 8 * 2) HQQ_NORM_GO(2);
+  else HQQ_NORM_GO(0);
+#undef HQQ_NORM_GO
   return check_launch("hqq_hip_add_rmsnorm");
 }
 

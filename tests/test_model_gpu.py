@@ -146,6 +146,18 @@ def test_block_glue_kernels_restate_the_hf_modules():
     diff = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
     assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= 8, (int(diff.max()), int((diff > 0).sum()))
     assert torch.equal(ops.add_rmsnorm(h.clone(), None, norm.weight, norm.variance_epsilon)[0, :4].isfinite(), torch.ones(4, dtype=torch.bool, device="cuda"))
+    for H2, rows in ((8192, 3), (5120, 2), (16392, 2), (64, 5)):   # two chunks per thread in registers; a ragged last chunk; the re-reading path; a tiny row
+        hh = torch.randn(rows, H2, device="cuda", generator=g).half()
+        dd = (torch.randn(rows, H2, device="cuda", generator=g) * 0.3).half()
+        nn2 = LlamaRMSNorm(H2, eps=1e-6).cuda().half()
+        nn2.weight.data = (1 + 0.1 * torch.randn(H2, device="cuda", generator=g)).half()
+        w_h = hh + dd
+        w_x = nn2(w_h)
+        hh2 = hh.clone()
+        g_x = ops.add_rmsnorm(hh2, dd, nn2.weight, nn2.variance_epsilon)
+        assert torch.equal(hh2, w_h)
+        df = (g_x.view(torch.int16).int() - w_x.view(torch.int16).int()).abs()
+        assert int(df.max()) <= 1 and int((df > 0).sum()) <= 8 * rows, (H2, int(df.max()), int((df > 0).sum()))
     # rotary + cache write
     cfg = LlamaConfig(hidden_size=H, num_attention_heads=nh, num_key_value_heads=nkv, max_position_embeddings=2048)
     rot = LlamaRotaryEmbedding(cfg).cuda()
