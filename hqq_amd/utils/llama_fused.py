@@ -105,6 +105,14 @@ class FusedLlamaStep:
         # (where(mask, 0, -inf) in the query dtype): built once per token here instead of once per decoder block inside the attention function
         self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.float16, device=dev)
         self.ar = torch.arange(max_cache_len, device=dev)
+        # cos / sin of every cache position, from the model's own rotary module called once (elementwise in the position: the rows equal what a
+        # per-token call returns); rope types whose frequencies depend on the sequence length ("dynamic") keep the per-token call
+        self.cos_tab = self.sin_tab = None
+        if getattr(inner.rotary_emb, "rope_type", "default") in ("default", "linear", "llama3", "yarn", "longrope") and \
+                max_cache_len <= getattr(cfg, "max_position_embeddings", max_cache_len):
+            with torch.no_grad():
+                c, s_ = inner.rotary_emb(torch.empty(1, 1, self.H, dtype=torch.float16, device=dev), self.ar.view(1, -1))
+            self.cos_tab, self.sin_tab = c[0].contiguous(), s_[0].contiguous()   # [max_cache_len, hd]
         self.zero = torch.zeros((), dtype=torch.float16, device=dev)
         self.ninf = torch.full((), float("-inf"), dtype=torch.float16, device=dev)
 
@@ -119,9 +127,13 @@ class FusedLlamaStep:
         inner = self.inner
         h = self.h
         h.copy_(inner.embed_tokens(tok).view(1, self.H))
-        cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))       # [1, 1, hd] each, the model's own rotary module
-        cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
-        torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
+        if self.cos_tab is not None:
+            cos, sin = self.cos_tab.index_select(0, pos).view(-1), self.sin_tab.index_select(0, pos).view(-1)
+        else:
+            cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))   # [1, 1, hd] each, the model's own rotary module
+            cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
+        if self.attention != "hip":
+            torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
         delta = None
         for b in self.blocks:
             at = b["attn"]
