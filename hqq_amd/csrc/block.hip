@@ -293,17 +293,6 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
   }
 }
 
-// ---- pull a byte range through the memory-side cache: every 128-byte line read once, nothing kept (the xor can never equal the guard) ----
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, int64_t n16, uint32_t* __restrict__ sink) {
-  uint32_t acc = 0;
-  // one 16-byte load per 128-byte line and lane: 8 lanes would fetch a line together; here each lane takes a line of its own (stride 8 chunks)
-  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 8; i < n16; i += static_cast<int64_t>(gridDim.x) * 256 * 8) {
-    const u32x4 v = p[i];
-    acc ^= v.x;
-  }
-  if (acc == 0x9E3779B9u && sink) *sink = acc;   // keeps the loads alive; practically never taken, and harmless if it is
-}
-
 }  // namespace hqq
 
 using namespace hqq;
@@ -400,14 +389,6 @@ int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache,
 int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache, void* out,
                              int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
   return attn_decode_run("hqq_hip_rope_attn_decode", true, q, k, v, cos, sin, pos_dev, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, stream);
-}
-
-int hqq_hip_prefetch(const void* ptr, int64_t bytes, int64_t workgroups, void* sink4, void* stream) {
-  clear_stale_error();
-  if (!ptr || bytes < 16 || workgroups < 1 || workgroups > 65535 || !aligned16(ptr)) { set_error("hqq_hip_prefetch: bad arguments"); return HQQ_ERR_SHAPE; }
-  hipLaunchKernelGGL(prefetch_kernel, dim3(static_cast<unsigned>(workgroups)), dim3(256), 0, as_stream(stream), static_cast<const u32x4*>(ptr), bytes / 16,
-                     static_cast<uint32_t*>(sink4));
-  return check_launch("hqq_hip_prefetch");
 }
 
 }  // extern "C"

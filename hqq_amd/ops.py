@@ -600,14 +600,6 @@ def rope_attn_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, 
     return out
 
 
-def prefetch(t: Tensor, workgroups: int = 64) -> None:
-    """pull a tensor's bytes through the memory-side cache on the current stream (a hint: run it on a side stream ahead of the launch that streams `t`)"""
-    _dev(t)
-    with torch.cuda.device(t.device):
-        rc = _C.lib().hqq_hip_prefetch(_p(t), t.numel() * t.element_size(), int(workgroups), None, _stream())
-    _C.check(rc, "hqq_hip_prefetch")
-
-
 def silu_mul(gate: Tensor, up: Tensor, out: Tensor | None = None) -> Tensor:
     """LlamaMLP's act_fn(gate) * up in one kernel (fp16)"""
     _dev(gate, up)

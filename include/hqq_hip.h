@@ -198,11 +198,6 @@ int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache,
  * [head_dim]; every workgroup rotates its query and its KV head's new key (hqq_hip_rope_cache's arithmetic, rounding for rounding), takes the new
  * key / value from on-chip memory for position pos and reads the cache only below it; the new key / value are written to the cache (by one workgroup
  * per KV head) for the following steps: the cache ends up bit-identical to what hqq_hip_rope_cache writes. */
-/* Reads `bytes` at `ptr` once (one request per 128-byte line) and keeps nothing: pulls a layer's packed weights into the memory-side cache ahead
- * of the launch that streams them (a speed hint for callers that have idle HBM time in front of a GEMV; no reference counterpart).
- * sink4: 4 writable bytes or NULL. */
-int hqq_hip_prefetch(const void* ptr, int64_t bytes, int64_t workgroups, void* sink4, void* stream);
-
 int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache,
                              void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
 
