@@ -89,6 +89,7 @@ def parse():
                     help="prefill: auto = ops.forward's own choice per layer (the product path); fused = the fused MFMA dequant-GEMM (gemm_pipe.hip); "
                          "dense = dequantise kernel + the in-tree MFMA GEMM (gemm_dense.hip); library = dequantise kernel + hipBLASLt (comparison only)")
     ap.add_argument("--library-gemm", action="store_true", help="prefill: same as --prefill-route library")
+    ap.add_argument("--shapes", default="auto", choices=["auto", "7b", "70b"], help="prefill: the block's layer shapes (auto = Llama-2-7B; 70b = BASELINE configs[4]'s shapes on one GPU)")
     ap.add_argument("--prefill-chunk", type=int, default=0, help="prefill: tokens per forward call (0 = all of them in one call: the weights are rebuilt once)")
     ap.add_argument("--streams", type=int, default=1, help="study mode: deal the launches over this many parallel graph branches (ignores the decoder's dependency chain)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (bs=32, single layer, int3 / int2, prefill, quantise, end to end)")
@@ -326,7 +327,7 @@ def main():
     if workload == "auto":
         workload = "decode" if world == 1 else "decode70b"
     decode = workload in ("decode", "decode70b")
-    big = workload == "decode70b"
+    big = workload == "decode70b" or (workload == "prefill" and a.shapes == "70b")
     cd = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     assert a.dtype == "f16" or (decode and (a.bs >= 5 or nbits in (4, 2))), "bf16: decode only; bs <= 4 needs int4 / int2 (bs 5..64: int8/4/2)"
     M = a.bs if decode else a.prefill_tokens
@@ -641,9 +642,9 @@ def main():
         }[route]
         tfl = world * flops_per_step_rank / sec_per_step / 1e12
         out.update({
-            "metric": f"int{nbits} gs=64 dequant-GEMM prefill throughput, Llama-2-7B block M={M} (tok/s; TFLOP/s alongside)",
+            "metric": f"int{nbits} gs=64 dequant-GEMM prefill throughput, Llama-2-{'70B' if big else '7B'} block M={M} (tok/s; TFLOP/s alongside)",
             "value": round(M / sec_per_step, 2), "unit": "tok/s (one block's 7 linears)", "tflops": round(tfl, 2),
-            "config": {"workload": f"llama2-7b one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens"
+            "config": {"workload": f"llama2-{'70b' if big else '7b'} one block (q,k,v,o,gate,up,down), nbits={nbits} gs=64 axis=1, M={M} prefill tokens"
                                    + (f" as {-(-M // PREFILL_CHUNK)} chunks of {PREFILL_CHUNK}" if M > PREFILL_CHUNK else "") + f", fp16, {route_txt}",
                        "global_batch": M, "parallelism": "single-gpu" if world == 1 else f"column-shard x{world} + RCCL all-gather"},
         })

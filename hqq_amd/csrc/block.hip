@@ -1,34 +1,58 @@
-// block.hip — the steps either side of the fused GEMVs in a decode step, gfx950, fp16.
+// block.hip — the steps either side of the fused GEMVs in a decode step, gfx950, fp16 and bf16.
 //
 // The reference's headline number is the tok/s of its generate loop (hqq/utils/generation_hf.py:117-540, Readme.md:153): HF's decoder
 // block around HQQLinear.forward — RMSNorm, rotary embedding, KV-cache update, SiLU(gate) * up, the residual adds — is ~25 small
 // eager kernels per block, 79 % of a bs = 1 token once the linears are fused.  Three kernels replace twenty of them;
-// each restates the HF module's arithmetic rounding for rounding, so that the fused loop emits the same tokens:
-//   add_rmsnorm   h += delta (fp16 add: `residual + hidden_states`), then LlamaRMSNorm: fp32 x * rsqrt(mean(x^2) + eps) -> fp16 -> weight * (fp16 mul)
-//   rope_cache    apply_rotary_pos_emb: (q * cos) + (rotate_half(q) * sin) with three fp16 roundings, k likewise, and the StaticCache
+// each restates the HF module's arithmetic rounding for rounding, so that the fused loop emits the same tokens (T = the model's dtype):
+//   add_rmsnorm   h += delta (one rounding: `residual + hidden_states`), then LlamaRMSNorm: fp32 x * rsqrt(mean(x^2) + eps) -> T -> weight * (a product in T)
+//   rope_cache    apply_rotary_pos_emb: (q * cos) + (rotate_half(q) * sin) with three roundings to T, k likewise, and the StaticCache
 //                 update (k_rot / v written at cache_position, read from device memory: graph-replay safe)
-//   silu_mul      LlamaMLP: act_fn(gate) * up — silu in fp32 (x / (1 + exp(-x))), rounded to fp16, then the fp16 product
-// and one that does NOT restate a kernel bit for bit (opt-in, FusedLlamaStep(attention="hip")):
+//   silu_mul      LlamaMLP: act_fn(gate) * up — silu in fp32 (x / (1 + exp(-x))), rounded to T, then the product in T
+// T = fp16: native half arithmetic.  T = bf16: float arithmetic + one round-to-nearest-even per op, which is how torch evaluates bf16 elementwise ops.
+// And one that does NOT restate a kernel bit for bit (opt-in, FusedLlamaStep(attention="hip")):
 //   attn_decode   softmax(q K^T * scaling) V for ONE query per head over the static KV cache's first pos + 1 positions, fp32 scores / softmax /
-//                 accumulation, one fp16 rounding of the output: what F.scaled_dot_product_attention computes for a decode step, within
-//                 rounding of it (SDPA's flash kernel blocks the keys and rounds P to fp16; this one does neither) — 3-4 us instead of the
+//                 accumulation, one rounding of the output: what F.scaled_dot_product_attention computes for a decode step, within
+//                 rounding of it (SDPA's flash kernel blocks the keys and rounds P to T; this one does neither) — ~4 us instead of the
 //                 12-15 us the library's prefill-shaped kernel takes for a single query (profiles/r04_e2e_kernel_times.txt)
 // Compiled with -ffp-contract=off: a fused multiply-add would remove a rounding HF's separate ops make.
 #include "hqq_common.h"
 
 namespace hqq {
 
-// ---- h (+= delta), xn = weight * fp16(float(h) * rsqrt(mean(float(h)^2) + eps)): one workgroup of 512 threads per row.
+// element arithmetic on raw 16-bit values, with the roundings torch's elementwise ops make
+template <bool BF>
+struct El {
+  static __device__ __forceinline__ float f(uint16_t a) {
+    if constexpr (BF) return bf16_to_f32(a);
+    else return static_cast<float>(__builtin_bit_cast(half_t, a));
+  }
+  static __device__ __forceinline__ uint16_t r(float v) {   // round to nearest even
+    if constexpr (BF) return f32_to_bf16(v);
+    else return __builtin_bit_cast(uint16_t, static_cast<half_t>(v));
+  }
+  static __device__ __forceinline__ uint16_t add(uint16_t a, uint16_t b) {
+    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) + bf16_to_f32(b));
+    else { const half_t s = __builtin_bit_cast(half_t, a) + __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
+  }
+  static __device__ __forceinline__ uint16_t mul(uint16_t a, uint16_t b) {
+    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) * bf16_to_f32(b));
+    else { const half_t s = __builtin_bit_cast(half_t, a) * __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
+  }
+  static __device__ __forceinline__ uint16_t neg(uint16_t a) { return static_cast<uint16_t>(a ^ 0x8000u); }
+};
+
+// ---- h (+= delta), xn = weight * T(float(h) * rsqrt(mean(float(h)^2) + eps)): one workgroup of 512 threads per row.
 //      Rows of up to 512 * 8 * RPT elements stay in registers between the two passes (every load is issued before the reduction: the kernel is
 //      one memory round trip + one barrier long); longer rows take the generic two-pass path ----
-template <int RPT>   // 16-byte chunks per thread held in registers; 0: re-read
-__global__ __launch_bounds__(512) void add_rmsnorm_kernel(half_t* __restrict__ h, const half_t* __restrict__ delta, const half_t* __restrict__ weight, float eps,
-                                                          half_t* __restrict__ xn, int H) {
+template <int RPT, bool BF>   // RPT: 16-byte chunks per thread held in registers; 0: re-read
+__global__ __launch_bounds__(512) void add_rmsnorm_kernel(uint16_t* __restrict__ h, const uint16_t* __restrict__ delta, const uint16_t* __restrict__ weight, float eps,
+                                                          uint16_t* __restrict__ xn, int H) {
+  using E = El<BF>;
   __shared__ float part[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  half_t* hr = h + static_cast<int64_t>(blockIdx.x) * H;
-  const half_t* dr = delta ? delta + static_cast<int64_t>(blockIdx.x) * H : nullptr;
-  half_t* xr = xn + static_cast<int64_t>(blockIdx.x) * H;
+  uint16_t* hr = h + static_cast<int64_t>(blockIdx.x) * H;
+  const uint16_t* dr = delta ? delta + static_cast<int64_t>(blockIdx.x) * H : nullptr;
+  uint16_t* xr = xn + static_cast<int64_t>(blockIdx.x) * H;
   constexpr int NR = RPT > 0 ? RPT : 1;
   u32x4 hv[NR], wv[NR];
   float sum = 0.f;
@@ -47,30 +71,30 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(half_t* __restrict__ h
     for (int c = 0; c < NR; ++c) {
       const int i = (c * 512 + tid) * 8;
       if (i < H) {
-        half_t* hp = reinterpret_cast<half_t*>(&hv[c]);
+        uint16_t* hp = reinterpret_cast<uint16_t*>(&hv[c]);
         if (dr) {
-          const half_t* dp = reinterpret_cast<const half_t*>(&dv[c]);
+          const uint16_t* dp = reinterpret_cast<const uint16_t*>(&dv[c]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) hp[j] = hp[j] + dp[j];   // residual + hidden_states, one fp16 rounding
+          for (int j = 0; j < 8; ++j) hp[j] = E::add(hp[j], dp[j]);   // residual + hidden_states, one rounding
           *reinterpret_cast<u32x4*>(hr + i) = hv[c];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = static_cast<float>(hp[j]); sum += f * f; }
+        for (int j = 0; j < 8; ++j) { const float f = E::f(hp[j]); sum += f * f; }
       }
     }
   } else {
     for (int i = tid * 8; i < H; i += 512 * 8) {
       u32x4 v = *reinterpret_cast<const u32x4*>(hr + i);
-      half_t* hp = reinterpret_cast<half_t*>(&v);
+      uint16_t* hp = reinterpret_cast<uint16_t*>(&v);
       if (dr) {
         const u32x4 dv = *reinterpret_cast<const u32x4*>(dr + i);
-        const half_t* dp = reinterpret_cast<const half_t*>(&dv);
+        const uint16_t* dp = reinterpret_cast<const uint16_t*>(&dv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hp[j] = hp[j] + dp[j];
+        for (int j = 0; j < 8; ++j) hp[j] = E::add(hp[j], dp[j]);
         *reinterpret_cast<u32x4*>(hr + i) = v;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = static_cast<float>(hp[j]); sum += f * f; }
+      for (int j = 0; j < 8; ++j) { const float f = E::f(hp[j]); sum += f * f; }
     }
   }
   // wave sum (shuffles), then the eight waves through LDS, fixed order
@@ -85,12 +109,12 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(half_t* __restrict__ h
     for (int c = 0; c < NR; ++c) {
       const int i = (c * 512 + tid) * 8;
       if (i < H) {
-        const half_t* hp = reinterpret_cast<const half_t*>(&hv[c]);
-        const half_t* wp = reinterpret_cast<const half_t*>(&wv[c]);
+        const uint16_t* hp = reinterpret_cast<const uint16_t*>(&hv[c]);
+        const uint16_t* wp = reinterpret_cast<const uint16_t*>(&wv[c]);
         u32x4 ov;
-        half_t* op = reinterpret_cast<half_t*>(&ov);
+        uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) op[j] = wp[j] * static_cast<half_t>(static_cast<float>(hp[j]) * r);
+        for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r(E::f(hp[j]) * r));
         *reinterpret_cast<u32x4*>(xr + i) = ov;
       }
     }
@@ -98,21 +122,30 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(half_t* __restrict__ h
     for (int i = tid * 8; i < H; i += 512 * 8) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(hr + i);
       const u32x4 w = *reinterpret_cast<const u32x4*>(weight + i);
-      const half_t* hp = reinterpret_cast<const half_t*>(&v);
-      const half_t* wp = reinterpret_cast<const half_t*>(&w);
+      const uint16_t* hp = reinterpret_cast<const uint16_t*>(&v);
+      const uint16_t* wp = reinterpret_cast<const uint16_t*>(&w);
       u32x4 ov;
-      half_t* op = reinterpret_cast<half_t*>(&ov);
+      uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) op[j] = wp[j] * static_cast<half_t>(static_cast<float>(hp[j]) * r);
+      for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r(E::f(hp[j]) * r));
       *reinterpret_cast<u32x4*>(xr + i) = ov;
     }
   }
 }
 
+// q_embed = (q * cos) + (rotate_half(q) * sin), rotate_half = cat(-x2, x1): every product and the sum round to T
+template <bool BF>
+__device__ __forceinline__ void rope_pair(uint16_t x1, uint16_t x2, uint16_t c1, uint16_t c2, uint16_t s1, uint16_t s2, uint16_t& o1, uint16_t& o2) {
+  using E = El<BF>;
+  o1 = E::add(E::mul(x1, c1), E::mul(E::neg(x2), s1));
+  o2 = E::add(E::mul(x2, c2), E::mul(x1, s2));
+}
+
 // ---- rotary embedding of q and k, KV-cache write.  One thread per (head, i < hd / 2): elements i and i + hd / 2 of a head ----
-__global__ __launch_bounds__(256) void rope_cache_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
-                                                         const half_t* __restrict__ cosv, const half_t* __restrict__ sinv, const int64_t* __restrict__ pos,
-                                                         half_t* __restrict__ q_out, half_t* __restrict__ k_cache, half_t* __restrict__ v_cache,
+template <bool BF>
+__global__ __launch_bounds__(256) void rope_cache_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                         const uint16_t* __restrict__ cosv, const uint16_t* __restrict__ sinv, const int64_t* __restrict__ pos,
+                                                         uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache, uint16_t* __restrict__ v_cache,
                                                          int n_heads, int n_kv, int hd, int cache_len) {
   const int half = hd / 2;
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,88 +153,85 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const half_t* __restric
   if (id >= total) return;
   const int head = id / half, i = id - head * half;
   const bool is_k = head >= n_heads;
-  const half_t* src = is_k ? k + static_cast<int64_t>(head - n_heads) * hd : q + static_cast<int64_t>(head) * hd;
-  const half_t x1 = src[i], x2 = src[i + half];
-  const half_t c1 = cosv[i], c2 = cosv[i + half], s1 = sinv[i], s2 = sinv[i + half];
-  // q_embed = (q * cos) + (rotate_half(q) * sin), rotate_half = cat(-x2, x1): every product and the sum round to fp16
-  const half_t o1 = (x1 * c1) + ((-x2) * s1);
-  const half_t o2 = (x2 * c2) + (x1 * s2);
+  const uint16_t* src = is_k ? k + static_cast<int64_t>(head - n_heads) * hd : q + static_cast<int64_t>(head) * hd;
+  uint16_t o1, o2;
+  rope_pair<BF>(src[i], src[i + half], cosv[i], cosv[i + half], sinv[i], sinv[i + half], o1, o2);
   if (!is_k) {
     q_out[static_cast<int64_t>(head) * hd + i] = o1;
     q_out[static_cast<int64_t>(head) * hd + i + half] = o2;
   } else {
     const int64_t p = pos[0];
     const int kh = head - n_heads;
-    half_t* kd = k_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
-    half_t* vd = v_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
+    uint16_t* kd = k_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
+    uint16_t* vd = v_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
     kd[i] = o1;
     kd[i + half] = o2;
-    const half_t* vs = v + static_cast<int64_t>(kh) * hd;
+    const uint16_t* vs = v + static_cast<int64_t>(kh) * hd;
     vd[i] = vs[i];
     vd[i + half] = vs[i + half];
   }
 }
 
-// ---- out = fp16(silu(gate)) * up ----
-__global__ __launch_bounds__(256) void silu_mul_kernel(const half_t* __restrict__ g, const half_t* __restrict__ u, half_t* __restrict__ out, int64_t n) {
+// ---- out = T(silu(gate)) * up ----
+template <bool BF>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ u, uint16_t* __restrict__ out, int64_t n) {
+  using E = El<BF>;
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 8;
   if (i >= n) return;
   const u32x4 gv = *reinterpret_cast<const u32x4*>(g + i);
   const u32x4 uv = *reinterpret_cast<const u32x4*>(u + i);
-  const half_t* gp = reinterpret_cast<const half_t*>(&gv);
-  const half_t* up = reinterpret_cast<const half_t*>(&uv);
+  const uint16_t* gp = reinterpret_cast<const uint16_t*>(&gv);
+  const uint16_t* up = reinterpret_cast<const uint16_t*>(&uv);
   u32x4 ov;
-  half_t* op = reinterpret_cast<half_t*>(&ov);
+  uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float x = static_cast<float>(gp[j]);
-    const half_t s = static_cast<half_t>(x / (1.0f + expf(-x)));
-    op[j] = s * up[j];
+    const float x = E::f(gp[j]);
+    op[j] = E::mul(E::r(x / (1.0f + expf(-x))), up[j]);
   }
   *reinterpret_cast<u32x4*>(out + i) = ov;
 }
 
 // ---- decode attention: one workgroup of 512 threads per query head.  Phase 1: a LANE per key (its 2 HD bytes in 16-byte loads, q broadcast
-//      from LDS, v_dot2_f32_f16 into fp32), scores into LDS, workgroup maximum.  Phase 2: exp(s - max) in place, workgroup sum.  Phase 3: a wave
+//      from LDS, v_dot2 into fp32), scores into LDS, workgroup maximum.  Phase 2: exp(s - max) in place, workgroup sum.  Phase 3: a wave
 //      per key (keys dealt round-robin to the 8 waves), a lane per pair of dims: o += p V[j]; the 8 partial vectors are added in wave order.
-//      Deterministic: no atomics, fixed orders.  Keys beyond pos are never read ----
+//      Deterministic: no atomics, fixed orders.  Keys beyond pos are never read.
 //      ROPE = true (hqq_hip_rope_attn_decode): q, k, v are the RAW projections; the workgroup applies the rotary embedding to its query and to its
 //      KV head's new key itself (rope_cache_kernel's arithmetic, rounding for rounding), uses the new key / value from LDS for position pos — the
-//      cache is only read below pos, so no workgroup depends on another's write — and the first query head of each KV head writes them to the cache
-template <int HD, bool ROPE>
-__global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restrict__ q, const half_t* __restrict__ kc_in, const half_t* __restrict__ vc_in,
-                                                          const int64_t* __restrict__ pos, half_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling,
-                                                          const half_t* __restrict__ k_raw, const half_t* __restrict__ v_raw, const half_t* __restrict__ cosv,
-                                                          const half_t* __restrict__ sinv, half_t* __restrict__ kc_out, half_t* __restrict__ vc_out) {
+//      cache is only read below pos, so no workgroup depends on another's write — and the first query head of each KV head writes them to the cache ----
+template <int HD, bool ROPE, bool BF>
+__global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc_in, const uint16_t* __restrict__ vc_in,
+                                                          const int64_t* __restrict__ pos, uint16_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling,
+                                                          const uint16_t* __restrict__ k_raw, const uint16_t* __restrict__ v_raw, const uint16_t* __restrict__ cosv,
+                                                          const uint16_t* __restrict__ sinv, uint16_t* __restrict__ kc_out, uint16_t* __restrict__ vc_out) {
+  using E = El<BF>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [16] reduction scratch
-  half_t* qs = reinterpret_cast<half_t*>(smem + 64);            // [HD] the query; ROPE: + [HD] the new key, [HD] the new value
+  uint16_t* qs = reinterpret_cast<uint16_t*>(smem + 64);        // [HD] the query; ROPE: + [HD] the new key, [HD] the new value
   float* part = reinterpret_cast<float*>(smem + 64 + HD * 6);   // [8][HD]
   float* sc = part + 8 * HD;                                    // [n] scores, then probabilities
-  half_t* knew = qs + HD;
-  half_t* vnew = qs + 2 * HD;
+  uint16_t* knew = qs + HD;
+  uint16_t* vnew = qs + 2 * HD;
   const int h = blockIdx.x, rep = n_heads / n_kv, kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = static_cast<int>(pos[0]);
   const int n = p0 + 1;
-  const half_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
-  const half_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
+  const uint16_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
+  const uint16_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
   if constexpr (ROPE) {
     // thread t < HD / 2: elements t and t + HD / 2 of the query; HD / 2 <= t < HD: of the new key; HD <= t < HD + HD / 8: a 16-byte chunk of the new value
     constexpr int half = HD / 2;
     if (tid < HD) {
       const bool is_k = tid >= half;
       const int i = is_k ? tid - half : tid;
-      const half_t* src = is_k ? k_raw + static_cast<int64_t>(kvh) * HD : q + static_cast<int64_t>(h) * HD;
-      const half_t x1 = src[i], x2 = src[i + half];
-      const half_t c1 = cosv[i], c2 = cosv[i + half], s1 = sinv[i], s2 = sinv[i + half];
-      const half_t o1 = (x1 * c1) + ((-x2) * s1);   // (q * cos) + (rotate_half(q) * sin): three fp16 roundings per element, as apply_rotary_pos_emb
-      const half_t o2 = (x2 * c2) + (x1 * s2);
-      half_t* dst = is_k ? knew : qs;
+      const uint16_t* src = is_k ? k_raw + static_cast<int64_t>(kvh) * HD : q + static_cast<int64_t>(h) * HD;
+      uint16_t o1, o2;
+      rope_pair<BF>(src[i], src[i + half], cosv[i], cosv[i + half], sinv[i], sinv[i + half], o1, o2);
+      uint16_t* dst = is_k ? knew : qs;
       dst[i] = o1;
       dst[i + half] = o2;
       if (is_k && h % rep == 0) {
-        half_t* kd = kc_out + (static_cast<int64_t>(kvh) * L + p0) * HD;
+        uint16_t* kd = kc_out + (static_cast<int64_t>(kvh) * L + p0) * HD;
         kd[i] = o1;
         kd[i + half] = o2;
       }
@@ -216,6 +246,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
   }
   __syncthreads();
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
   // phase 1
   float mx = -INFINITY;
   for (int j = tid; j < n; j += 512) {
@@ -229,7 +260,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const uint32_t qe = qv[e], ke = kv[e];   // (a bit_cast of an ext-vector ELEMENT reads element 0: copy to a scalar first)
-        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qe), __builtin_bit_cast(h2, ke), acc, false);
+        if constexpr (BF) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, qe), __builtin_bit_cast(b2, ke), acc, false);
+        else acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qe), __builtin_bit_cast(h2, ke), acc, false);
       }
     }
     const float sv = acc * scaling;
@@ -262,11 +294,11 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
   for (int d = 0; d < DPL; ++d) o[d] = 0.f;
   int j = wave;
   for (; j + 24 < n; j += 32) {   // four keys of this wave in flight
-    half_t v4[4][DPL];
+    uint16_t v4[4][DPL];
     float p4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const half_t* vr = (ROPE && j + 8 * u == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
+      const uint16_t* vr = (ROPE && j + 8 * u == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
 #pragma unroll
       for (int d = 0; d < DPL; ++d) v4[u][d] = vr[d];
       p4[u] = sc[j + 8 * u];
@@ -274,13 +306,13 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], static_cast<float>(v4[u][d]), o[d]);
+      for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], E::f(v4[u][d]), o[d]);
   }
   for (; j < n; j += 8) {
-    const half_t* vr = (ROPE && j == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j) * HD + DPL * lane;
+    const uint16_t* vr = (ROPE && j == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j) * HD + DPL * lane;
     const float pj = sc[j];
 #pragma unroll
-    for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, static_cast<float>(vr[d]), o[d]);
+    for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, E::f(vr[d]), o[d]);
   }
 #pragma unroll
   for (int d = 0; d < DPL; ++d) part[wave * HD + DPL * lane + d] = o[d];
@@ -289,7 +321,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) t += part[w * HD + tid];
-    out[static_cast<int64_t>(h) * HD + tid] = static_cast<half_t>(t / sum);
+    out[static_cast<int64_t>(h) * HD + tid] = E::r(t / sum);
   }
 }
 
@@ -297,19 +329,33 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const half_t* __restri
 
 using namespace hqq;
 
+static inline bool block_dtype_ok(int dtype, const char* who) {
+  if (dtype == HQQ_F16 || dtype == HQQ_BF16) return true;
+  set_error("%s: fp16 / bf16 only (dtype %d)", who, dtype);
+  return false;
+}
+typedef const uint16_t* cu16;
+typedef uint16_t* u16;
+
 extern "C" {
 
 int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float eps, void* xn_out, int64_t rows, int64_t H, int dtype, void* stream) {
   clear_stale_error();
-  if (dtype != HQQ_F16) { set_error("hqq_hip_add_rmsnorm: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!block_dtype_ok(dtype, "hqq_hip_add_rmsnorm")) return HQQ_ERR_UNSUPPORTED;
   if (!h || !weight || !xn_out || rows < 1 || H < 8 || H % 8 || rows > INT32_MAX || H > INT32_MAX) { set_error("hqq_hip_add_rmsnorm: bad arguments (H must be a multiple of 8)"); return HQQ_ERR_SHAPE; }
   if (!aligned16(h) || !aligned16(weight) || !aligned16(xn_out) || (delta && !aligned16(delta))) { set_error("hqq_hip_add_rmsnorm: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-#define HQQ_NORM_GO(RPTV)                                                                                                                         \
-  hipLaunchKernelGGL(add_rmsnorm_kernel<RPTV>, dim3(static_cast<unsigned>(rows)), dim3(512), 0, as_stream(stream), static_cast<half_t*>(h), static_cast<const half_t*>(delta), \
-                     static_cast<const half_t*>(weight), eps, static_cast<half_t*>(xn_out), static_cast<int>(H))
-  if (H <= 512 * 8) HQQ_NORM_GO(1);
-  else if (H <= 512 * 8 * 2) HQQ_NORM_GO(2);
-  else HQQ_NORM_GO(0);
+#define HQQ_NORM_GO(RPTV, BFV)                                                                                                                   \
+  hipLaunchKernelGGL((add_rmsnorm_kernel<RPTV, BFV>), dim3(static_cast<unsigned>(rows)), dim3(512), 0, as_stream(stream), static_cast<u16>(h), static_cast<cu16>(delta), \
+                     static_cast<cu16>(weight), eps, static_cast<u16>(xn_out), static_cast<int>(H))
+  if (dtype == HQQ_BF16) {
+    if (H <= 512 * 8) HQQ_NORM_GO(1, true);
+    else if (H <= 512 * 8 * 2) HQQ_NORM_GO(2, true);
+    else HQQ_NORM_GO(0, true);
+  } else {
+    if (H <= 512 * 8) HQQ_NORM_GO(1, false);
+    else if (H <= 512 * 8 * 2) HQQ_NORM_GO(2, false);
+    else HQQ_NORM_GO(0, false);
+  }
 #undef HQQ_NORM_GO
   return check_launch("hqq_hip_add_rmsnorm");
 }
@@ -317,24 +363,28 @@ int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float ep
 int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* q_out, void* k_cache,
                        void* v_cache, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, int dtype, void* stream) {
   clear_stale_error();
-  if (dtype != HQQ_F16) { set_error("hqq_hip_rope_cache: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!block_dtype_ok(dtype, "hqq_hip_rope_cache")) return HQQ_ERR_UNSUPPORTED;
   if (!q || !k || !v || !cos || !sin || !pos_dev || !q_out || !k_cache || !v_cache || n_heads < 1 || n_kv_heads < 1 || head_dim < 2 || head_dim % 2 || cache_len < 1 ||
       (n_heads + n_kv_heads) * head_dim > INT32_MAX || cache_len > INT32_MAX) { set_error("hqq_hip_rope_cache: bad arguments"); return HQQ_ERR_SHAPE; }
   const int64_t total = (n_heads + n_kv_heads) * (head_dim / 2);
-  hipLaunchKernelGGL(rope_cache_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(q), static_cast<const half_t*>(k),
-                     static_cast<const half_t*>(v), static_cast<const half_t*>(cos), static_cast<const half_t*>(sin), pos_dev, static_cast<half_t*>(q_out),
-                     static_cast<half_t*>(k_cache), static_cast<half_t*>(v_cache), static_cast<int>(n_heads), static_cast<int>(n_kv_heads), static_cast<int>(head_dim),
-                     static_cast<int>(cache_len));
+#define HQQ_ROPE_GO(BFV)                                                                                                                          \
+  hipLaunchKernelGGL(rope_cache_kernel<BFV>, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<cu16>(q), static_cast<cu16>(k), \
+                     static_cast<cu16>(v), static_cast<cu16>(cos), static_cast<cu16>(sin), pos_dev, static_cast<u16>(q_out), static_cast<u16>(k_cache),  \
+                     static_cast<u16>(v_cache), static_cast<int>(n_heads), static_cast<int>(n_kv_heads), static_cast<int>(head_dim), static_cast<int>(cache_len))
+  if (dtype == HQQ_BF16) HQQ_ROPE_GO(true);
+  else HQQ_ROPE_GO(false);
+#undef HQQ_ROPE_GO
   return check_launch("hqq_hip_rope_cache");
 }
 
 int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream) {
   clear_stale_error();
-  if (dtype != HQQ_F16) { set_error("hqq_hip_silu_mul: fp16 only (dtype %d)", dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!block_dtype_ok(dtype, "hqq_hip_silu_mul")) return HQQ_ERR_UNSUPPORTED;
   if (!gate || !up || !out || n < 8 || n % 8) { set_error("hqq_hip_silu_mul: bad arguments (n must be a multiple of 8)"); return HQQ_ERR_SHAPE; }
   if (!aligned16(gate) || !aligned16(up) || !aligned16(out)) { set_error("hqq_hip_silu_mul: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-  hipLaunchKernelGGL(silu_mul_kernel, dim3(static_cast<unsigned>((n / 8 + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const half_t*>(gate),
-                     static_cast<const half_t*>(up), static_cast<half_t*>(out), n);
+  const dim3 grid(static_cast<unsigned>((n / 8 + 255) / 256));
+  if (dtype == HQQ_BF16) hipLaunchKernelGGL(silu_mul_kernel<true>, grid, dim3(256), 0, as_stream(stream), static_cast<cu16>(gate), static_cast<cu16>(up), static_cast<u16>(out), n);
+  else hipLaunchKernelGGL(silu_mul_kernel<false>, grid, dim3(256), 0, as_stream(stream), static_cast<cu16>(gate), static_cast<cu16>(up), static_cast<u16>(out), n);
   return check_launch("hqq_hip_silu_mul");
 }
 
@@ -342,7 +392,7 @@ static int attn_decode_run(const char* who, bool rope, const void* q, const void
                            void* k_cache, void* v_cache, void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype,
                            void* stream) {
   clear_stale_error();
-  if (dtype != HQQ_F16) { set_error("%s: fp16 only (dtype %d)", who, dtype); return HQQ_ERR_UNSUPPORTED; }
+  if (!block_dtype_ok(dtype, who)) return HQQ_ERR_UNSUPPORTED;
   if (!q || !k_cache || !v_cache || !pos_dev || !out || (rope && (!k_raw || !v_raw || !cosv || !sinv)) || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads ||
       cache_len < 1 || cache_len > 30000 || n_heads > INT32_MAX) {
     set_error("%s: bad arguments (cache_len <= 30000, n_heads a multiple of n_kv_heads)", who);
@@ -356,26 +406,29 @@ static int attn_decode_run(const char* who, bool rope, const void* q, const void
   const int HD = static_cast<int>(head_dim);
   const int lds = 64 + HD * 6 + 8 * HD * 4 + static_cast<int>(cache_len) * 4;
   const dim3 grid(static_cast<unsigned>(n_heads)), block(512);
-  static LdsRaised raised[6];
+  static LdsRaised raised[12];
   constexpr int LDS_MAX = 64 + 256 * 6 + 8 * 256 * 4 + 30000 * 4;
-#define HQQ_ATTN_GO(HDV, RP, IDX)                                                                                                          \
+#define HQQ_ATTN_GO(HDV, RP, BFV, IDX)                                                                                                     \
   do {                                                                                                                                     \
     if (lds > 48 * 1024)                                                                                                                   \
-      if (const int rc = raise_lds_limit(raised[IDX], reinterpret_cast<const void*>(&attn_decode_kernel<HDV, RP>), LDS_MAX, who)) return rc; \
-    hipLaunchKernelGGL((attn_decode_kernel<HDV, RP>), grid, block, lds, as_stream(stream), static_cast<const half_t*>(q), static_cast<const half_t*>(k_cache), \
-                       static_cast<const half_t*>(v_cache), pos_dev, static_cast<half_t*>(out), static_cast<int>(n_heads), static_cast<int>(n_kv_heads), \
-                       static_cast<int>(cache_len), scaling, static_cast<const half_t*>(k_raw), static_cast<const half_t*>(v_raw),          \
-                       static_cast<const half_t*>(cosv), static_cast<const half_t*>(sinv), static_cast<half_t*>(k_cache), static_cast<half_t*>(v_cache)); \
+      if (const int rc = raise_lds_limit(raised[IDX], reinterpret_cast<const void*>(&attn_decode_kernel<HDV, RP, BFV>), LDS_MAX, who)) return rc; \
+    hipLaunchKernelGGL((attn_decode_kernel<HDV, RP, BFV>), grid, block, lds, as_stream(stream), static_cast<cu16>(q), static_cast<cu16>(k_cache), \
+                       static_cast<cu16>(v_cache), pos_dev, static_cast<u16>(out), static_cast<int>(n_heads), static_cast<int>(n_kv_heads),  \
+                       static_cast<int>(cache_len), scaling, static_cast<cu16>(k_raw), static_cast<cu16>(v_raw),                            \
+                       static_cast<cu16>(cosv), static_cast<cu16>(sinv), static_cast<u16>(k_cache), static_cast<u16>(v_cache));             \
   } while (0)
-  if (rope) {
-    if (HD == 64) HQQ_ATTN_GO(64, true, 0);
-    else if (HD == 128) HQQ_ATTN_GO(128, true, 1);
-    else HQQ_ATTN_GO(256, true, 2);
-  } else {
-    if (HD == 64) HQQ_ATTN_GO(64, false, 3);
-    else if (HD == 128) HQQ_ATTN_GO(128, false, 4);
-    else HQQ_ATTN_GO(256, false, 5);
-  }
+#define HQQ_ATTN_HD(RP, BFV, BASE)                                                                                                         \
+  do {                                                                                                                                     \
+    if (HD == 64) HQQ_ATTN_GO(64, RP, BFV, BASE);                                                                                          \
+    else if (HD == 128) HQQ_ATTN_GO(128, RP, BFV, BASE + 1);                                                                               \
+    else HQQ_ATTN_GO(256, RP, BFV, BASE + 2);                                                                                              \
+  } while (0)
+  const bool bf = dtype == HQQ_BF16;
+  if (rope && bf) HQQ_ATTN_HD(true, true, 0);
+  else if (rope) HQQ_ATTN_HD(true, false, 3);
+  else if (bf) HQQ_ATTN_HD(false, true, 6);
+  else HQQ_ATTN_HD(false, false, 9);
+#undef HQQ_ATTN_HD
 #undef HQQ_ATTN_GO
   return check_launch(who);
 }

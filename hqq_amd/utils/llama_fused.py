@@ -26,27 +26,30 @@ def _hip(layer):
 
 def supports(model) -> bool:
     """a LlamaForCausalLM-shaped model (model.model.layers[*].self_attn.{q,k,v,o}_proj, .mlp.{gate,up,down}_proj, RMSNorm without bias),
-    fp16, every decoder linear an HQQLinearHIP without bias whose group can share one launch"""
+    fp16 or bf16, every decoder linear an HQQLinearHIP without bias whose group can share one launch"""
     try:
         inner = model.model
+        dt = inner.norm.weight.dtype
+        if dt not in (torch.float16, torch.bfloat16):
+            return False
         layers = inner.layers
         if not hasattr(inner, "rotary_emb") or not hasattr(inner, "embed_tokens") or not hasattr(model, "lm_head"):
             return False
         for blk in layers:
             at, mlp = blk.self_attn, blk.mlp
             lin = [_hip(getattr(at, n)) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + [_hip(getattr(mlp, n)) for n in ("gate_proj", "up_proj", "down_proj")]
-            if not all(isinstance(L, HQQLinearHIP) and L.bias is None and L.compute_dtype == torch.float16 and L.W_q.is_cuda for L in lin):
+            if not all(isinstance(L, HQQLinearHIP) and L.bias is None and L.compute_dtype == dt and L.W_q.is_cuda for L in lin):
                 return False
             if len({(L.nbits, L.group_size, L.w3s) for L in lin[:3]}) != 1 or len({(L.nbits, L.group_size, L.w3s) for L in lin[4:6]}) != 1:
                 return False
-            if not ops.decode_covers(torch.float16, 1, lin[0].out_features, lin[0].in_features, lin[0].group_size, lin[0].nbits) and not lin[0].w3s:
+            if not ops.decode_covers(dt, 1, lin[0].out_features, lin[0].in_features, lin[0].group_size, lin[0].nbits) and not lin[0].w3s:
                 return False
             if type(getattr(mlp, "act_fn", None)).__name__ not in ("SiLUActivation", "SiLU"):
                 return False
             for nrm in (blk.input_layernorm, blk.post_attention_layernorm):
-                if nrm.weight.dtype != torch.float16 or nrm.weight.shape[0] % 8:
+                if nrm.weight.dtype != dt or nrm.weight.shape[0] % 8:
                     return False
-        return inner.norm.weight.dtype == torch.float16
+        return True
     except AttributeError:
         return False
 
@@ -65,6 +68,7 @@ class FusedLlamaStep:
         self.inner = inner
         cfg = model.config
         self.device = inner.embed_tokens.weight.device
+        self.dt = dt = inner.norm.weight.dtype   # fp16 or bf16 (supports())
         self.n_heads = cfg.num_attention_heads
         self.n_kv = getattr(cfg, "num_key_value_heads", None) or cfg.num_attention_heads
         self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
@@ -92,18 +96,18 @@ class FusedLlamaStep:
                 "o": o, "gu": [(L.W_q, L.scale, L.zero, None, L.out_features) for L in (g, u)], "gu_opts": self._gopts((g, u)), "gu_nbits": g.nbits, "d": d,
                 "kc": lay.keys[0], "vc": lay.values[0], "len": lay.cumulative_length,
                 # outputs of the launches (static addresses: the step is captured in a hipGraph)
-                "q": torch.empty(1, q.out_features, dtype=torch.float16, device=dev), "k": torch.empty(1, k.out_features, dtype=torch.float16, device=dev),
-                "v": torch.empty(1, v.out_features, dtype=torch.float16, device=dev), "qr": torch.empty(1, self.n_heads, 1, self.hd, dtype=torch.float16, device=dev),
-                "g": torch.empty(1, g.out_features, dtype=torch.float16, device=dev), "u": torch.empty(1, u.out_features, dtype=torch.float16, device=dev),
-                "a": torch.empty(1, g.out_features, dtype=torch.float16, device=dev),
+                "q": torch.empty(1, q.out_features, dtype=dt, device=dev), "k": torch.empty(1, k.out_features, dtype=dt, device=dev),
+                "v": torch.empty(1, v.out_features, dtype=dt, device=dev), "qr": torch.empty(1, self.n_heads, 1, self.hd, dtype=dt, device=dev),
+                "g": torch.empty(1, g.out_features, dtype=dt, device=dev), "u": torch.empty(1, u.out_features, dtype=dt, device=dev),
+                "a": torch.empty(1, g.out_features, dtype=dt, device=dev),
             })
-        self.h = torch.empty(1, self.H, dtype=torch.float16, device=dev)       # the residual stream
-        self.xn = torch.empty(1, self.H, dtype=torch.float16, device=dev)      # its normalised copy, input of the next linears
-        self.delta = torch.empty(1, self.H, dtype=torch.float16, device=dev)   # output of o / down, added by the next add_rmsnorm
-        self.att = torch.empty(1, self.n_heads * self.hd, dtype=torch.float16, device=dev)   # attention output (attention="hip")
+        self.h = torch.empty(1, self.H, dtype=dt, device=dev)       # the residual stream
+        self.xn = torch.empty(1, self.H, dtype=dt, device=dev)      # its normalised copy, input of the next linears
+        self.delta = torch.empty(1, self.H, dtype=dt, device=dev)   # output of o / down, added by the next add_rmsnorm
+        self.att = torch.empty(1, self.n_heads * self.hd, dtype=dt, device=dev)   # attention output (attention="hip")
         # the causal mask of one query over the static cache, in the additive form SDPA turns a boolean mask into on every call
         # (where(mask, 0, -inf) in the query dtype): built once per token here instead of once per decoder block inside the attention function
-        self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=torch.float16, device=dev)
+        self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=dt, device=dev)
         self.ar = torch.arange(max_cache_len, device=dev)
         # cos / sin of every cache position, from the model's own rotary module called once (elementwise in the position: the rows equal what a
         # per-token call returns); rope types whose frequencies depend on the sequence length ("dynamic") keep the per-token call
@@ -111,10 +115,10 @@ class FusedLlamaStep:
         if getattr(inner.rotary_emb, "rope_type", "default") in ("default", "linear", "llama3", "yarn", "longrope") and \
                 max_cache_len <= getattr(cfg, "max_position_embeddings", max_cache_len):
             with torch.no_grad():
-                c, s_ = inner.rotary_emb(torch.empty(1, 1, self.H, dtype=torch.float16, device=dev), self.ar.view(1, -1))
+                c, s_ = inner.rotary_emb(torch.empty(1, 1, self.H, dtype=dt, device=dev), self.ar.view(1, -1))
             self.cos_tab, self.sin_tab = c[0].contiguous(), s_[0].contiguous()   # [max_cache_len, hd]
-        self.zero = torch.zeros((), dtype=torch.float16, device=dev)
-        self.ninf = torch.full((), float("-inf"), dtype=torch.float16, device=dev)
+        self.zero = torch.zeros((), dtype=dt, device=dev)
+        self.ninf = torch.full((), float("-inf"), dtype=dt, device=dev)
 
     @staticmethod
     def _gopts(Ls) -> int:

@@ -174,11 +174,11 @@ int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_lo
  * The steps either side of the GEMVs in a decode step (ABI 5; csrc/block.hip).  The reference's headline is the
  * tok/s of its generate loop (hqq/utils/generation_hf.py:117-540, Readme.md:153), whose decoder block around HQQLinear.forward is HF's
  * eager code: ~25 small kernels per block.  These three restate the HF modules' arithmetic rounding for rounding (transformers
- * models/llama/modeling_llama.py: LlamaRMSNorm.forward, apply_rotary_pos_emb, LlamaMLP.forward; cache_utils.StaticLayer.update), fp16:
- *   hqq_hip_add_rmsnorm  h[rows, H] += delta (if delta != NULL: the residual add, fp16), then xn = weight * fp16(float(h) * rsqrt(mean(h^2) + eps))
+ * models/llama/modeling_llama.py: LlamaRMSNorm.forward, apply_rotary_pos_emb, LlamaMLP.forward; cache_utils.StaticLayer.update), fp16 or bf16 (T below; bf16 ops = float arithmetic + one rounding per op, as torch evaluates them):
+ *   hqq_hip_add_rmsnorm  h[rows, H] += delta (if delta != NULL: the residual add, one rounding), then xn = weight * T(float(h) * rsqrt(mean(h^2) + eps))
  *   hqq_hip_rope_cache   q_out[n_heads, hd] = (q * cos) + (rotate_half(q) * sin); the same for k, written with v into the caches
  *                        [n_kv_heads, cache_len, hd] at position *pos_dev (device memory: the call is graph-replay safe)
- *   hqq_hip_silu_mul     out[n] = fp16(silu(gate)) * up
+ *   hqq_hip_silu_mul     out[n] = T(silu(gate)) * up
  * ------------------------------------------------------------------------------------------- */
 int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float eps, void* xn_out, int64_t rows, int64_t H, int dtype, void* stream);
 int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* q_out, void* k_cache,
@@ -188,9 +188,9 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
 /* Decode attention for ONE query per head over a static KV cache (opt-in: hqq_amd.utils.llama_fused.FusedLlamaStep(attention="hip")).
  * Replaces, in the reference's generate loop (hqq/utils/generation_hf.py:117-540), HF's call of F.scaled_dot_product_attention for a decode step:
  *   out[h, :] = softmax_j(q[h, :] . k_cache[h / (n_heads / n_kv_heads), j, :] * scaling) . v_cache[..., j, :]   over j = 0 .. pos_dev[0]
- * fp32 scores, softmax and accumulation, one fp16 rounding of the output: WITHIN ROUNDING of SDPA's result, not bit-identical to it (its flash
- * kernel blocks the keys and rounds the probabilities to fp16) — which is why the default decode step keeps HF's attention function.
- * q [n_heads, head_dim] (rotary already applied), k_cache / v_cache [n_kv_heads, cache_len, head_dim], out [n_heads, head_dim]; fp16;
+ * fp32 scores, softmax and accumulation, one rounding of the output: WITHIN ROUNDING of SDPA's result, not bit-identical to it (its flash
+ * kernel blocks the keys and rounds the probabilities to the tensors' dtype) — which is why the default decode step keeps HF's attention function.
+ * q [n_heads, head_dim] (rotary already applied), k_cache / v_cache [n_kv_heads, cache_len, head_dim], out [n_heads, head_dim]; fp16 / bf16;
  * head_dim 64 / 128 / 256; cache_len <= 30000; pos_dev: the query's position in device memory (graph-replay safe). */
 int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
                         int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);

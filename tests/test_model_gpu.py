@@ -124,9 +124,10 @@ def test_quantize_model_matches_the_reference_fixture(nbits):
         assert sha(m.meta["scale"].float().cpu().numpy()) == g[f"scale__{n}"].tobytes(), f"{n}: scale differs from the reference"
 
 
-def test_block_glue_kernels_restate_the_hf_modules():
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_block_glue_kernels_restate_the_hf_modules(dt):
     """csrc/block.hip against the HF modules it replaces in the fused decode step: rotary + cache write and SiLU * up bit for bit (elementwise,
-    the same roundings); RMSNorm within one fp16 ulp on a handful of elements (the fp32 sum of squares is taken in another order)"""
+    the same roundings); RMSNorm within one ulp on a handful of elements (the fp32 sum of squares is taken in another order); fp16 and bf16"""
     import torch.nn.functional as F
     from transformers import LlamaConfig
     from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding, apply_rotary_pos_emb
@@ -134,10 +135,10 @@ def test_block_glue_kernels_restate_the_hf_modules():
     g = torch.Generator(device="cuda").manual_seed(0)
     H, nh, nkv, hd, L = 4096, 32, 8, 128, 64
     # RMSNorm (+ residual add)
-    h = torch.randn(1, H, device="cuda", generator=g).half()
-    d = (torch.randn(1, H, device="cuda", generator=g) * 0.3).half()
-    norm = LlamaRMSNorm(H, eps=1e-5).cuda().half()
-    norm.weight.data = (1 + 0.1 * torch.randn(H, device="cuda", generator=g)).half()
+    h = torch.randn(1, H, device="cuda", generator=g).to(dt)
+    d = (torch.randn(1, H, device="cuda", generator=g) * 0.3).to(dt)
+    norm = LlamaRMSNorm(H, eps=1e-5).cuda().to(dt)
+    norm.weight.data = (1 + 0.1 * torch.randn(H, device="cuda", generator=g)).to(dt)
     want_h = h + d
     want = norm(want_h)
     h2 = h.clone()
@@ -147,10 +148,10 @@ def test_block_glue_kernels_restate_the_hf_modules():
     assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= 8, (int(diff.max()), int((diff > 0).sum()))
     assert torch.equal(ops.add_rmsnorm(h.clone(), None, norm.weight, norm.variance_epsilon)[0, :4].isfinite(), torch.ones(4, dtype=torch.bool, device="cuda"))
     for H2, rows in ((8192, 3), (5120, 2), (16392, 2), (64, 5)):   # two chunks per thread in registers; a ragged last chunk; the re-reading path; a tiny row
-        hh = torch.randn(rows, H2, device="cuda", generator=g).half()
-        dd = (torch.randn(rows, H2, device="cuda", generator=g) * 0.3).half()
-        nn2 = LlamaRMSNorm(H2, eps=1e-6).cuda().half()
-        nn2.weight.data = (1 + 0.1 * torch.randn(H2, device="cuda", generator=g)).half()
+        hh = torch.randn(rows, H2, device="cuda", generator=g).to(dt)
+        dd = (torch.randn(rows, H2, device="cuda", generator=g) * 0.3).to(dt)
+        nn2 = LlamaRMSNorm(H2, eps=1e-6).cuda().to(dt)
+        nn2.weight.data = (1 + 0.1 * torch.randn(H2, device="cuda", generator=g)).to(dt)
         w_h = hh + dd
         w_x = nn2(w_h)
         hh2 = hh.clone()
@@ -162,20 +163,20 @@ def test_block_glue_kernels_restate_the_hf_modules():
     cfg = LlamaConfig(hidden_size=H, num_attention_heads=nh, num_key_value_heads=nkv, max_position_embeddings=2048)
     rot = LlamaRotaryEmbedding(cfg).cuda()
     pos = torch.tensor([37], device="cuda")
-    q = torch.randn(1, nh * hd, device="cuda", generator=g).half()
-    k = torch.randn(1, nkv * hd, device="cuda", generator=g).half()
-    v = torch.randn(1, nkv * hd, device="cuda", generator=g).half()
+    q = torch.randn(1, nh * hd, device="cuda", generator=g).to(dt)
+    k = torch.randn(1, nkv * hd, device="cuda", generator=g).to(dt)
+    v = torch.randn(1, nkv * hd, device="cuda", generator=g).to(dt)
     cos, sin = rot(q.view(1, 1, -1), pos.view(1, 1))
     qe, ke = apply_rotary_pos_emb(q.view(1, 1, nh, hd).transpose(1, 2), k.view(1, 1, nkv, hd).transpose(1, 2), cos, sin)
-    kc = torch.zeros(nkv, L, hd, dtype=torch.float16, device="cuda")
-    vc = torch.zeros(nkv, L, hd, dtype=torch.float16, device="cuda")
-    qr = torch.empty(1, nh, 1, hd, dtype=torch.float16, device="cuda")
+    kc = torch.zeros(nkv, L, hd, dtype=dt, device="cuda")
+    vc = torch.zeros(nkv, L, hd, dtype=dt, device="cuda")
+    qr = torch.empty(1, nh, 1, hd, dtype=dt, device="cuda")
     ops.rope_cache(q, k, v, cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous(), pos, kc, vc, qr)
     assert torch.equal(qr, qe) and torch.equal(kc[:, 37], ke[0, :, 0]) and torch.equal(vc[:, 37], v.view(nkv, hd))
     assert torch.count_nonzero(kc[:, :37]) == 0 and torch.count_nonzero(kc[:, 38:]) == 0
     # SiLU(gate) * up
-    gt = (torch.randn(1, 11008, device="cuda", generator=g) * 2).half()
-    up = torch.randn(1, 11008, device="cuda", generator=g).half()
+    gt = (torch.randn(1, 11008, device="cuda", generator=g) * 2).to(dt)
+    up = torch.randn(1, 11008, device="cuda", generator=g).to(dt)
     assert torch.equal(ops.silu_mul(gt, up), F.silu(gt) * up)
 
 
@@ -235,19 +236,20 @@ def _toy_llama_hip(nbits):
 
 @pytest.mark.parametrize("n_heads,n_kv,hd,L,pos", [(32, 32, 128, 256, 0), (32, 32, 128, 256, 17), (32, 32, 128, 256, 255), (32, 8, 128, 1024, 700),
                                                   (16, 4, 64, 512, 511), (8, 8, 256, 300, 123), (64, 8, 128, 4096, 4000)])
-def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads, n_kv, hd, L, pos):
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads, n_kv, hd, L, pos, dt):
     """hqq_hip_attn_decode (opt-in replacement of the SDPA call of a decode step): one query per head over the first pos + 1 cache positions —
     against softmax attention in float64 on the same fp16 inputs (1e-3 + one fp16 ulp of the output) and against torch's SDPA with the additive
     mask the fused step builds (2e-3: SDPA itself rounds the probabilities to fp16); positions beyond pos are NaN-poisoned and must not be read"""
     from hqq_amd import ops
     g = torch.Generator(device="cuda").manual_seed(n_heads * 1000 + pos)
-    q = torch.randn(n_heads, hd, device="cuda", generator=g).half()
-    kc = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
-    vc = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    q = torch.randn(n_heads, hd, device="cuda", generator=g).to(dt)
+    kc = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
+    vc = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
     kc[:, pos + 1:] = float("nan")
     vc[:, pos + 1:] = float("nan")
     p = torch.tensor([pos], device="cuda")
-    out = torch.full((n_heads * hd,), float("nan"), dtype=torch.float16, device="cuda")
+    out = torch.full((n_heads * hd,), float("nan"), dtype=dt, device="cuda")
     scaling = hd ** -0.5
     ops.attn_decode(q, kc, vc, p, out, scaling)
     rep = n_heads // n_kv
@@ -257,40 +259,43 @@ def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads
     want = torch.einsum("hj,hjd->hd", torch.softmax(sc, -1), vv)
     got = out.view(n_heads, hd).double()
     assert torch.isfinite(got).all()
-    tol = 1e-3 + 1e-3 * want.abs() + want.abs() * 2.0 ** -10
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    tol = 1e-3 + 1e-3 * want.abs() + want.abs() * ulp
     assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
-    mask = torch.zeros(1, 1, 1, L, dtype=torch.float16, device="cuda")
+    mask = torch.zeros(1, 1, 1, L, dtype=dt, device="cuda")
     mask[..., pos + 1:] = float("-inf")
     ks = torch.nan_to_num(kc, nan=0.0).unsqueeze(0)
     vs = torch.nan_to_num(vc, nan=0.0).unsqueeze(0)
     sd = torch.nn.functional.scaled_dot_product_attention(q.view(1, n_heads, 1, hd), ks, vs, attn_mask=mask, scale=scaling, enable_gqa=(rep > 1))
-    torch.testing.assert_close(out.view(n_heads, hd).float(), sd.view(n_heads, hd).float(), rtol=2e-3, atol=2e-3)
+    tl = 2e-3 if dt == torch.float16 else 1.6e-2   # (SDPA rounds its probabilities to the tensors' dtype)
+    torch.testing.assert_close(out.view(n_heads, hd).float(), sd.view(n_heads, hd).float(), rtol=tl, atol=tl)
     again = torch.empty_like(out)
     ops.attn_decode(q, kc, vc, p, again, scaling)
     assert torch.equal(out, again)
 
 
 @pytest.mark.parametrize("n_heads,n_kv,hd,L,pos", [(32, 32, 128, 256, 0), (32, 32, 128, 256, 100), (32, 8, 128, 512, 511), (8, 2, 64, 128, 31), (4, 4, 256, 64, 9)])
-def test_rope_attn_decode_equals_rope_cache_then_attn_decode(n_heads, n_kv, hd, L, pos):
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_rope_attn_decode_equals_rope_cache_then_attn_decode(n_heads, n_kv, hd, L, pos, dt):
     """the one-launch form (rotary + cache write + attention) against the two launches it replaces: output and both caches bit for bit"""
     from hqq_amd import ops
     g = torch.Generator(device="cuda").manual_seed(pos + hd)
-    q = torch.randn(1, n_heads * hd, device="cuda", generator=g).half()
-    k = torch.randn(1, n_kv * hd, device="cuda", generator=g).half()
-    v = torch.randn(1, n_kv * hd, device="cuda", generator=g).half()
+    q = torch.randn(1, n_heads * hd, device="cuda", generator=g).to(dt)
+    k = torch.randn(1, n_kv * hd, device="cuda", generator=g).to(dt)
+    v = torch.randn(1, n_kv * hd, device="cuda", generator=g).to(dt)
     ang = torch.rand(hd // 2, device="cuda", generator=g) * 6.28
-    cos = torch.cat([ang.cos(), ang.cos()]).half()
-    sin = torch.cat([ang.sin(), ang.sin()]).half()
-    kc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
-    vc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).half()
+    cos = torch.cat([ang.cos(), ang.cos()]).to(dt)
+    sin = torch.cat([ang.sin(), ang.sin()]).to(dt)
+    kc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
+    vc0 = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
     kc0[:, pos:] = float("nan")   # position pos is written by the call; beyond it nothing may be read
     vc0[:, pos:] = float("nan")
     p = torch.tensor([pos], device="cuda")
     scaling = hd ** -0.5
     kc1, vc1 = kc0.clone(), vc0.clone()
-    qr = torch.empty(1, n_heads, 1, hd, dtype=torch.float16, device="cuda")
+    qr = torch.empty(1, n_heads, 1, hd, dtype=dt, device="cuda")
     ops.rope_cache(q, k, v, cos, sin, p, kc1, vc1, qr)
-    want = torch.empty(n_heads * hd, dtype=torch.float16, device="cuda")
+    want = torch.empty(n_heads * hd, dtype=dt, device="cuda")
     ops.attn_decode(qr, kc1, vc1, p, want, scaling)
     kc2, vc2 = kc0.clone(), vc0.clone()
     got = torch.empty_like(want)
@@ -328,3 +333,46 @@ def test_fused_decoder_with_the_decode_attention_kernel_stays_within_the_logit_t
             rows.append(step(a[:, ids.shape[1] + t:ids.shape[1] + t + 1], pos).float().clone())
         logits[mode] = torch.cat(rows)
     torch.testing.assert_close(logits["hip"], logits["sdpa"], rtol=5e-3, atol=5e-3)
+
+
+def test_fused_decoder_bf16():
+    """a bf16 model: the fused step (csrc/block.hip's bf16 arithmetic = torch's, the bf16 decode GEMVs) against the same model under
+    HQQBackend.PYTORCH_FORWARD — teacher-forced logits within the bf16 forward tolerance; the kernel-attention mode within the same of the sdpa mode"""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM, StaticCache
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear
+    from hqq_amd.utils import llama_fused
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=512, max_position_embeddings=128)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).cuda().eval()
+    quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.bfloat16, device="cuda")
+    ref_model = copy.deepcopy(model)
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    assert llama_fused.supports(model)
+    ids = torch.randint(0, 512, (1, 6), generator=torch.Generator().manual_seed(3)).cuda()
+    dec = GraphedGreedyDecoder(model, max_cache_len=64)
+    toks = dec.generate(ids, 24, use_graph=True)
+    assert dec.fused and dec.graph is not None and toks.shape == (1, 30)
+    HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+    try:
+        with torch.no_grad():
+            ref_logits = ref_model(toks[:, :-1]).logits.float()
+    finally:
+        HQQLinear.set_backend(HQQBackend.HIP)
+    logits = {}
+    for mode in ("sdpa", "hip"):
+        cache = StaticCache(config=model.config, max_cache_len=64)
+        with torch.no_grad():
+            model(ids, past_key_values=cache, cache_position=torch.arange(ids.shape[1], device="cuda"), use_cache=True)
+        step = llama_fused.FusedLlamaStep(model, cache, 64, attention=mode)
+        rows = [step(toks[:, ids.shape[1] + t:ids.shape[1] + t + 1], torch.tensor([ids.shape[1] + t], device="cuda")).float().clone() for t in range(20)]
+        logits[mode] = torch.cat(rows)
+    want = ref_logits[0, ids.shape[1]:ids.shape[1] + 20]
+    torch.testing.assert_close(logits["sdpa"], want, rtol=4e-2, atol=4e-2)
+    torch.testing.assert_close(logits["hip"], logits["sdpa"], rtol=4e-2, atol=4e-2)
