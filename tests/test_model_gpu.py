@@ -235,7 +235,7 @@ def _toy_llama_hip(nbits):
 
 
 @pytest.mark.parametrize("n_heads,n_kv,hd,L,pos", [(32, 32, 128, 256, 0), (32, 32, 128, 256, 17), (32, 32, 128, 256, 255), (32, 8, 128, 1024, 700),
-                                                  (16, 4, 64, 512, 511), (8, 8, 256, 300, 123), (64, 8, 128, 4096, 4000)])
+                                                  (16, 4, 64, 512, 511), (8, 8, 256, 300, 123), (64, 8, 128, 4096, 4000), (8, 2, 128, 20000, 19999)])   # (the last: > 48 KiB of LDS for the scores)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_decode_attention_kernel_against_fp64_softmax_attention_and_sdpa(n_heads, n_kv, hd, L, pos, dt):
     """hqq_hip_attn_decode (opt-in replacement of the SDPA call of a decode step): one query per head over the first pos + 1 cache positions —

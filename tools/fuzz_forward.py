@@ -24,7 +24,7 @@ def main():
         K = gs * rnd.randint(1, 40) if rnd.random() < 0.4 else 256 * rnd.randint(1, 24) if rnd.random() < 0.7 else 1024 * rnd.randint(8, 28)
         K = (K // gs) * gs or gs
         N = (per if nbits != 3 else 1) * (rnd.randint(1, 700) if K < 8192 else rnd.randint(1, 90))
-        M = rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 257, 300, 513, 700])
+        M = rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 257, 300, 513, 700, 2561, 3001])   # (beyond 2560: dequantise + in-tree dense GEMM)
         g = torch.Generator().manual_seed(it)
         R = N * K // gs
         U = torch.randint(0, 2 ** nbits, (R, gs), generator=g, dtype=torch.uint8)
