@@ -31,3 +31,6 @@ cat $OUT/bench_default.json | cut -c1-600
 cat $OUT/bench_prefill_65536.json | cut -c1-900
 cat gpurun_out/r4prof/pmc/pmc_summary.json
 cat $OUT/dense_clock.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -n 2 $OUT/smoke.txt
+python bench.py --workload decode70b --no-cpu-baseline --steps 10 --warmup 3 > $OUT/bench_decode70b_1gpu.json 2> $OUT/bench_decode70b_1gpu.err; cut -c1-500 $OUT/bench_decode70b_1gpu.json
+python bench.py --workload prefill --shapes 70b --prefill-tokens 8192 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prefill70b_8192.json 2> $OUT/bench_prefill70b_8192.err; cut -c1-700 $OUT/bench_prefill70b_8192.json
