@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void pack_u8_kernel(const IN* __restrict__ U, 
   else out[i0] = acc[0];
 }
 
-// pack: 3-bit into int32, VEC packed words per thread (4 or 1); slabs past `total` are the zero padding
+// pack: 3-bit into int32, VEC packed words per thread (16, 4 or 1); slabs past `total` are the zero padding.  VEC = 16: a slab's 16 levels in
+// one 16-byte load (four for float levels) — n is a multiple of 64, so every slab's run starts 16-byte aligned — and four 16-byte stores
 template <typename IN, int VEC>
 __global__ __launch_bounds__(256) void pack_3bit_kernel(const IN* __restrict__ U, int32_t* __restrict__ out, int64_t n, int64_t total) {
   const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * VEC;
@@ -68,14 +69,33 @@ __global__ __launch_bounds__(256) void pack_3bit_kernel(const IN* __restrict__ U
 #pragma unroll
   for (int s = 0; s < 10; ++s) {
     const int64_t e0 = static_cast<int64_t>(s) * n + i0;
+    if constexpr (VEC == 16) {
+      if (e0 + 15 < total) {
+        IN v[16];
+        if constexpr (sizeof(IN) == 1) {
+          *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(U + e0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(v)[q] = reinterpret_cast<const f32x4*>(U + e0)[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] |= level_of(v[j]) << (27 - 3 * s);
+        continue;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const uint32_t v = (e0 + j < total) ? level_of(U[e0 + j]) : 0u;
       acc[j] |= v << (27 - 3 * s);
     }
   }
+  if constexpr (VEC == 16) {
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) out[i0 + j] = static_cast<int32_t>(acc[j]);
+    for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(out + i0)[q] = u32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[i0 + j] = static_cast<int32_t>(acc[j]);
+  }
 }
 
 // =================================================================================================
@@ -163,7 +183,8 @@ static int launch_pack_u8(const void* U, void* out, int64_t n, hipStream_t st) {
 }
 template <typename IN>
 static int launch_pack_3(const void* U, void* out, int64_t n, int64_t total, hipStream_t st) {
-  if (n % 4 == 0) hipLaunchKernelGGL((pack_3bit_kernel<IN, 4>), grid_for(n, 4), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
+  if (n % 16 == 0 && aligned16(U) && aligned16(out)) hipLaunchKernelGGL((pack_3bit_kernel<IN, 16>), grid_for(n, 16), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
+  else if (n % 4 == 0) hipLaunchKernelGGL((pack_3bit_kernel<IN, 4>), grid_for(n, 4), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
   else hipLaunchKernelGGL((pack_3bit_kernel<IN, 1>), grid_for(n, 1), dim3(256), 0, st, static_cast<const IN*>(U), static_cast<int32_t*>(out), n, total);
   return check_launch("hqq_hip_pack");
 }
