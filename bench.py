@@ -650,7 +650,7 @@ def main():
         })
         ach = flops_per_step_rank / dev_sec_per_step / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                           "traffic": None, "kernel": route_kernel}
+                           "traffic": None, "kernel": route_kernel, "mfma_busy": _pmc_dense_busy()}
 
     # ---- the other shapes the metric names, same resident weights (N = 1, default decode only) ----
     if decode and world == 1 and not a.no_legs and not big and M == 1 and a.dtype == "f16" and S == 1 and nbits in (4, 2, 8):
@@ -898,6 +898,17 @@ def _solver_valu():
         with open(os.path.join(ROOT, "profiles", "solver_valu.json")) as f:
             return json.load(f)
     except (OSError, ValueError):
+        return None
+
+
+def _pmc_dense_busy():
+    """MFMA-busy share and effective clock of the dense GEMM from the committed PMC pass (profiles/pmc_traffic.json names the commit); None if absent."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+        return {"dense_gemm_kernel_8192x4096x4096": d["dense_gemm_8192x4096x4096"]["in_tree"], "commit": d.get("commit")}
+    except (OSError, ValueError, KeyError):
         return None
 
 
