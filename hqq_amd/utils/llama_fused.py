@@ -110,9 +110,9 @@ class FusedLlamaStep:
         self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=dt, device=dev)
         self.ar = torch.arange(max_cache_len, device=dev)
         # cos / sin of every cache position, from the model's own rotary module called once (elementwise in the position: the rows equal what a
-        # per-token call returns); rope types whose frequencies depend on the sequence length ("dynamic") keep the per-token call
+        # per-token call returns); rope types whose frequencies depend on the sequence length ("dynamic", "longrope") keep the per-token call
         self.cos_tab = self.sin_tab = None
-        if getattr(inner.rotary_emb, "rope_type", "default") in ("default", "linear", "llama3", "yarn", "longrope") and \
+        if getattr(inner.rotary_emb, "rope_type", "default") in ("default", "linear", "llama3", "yarn") and \
                 max_cache_len <= getattr(cfg, "max_position_embeddings", max_cache_len):
             with torch.no_grad():
                 c, s_ = inner.rotary_emb(torch.empty(1, 1, self.H, dtype=dt, device=dev), self.ar.view(1, -1))
