@@ -97,16 +97,8 @@ class HQQLinearHIP(nn.Module):
         if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
         rows = x.numel() // x.shape[-1]
-        if self.w3s:   # every M: GEMV / skinny GEMM on the stream layout, library GEMM on the restored weights beyond 64 rows (ops.forward)
-            return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, 3,
-                               opts=ops.layer_opts(self.opts))
-        if (self.compute_dtype == torch.bfloat16 or self.nbits == 3) and rows > 4 and \
-                not ops.skinny_covers(x.dtype, rows, self.out_features, self.in_features, self.group_size, self.nbits):
-            # bf16 / 3-bit beyond the decode kernels' 4 rows: HIP dequantise kernel + library GEMM
-            out = torch.matmul(x, self.dequantize().t())
-            if self.bias is not None:
-                out += self.bias
-            return out
+        # every number of rows through ops.forward: decode kernels, skinny GEMM, pipelined GEMM, and beyond them (long prompts, shapes the fused
+        # kernels do not cover) the dequantise kernel + the in-tree dense GEMM; a 3-bit layer in the stream layout says so in its option bits
         return ops.forward(x, self.W_q, self.scale, self.zero, self.bias, self.out_features, self.in_features, self.group_size, self.nbits,
                            opts=ops.layer_opts(self.opts))
 

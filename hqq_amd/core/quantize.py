@@ -428,27 +428,17 @@ class HQQLinear(nn.Module):
 
     # ---- forward methods named by HQQBackend ----
     def _fused_ok(self, x: Tensor) -> bool:
+        """fp16 / bf16 layers quantised along axis 1 go through hqq_amd.ops.forward for every number of rows: the fused kernels where they
+        cover the shape, the HIP dequantise kernel + the in-tree dense MFMA GEMM elsewhere (ops.forward decides).  Anything else —
+        fp32 compute dtype, axis 0, group sizes that are not multiples of 16, quantised meta — keeps the reference's dequantise + matmul"""
         m = self.meta
-        if not (m["axis"] == 1 and bool(m["group_size"]) and m["group_size"] % 16 == 0 and x.dtype == m["scale"].dtype):
-            return False
-        rows = x.numel() // x.shape[-1]
-        if x.dtype == float16:
-            if m["packing"] == "3bit_32":   # fused 3-bit kernel: decode-sized batches, group_size 64
-                return rows <= 4 and m["group_size"] == 64
-            if m["packing"] not in ("4bit_u8", "2bit_u8", "8bit_u8", "1bit_u8"):
-                return False
-            # 5..16 rows run on 16-row MFMA tiles over 64-k blocks: K must be a multiple of 64 (the row-per-wave kernel, <= 4 rows,
-            # and the library route, >= 17 rows, have no such condition)
-            return not (4 < rows <= ops.GEMV_MAX_M and m["shape"][1] % 64)
-        # bf16: the fused decode kernel covers 4-/2-bit up to 4 activation rows; everything else dequantises + library GEMM
-        if x.dtype != torch.bfloat16 or m["packing"] not in ("4bit_u8", "2bit_u8", "8bit_u8"):
-            return False
-        N, K = m["shape"]
-        return (rows <= 4 and m["packing"] != "8bit_u8") or ops.skinny_covers(x.dtype, rows, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]])
+        return (m["axis"] == 1 and bool(m["group_size"]) and m["group_size"] % 16 == 0 and x.dtype == m["scale"].dtype
+                and x.dtype in (float16, torch.bfloat16) and m["packing"] in ("8bit_u8", "4bit_u8", "3bit_32", "2bit_u8", "1bit_u8")
+                and x.is_cuda and self.W_q.is_cuda)
 
     def forward_hip(self, x: Tensor) -> Tensor:
-        """Fused unpack -> dequantize -> GEMV / GEMM (one launch).  Configurations the fused kernels do not cover run the
-        dequantise kernel + a library GEMM — still entirely on the GPU, never a CPU fallback."""
+        """Fused unpack -> dequantize -> GEMV / GEMM (one launch); shapes and prompt lengths the fused kernels do not cover run the HIP
+        dequantise kernel + the in-tree dense GEMM (hqq_amd.ops.forward) — entirely on the GPU, never a CPU fallback."""
         if torch.is_grad_enabled() and x.requires_grad:
             return _MatmulNoCache.apply(x, self._matmul_hip, self.bias)
         return self._matmul_hip(x, transpose=True, bias=self.bias)

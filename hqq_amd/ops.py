@@ -429,15 +429,16 @@ def _compose(x, W, bias, out, N, K, library: bool) -> Tensor:
 
 def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=None, opts=None, library_gemm: bool = False) -> Tensor:
     """y = x @ dequantize(W_q)^T (+ bias).  M <= 16 (<= 64 where the skinny-GEMM kernel applies): weight-streaming decode kernels;
-    larger M: fused MFMA dequant-GEMM, or — from LIBRARY_GEMM_MIN_M rows on, unless fused=True — dequantise kernel + library GEMM.
-    Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit beyond 4 rows,
+    larger M: fused MFMA dequant-GEMM to 2560 rows, beyond — and for what the fused kernels do not cover, unless fused=True — the dequantise
+    kernel + the in-tree dense MFMA GEMM (library_gemm=True: a library GEMM instead, the bench's comparison; also the residual route for
+    K % 64 != 0 or N % 4 != 0).  Same dequantised weights either way.  fused=None also composes the few decode-sized cases the kernels do not cover (3-bit beyond 4 rows,
     bf16 beyond 4 rows outside the skinny-GEMM kernel, 5..16 rows with K % 64 != 0); fused=True never composes: an uncovered configuration raises."""
     M = x.numel() // K if K else 0
     if x.dtype != scale.dtype or zero.dtype != scale.dtype or (bias is not None and bias.dtype != scale.dtype):
         raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
     if nbits == 3 and (_opts(opts) & OPT_W3S):
         # the 3-bit stream layout: the 4-bit container's kernels (1..4 rows: row-per-wave GEMV; 5..64: the skinny GEMM); beyond, the reference
-        # container is restored on the fly for the dequantise kernel + library GEMM (prefill of a patched 3-bit layer)
+        # container is restored on the fly for the dequantise kernel + dense GEMM (long prompts of a patched 3-bit layer)
         if M <= 4 or (M <= SKINNY_MAX_M and group_size == 64 and K % 256 == 0 and K >= 512 and x.dtype in (torch.float16, torch.bfloat16)) or fused or \
                 (fused is None and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(4, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):   # (asked as a 4-bit layer: same kernels, same plan)
             return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
