@@ -41,7 +41,7 @@ def main():
         lin = nn.Linear(K, N, bias=bias)
         cfg = BaseQuantizeConfig(nbits=nbits, group_size=gs, axis=1, view_as_float=rnd.random() < 0.2)
         layer = HQQLinear(lin, cfg, compute_dtype=dt, device="cuda")
-        shape = rnd.choice([(1,), (3,), (1, 1), (2, 5), (4, 8), (17,), (2, 32), (70,), (1, 4), (9,)])
+        shape = rnd.choice([(1,), (3,), (1, 1), (2, 5), (4, 8), (17,), (2, 32), (70,), (1, 4), (9,), (300,), (2, 1300)])
         x = torch.randn(*shape, K, device="cuda", dtype=dt)
         what = f"[{it}] int{nbits} {N}x{K} gs={gs} {str(dt)[6:]} bias={bias} vf={cfg['weight_quant_params']['view_as_float']} x{shape}"
         HQQLinear.set_backend(HQQBackend.PYTORCH)
