@@ -417,9 +417,16 @@ def dense_covers(dtype, N, K) -> bool:
     return dtype in (torch.float16, torch.bfloat16) and K % 64 == 0 and K >= 64 and N % 4 == 0
 
 
+# The dense kernel's 256 x 256 tiles leave most CUs idle below a few thousand rows (16 workgroups at 256 rows of a 4096-wide layer: 90 us where the
+# library's small-tile / split-K kernels take 40).  Layers the fused kernels cover never get there (they take the fused GEMM to 2560 rows); for
+# the others — group sizes other than 64, K % 128 != 0 — the composition keeps the library GEMM up to the same row count.
+DENSE_MIN_M = 2561
+
+
 def _compose(x, W, bias, out, N, K, library: bool) -> Tensor:
-    """the long-prompt route after the dequantise kernel: the in-tree MFMA GEMM, or (library=True, or a shape it does not cover) a library GEMM"""
-    if not library and dense_covers(x.dtype, N, K):
+    """the route after the dequantise kernel: the in-tree MFMA GEMM from DENSE_MIN_M rows on; a library GEMM below (only layers the fused kernels
+    do not cover get there), for shapes the in-tree kernel does not cover (K % 64 != 0, N % 4 != 0), or when asked for (library=True)"""
+    if not library and dense_covers(x.dtype, N, K) and x.numel() // K >= DENSE_MIN_M:
         return gemm_dense(x, W, bias, out=None if out is None else out.reshape(-1, N))
     y = torch.matmul(x.reshape(-1, K), W.t(), out=out)
     if bias is not None:
