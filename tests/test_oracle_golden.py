@@ -188,3 +188,29 @@ def test_one_solver_step_formula_matches_reference(name):
     assert np.array_equal(W_q.numpy().astype(np.uint8), g["W_q"])
     assert np.array_equal(W_r.numpy().view(np.uint32), g["W_r"].view(np.uint32))
     assert np.array_equal(zero_new.numpy().view(np.uint32), g["zero_out"].view(np.uint32))
+
+
+def test_w3s_stream_layout_matches_the_golden_fixture(oracle):
+    """the 3-bit stream layout (hqq_amd/csrc/w3s.h) as the oracle restates it, against tests/golden/w3s_layout.npz (written from the
+    REFERENCE's pack_3bit_32 container by tests/golden/make_w3s_golden.py): container -> layout and back, byte for byte; and the layout's
+    definition checked element by element on the smallest case (level (slab s, k) of a chunk where csrc/w3s.h says it is)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "w3s_layout.npz"))
+    for name in ("a", "b", "c"):
+        N, K = (int(v) for v in g[f"{name}_shape"])
+        ref, want = g[f"{name}_ref"], g[f"{name}_w3s"]
+        assert np.array_equal(oracle.pack(3, g[f"{name}_levels"]).view(np.int32), ref)
+        got = oracle.w3s_pack_np(ref, N, K)
+        assert got.shape == (N // 2, K // 16, 3) and np.array_equal(got.view(np.uint32), want)
+        assert np.array_equal(oracle.w3s_unpack_np(want, N, K).view(np.int32), ref)
+    N, K = (int(v) for v in g["a_shape"])
+    L = g["a_levels"].reshape(N, K)
+    D = g["a_w3s"]
+    for p_ in range(N // 2):
+        for c in range(K // 16):
+            for s_ in range(2):
+                for i in range(16):
+                    d, b = oracle.w3s_pos(s_, i)
+                    w = D[p_, c]
+                    lv = (int(w[d]) >> b) & 7 if d >= 0 else sum(((int(w[t]) >> b) & 1) << t for t in range(3))
+                    assert lv == int(L[p_ + s_ * (N // 2), 16 * c + i])

@@ -288,3 +288,19 @@ def test_patched_3bit_layer_keeps_the_reference_bytes(ops, oracle, dt):
     new.W_q.data.zero_()
     new.load_state_dict(sd)
     assert torch.equal(new.W_q.data, W3_before)
+
+
+def test_w3s_pack_kernel_matches_the_golden_fixture(ops):
+    """hqq_hip_w3s_pack / _unpack against tests/golden/w3s_layout.npz (the REFERENCE's container re-laid out by the oracle): byte for byte"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "w3s_layout.npz"))
+    for name in ("a", "b", "c"):
+        N, K = (int(v) for v in g[f"{name}_shape"])
+        ref = torch.from_numpy(g[f"{name}_ref"].copy()).cuda()
+        want = g[f"{name}_w3s"]
+        if not ops.w3s_covers(N, K, 64):
+            continue
+        got = ops.w3s_pack(ref, N, K)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32).reshape(want.shape), want)
+        back = ops.w3s_unpack(got, N, K)
+        assert np.array_equal(back.cpu().numpy().view(np.int32), g[f"{name}_ref"])
