@@ -214,30 +214,10 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   uint16_t* vnew = qs + 2 * HD;
   const int h = blockIdx.x, rep = n_heads / n_kv, kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint16_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
-  const uint16_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
-  // the kernel is a chain of memory round trips (position, rotary inputs, keys, values), ~1 us each: the first key of every lane and the first
-  // eight value rows of every wave are requested before anything else — whether they are needed (key < pos + 1) is known later; a cache row
-  // beyond the position is readable memory and is thrown away (the position's own row, which another workgroup may be writing, too)
-  constexpr int DPL = HD / 64;
-  constexpr int VPRE = 8;
-  constexpr bool KPRE = HD <= 128;   // (a 256-wide head's key row is 128 registers: no room)
-  u32x4 kpre[KPRE ? HD / 8 : 1];
-  if constexpr (KPRE) {
-    if (tid < L) {
-#pragma unroll
-      for (int c = 0; c < HD / 8; ++c) kpre[c] = reinterpret_cast<const u32x4*>(K + static_cast<int64_t>(tid) * HD)[c];
-    }
-  }
-  uint16_t vpre[VPRE][DPL];
-#pragma unroll
-  for (int u = 0; u < VPRE; ++u)
-    if (wave + 8 * u < L) {
-#pragma unroll
-      for (int d = 0; d < DPL; ++d) vpre[u][d] = V[static_cast<int64_t>(wave + 8 * u) * HD + DPL * lane + d];
-    }
   const int p0 = static_cast<int>(pos[0]);
   const int n = p0 + 1;
+  const uint16_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
+  const uint16_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
   if constexpr (ROPE) {
     // thread t < HD / 2: elements t and t + HD / 2 of the query; HD / 2 <= t < HD: of the new key; HD <= t < HD + HD / 8: a 16-byte chunk of the new value
     constexpr int half = HD / 2;
@@ -275,7 +255,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < HD / 8; ++c) {
-      const u32x4 kv = fresh ? reinterpret_cast<const u32x4*>(knew)[c] : ((KPRE && j == tid) ? kpre[KPRE ? c : 0] : kr[c]);
+      const u32x4 kv = fresh ? reinterpret_cast<const u32x4*>(knew)[c] : kr[c];
       const u32x4 qv = reinterpret_cast<const u32x4*>(qs)[c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -308,22 +288,11 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   __syncthreads();
   sum = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
   // phase 3: lane -> dims [DPL lane, DPL lane + DPL), DPL = HD / 64
+  constexpr int DPL = HD / 64;
   float o[DPL];
 #pragma unroll
   for (int d = 0; d < DPL; ++d) o[d] = 0.f;
   int j = wave;
-#pragma unroll
-  for (int u = 0; u < VPRE; ++u) {   // the value rows requested at the start
-    if (j < n) {
-      const float pj = sc[j];
-#pragma unroll
-      for (int d = 0; d < DPL; ++d) {
-        const uint16_t vv = (ROPE && j == p0) ? vnew[DPL * lane + d] : vpre[u][d];
-        o[d] = fmaf(pj, E::f(vv), o[d]);
-      }
-    }
-    j += 8;
-  }
   for (; j + 24 < n; j += 32) {   // four keys of this wave in flight
     uint16_t v4[4][DPL];
     float p4[4];
