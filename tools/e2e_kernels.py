@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The fused decode loop on a random Llama-shaped model with NB decoder blocks, T tokens, for rocprofv3 --kernel-trace (development aid; needs
 an MI355X): the kernel count per token / per decoder block comes from runs that differ in T and in NB.  The trace does not list the kernels of a
-hipGraph replay, so the step runs stream-ordered here (the same launches the graph captures).   python tools/e2e_kernels.py NB T"""
+hipGraph replay, so the step runs stream-ordered here (the same launches the graph captures).   python tools/e2e_kernels.py NB T [sdpa|hip]"""
 import sys
 
 import torch
@@ -15,6 +15,7 @@ from hqq_amd.utils.model import quantize_model  # noqa: E402
 from hqq_amd.utils.patching import prepare_for_inference  # noqa: E402
 
 NB, T = int(sys.argv[1]), int(sys.argv[2])
+ATT = sys.argv[3] if len(sys.argv) > 3 else "sdpa"
 torch.manual_seed(0)
 cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=NB, num_attention_heads=32, num_key_value_heads=32, vocab_size=32000,
                   max_position_embeddings=512, torch_dtype=torch.float16)
@@ -26,7 +27,7 @@ quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), comput
 prepare_for_inference(model, backend="hip")
 from hqq_amd.backends.hip import group_llama_projections  # noqa: E402
 group_llama_projections(model)
-dec = GraphedGreedyDecoder(model, max_cache_len=128)
+dec = GraphedGreedyDecoder(model, max_cache_len=128, attention=ATT)
 ids = torch.randint(0, 32000, (1, 16), device="cuda")
 out = dec.generate(ids, max_new_tokens=T, use_graph=False)
 torch.cuda.synchronize()

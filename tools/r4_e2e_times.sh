@@ -4,8 +4,8 @@ mkdir -p gpurun_out/r4
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/e2e_t
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_t -o t -- python $GRAFT_REPO_ROOT/tools/e2e_kernels.py 8 40 > /tmp/e2e_t.log 2>&1
-python - <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/r4/e2e_kernel_times.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_t -o t -- python $GRAFT_REPO_ROOT/tools/e2e_kernels.py 8 40 ${1:-sdpa} > /tmp/e2e_t.log 2>&1
+python - <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/r4/e2e_kernel_times_${1:-sdpa}.txt
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0, 0])
 for f in glob.glob("/tmp/e2e_t/**/*kernel_trace.csv", recursive=True):
