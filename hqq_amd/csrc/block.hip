@@ -12,7 +12,7 @@
 // And one that does NOT restate a kernel bit for bit (opt-in, FusedLlamaStep(attention="hip")):
 //   attn_decode   softmax(q K^T * scaling) V for ONE query per head over the static KV cache's first pos + 1 positions, fp32 scores / softmax /
 //                 accumulation, one rounding of the output: what F.scaled_dot_product_attention computes for a decode step, within
-//                 rounding of it (SDPA's flash kernel blocks the keys and rounds P to T; this one does neither) — ~4 us instead of the
+//                 rounding of it (SDPA's flash kernel blocks the keys and rounds P to T; this one does neither) — 8 us instead of the
 //                 12-15 us the library's prefill-shaped kernel takes for a single query (profiles/r04_e2e_kernel_times.txt)
 // Compiled with -ffp-contract=off: a fused multiply-add would remove a rounding HF's separate ops make.
 #include "hqq_common.h"
