@@ -6,7 +6,7 @@ cd /tmp
 for cfg in "2 8" "2 24" "4 24"; do
   set -- $cfg
   rm -rf /tmp/e2e_$1_$2
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_$1_$2 -o t -- python $GRAFT_REPO_ROOT/tools/e2e_kernels.py $1 $2 > /tmp/e2e_$1_$2.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/e2e_$1_$2 -o t -- python $GRAFT_REPO_ROOT/tools/e2e_kernels.py $1 $2 ${ATT:-sdpa} > /tmp/e2e_$1_$2.log 2>&1
   tail -n 1 /tmp/e2e_$1_$2.log
 done
 python - <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/r4/e2e_kernels_per_block.txt
