@@ -865,6 +865,16 @@ def main():
                                 "rope_cache + F.scaled_dot_product_attention in every block; "
                                 "teacher-forced logits within 5e-3 of the default step's (tests/test_model_gpu.py); the headline tok_s above is the token-identical default"}
                     del dec2
+                    # the static cache's length: HF's attention function attends over the whole cache behind a mask, the kernel over pos + 1 keys
+                    longc = {}
+                    for mode in ("sdpa", "hip"):
+                        d3 = GraphedGreedyDecoder(model, max_cache_len=2048, attention=mode)
+                        r3 = d3.benchmark(ids, new_tokens=32, warmup=4)
+                        longc[mode] = {"tok_s": round(r3["tok_s"], 2), "ms_per_token": round(r3["ms_per_token"], 4)}
+                        del d3
+                    out["end_to_end"]["max_cache_len"] = 256
+                    out["end_to_end"]["at_max_cache_len_2048"] = {"default_sdpa": longc["sdpa"], "with_decode_attention_kernel": longc["hip"],
+                                                                  "note": "same prompt and positions, only the static cache is longer"}
                 except Exception as e:
                     out["end_to_end"]["with_decode_attention_kernel"] = {"error": repr(e)}
                 del model, dec
