@@ -15,23 +15,36 @@ class GraphedGreedyDecoder:
     RMSNorm (+ the residual adds), rotary + KV-cache write and SiLU * up as one HIP kernel each around the grouped GEMVs, HF's own attention
     function on HF's cache: the same tokens in a third of the launches.  Any other model, or fused=False: the model's own forward."""
 
-    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa"):
+    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa", bucket_cache: bool = True):
         from transformers import StaticCache
         from . import llama_fused
         self.model = model.eval()
         self.fused = bool(fused) and llama_fused.supports(model)
         self._fused_mod = llama_fused
         self.attention = attention   # "sdpa": HF's attention function (token-identical to model(...)); "hip": the decode-attention kernel (faster, within rounding)
+        self.bucket_cache = bucket_cache   # attention="sdpa": attend over a bucket of the static cache just above the position (False: all of it)
         self.step = None
         self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
         self.max_cache_len = max_cache_len
         self._StaticCache = StaticCache
-        self.graph = None
+        self.graph = None      # the graph of the last step taken
+        self.graphs = {}       # attended cache length -> captured step
+
+    def _kv_len(self, p: int) -> int:
+        """how much of the static cache a step at position p attends over.  HF's attention function costs what it is given (the whole masked cache:
+        304 tok/s at 1024 positions, 119 at 4096, against 500 at 256), so the fused step hands it the smallest bucket 256 * 2^k above the
+        position and keeps one captured graph per bucket; the kernel attention reads pos + 1 keys by itself: one graph"""
+        if self.step is None or self.attention == "hip" or not self.bucket_cache:
+            return self.max_cache_len
+        b = 256
+        while b < p + 1:
+            b *= 2
+        return min(b, self.max_cache_len)
 
     @torch.no_grad()
-    def _decode_once(self):
+    def _decode_once(self, kv_len=None):
         if self.step is not None:
-            self.next_tok.copy_(self.step(self.tok, self.pos).argmax(-1, keepdim=True))
+            self.next_tok.copy_(self.step(self.tok, self.pos, kv_len).argmax(-1, keepdim=True))
             return
         out = self.model(self.tok, past_key_values=self.cache, cache_position=self.pos, use_cache=True)
         self.next_tok.copy_(out.logits[:, -1].argmax(-1, keepdim=True))
@@ -51,30 +64,38 @@ class GraphedGreedyDecoder:
         self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention) if self.fused else None
         toks = [self.tok.clone()]
         self.graph = None
+        self.graphs = {}
         for i in range(max_new_tokens - 1):
-            if use_graph and self.graph is None and i == 1:
-                # step 0 ran eagerly (lazy initialisation inside the model); capture the step once, replay it afterwards
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    snap = (self.tok.clone(), self.pos.clone())
-                    self._decode_once()                      # warm-up on the side stream (writes cache slot pos, re-written below)
-                    self.tok.copy_(snap[0]); self.pos.copy_(snap[1])
-                torch.cuda.current_stream().wait_stream(side)
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._decode_once()
-                # the capture itself does not execute: fall through and replay for this step
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self._decode_once()
-            self.tok.copy_(self.next_tok)
-            self.pos += 1
+            self._advance(T + i, use_graph and i >= 1)   # step 0 runs eagerly (lazy initialisation inside the model)
             toks.append(self.tok.clone())
         if self.step is not None:
             self.step.account_tokens(max_new_tokens - 1)
         return torch.cat([ids] + toks, dim=1)
+
+    @torch.no_grad()
+    def _advance(self, p: int, use_graph: bool) -> None:
+        """one decode step at position p (the host's copy of self.pos): replay the graph of p's cache bucket, capturing it first if need be"""
+        kv = self._kv_len(p)
+        g = self.graphs.get(kv) if use_graph else None
+        if use_graph and g is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                snap = (self.tok.clone(), self.pos.clone())
+                self._decode_once(kv)                    # warm-up on the side stream (writes cache slot pos, re-written below)
+                self.tok.copy_(snap[0]); self.pos.copy_(snap[1])
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_once(kv)
+            self.graphs[kv] = g                          # the capture itself does not execute: replay for this step
+        if g is not None:
+            g.replay()
+            self.graph = g
+        else:
+            self._decode_once(kv)
+        self.tok.copy_(self.next_tok)
+        self.pos += 1
 
     @torch.no_grad()
     def benchmark(self, input_ids: Tensor, new_tokens: int = 64, warmup: int = 8) -> dict:
@@ -83,20 +104,23 @@ class GraphedGreedyDecoder:
         assert input_ids.shape[0] == 1
         T = input_ids.shape[1]
         assert T + warmup + new_tokens + 4 <= self.max_cache_len
-        self.generate(input_ids, 3, use_graph=True)          # prefill + eager step + captured step (leaves self.graph, self.tok, self.pos)
+        self.generate(input_ids, 3, use_graph=True)          # prefill + eager step + captured step (leaves self.graphs, self.tok, self.pos)
         assert self.graph is not None
-
-        def step():
-            self.graph.replay()
-            self.tok.copy_(self.next_tok)
-            self.pos += 1
+        p = T + 2                                             # the host's copy of self.pos
         for _ in range(warmup):
-            step()
+            self._advance(p, True)
+            p += 1
+        for q in range(p, p + new_tokens):                    # buckets the timed steps will enter: captured before the clock starts
+            if self._kv_len(q) not in self.graphs:
+                snap = (self.tok.clone(), self.pos.clone())
+                self._advance(q, True)
+                self.tok.copy_(snap[0]); self.pos.copy_(snap[1])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(new_tokens):
-            step()
+            self._advance(p, True)
+            p += 1
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / new_tokens

@@ -126,8 +126,10 @@ class FusedLlamaStep:
         return ops.layer_opts((ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in Ls) else 0) | lay)
 
     @torch.no_grad()
-    def __call__(self, tok: Tensor, pos: Tensor) -> Tensor:
-        """tok [1, 1] int64, pos [1] int64 (its position; both on the device) -> logits [1, vocab] of the next token"""
+    def __call__(self, tok: Tensor, pos: Tensor, kv_len: int | None = None) -> Tensor:
+        """tok [1, 1] int64, pos [1] int64 (its position; both on the device) -> logits [1, vocab] of the next token.
+        kv_len (host integer > the position, default the whole cache): HF's attention function attends over the first kv_len cache positions only
+        (masked beyond pos as before) — its cost follows the length it is given, so a caller that knows the position passes a bucket just above it"""
         inner = self.inner
         h = self.h
         h.copy_(inner.embed_tokens(tok).view(1, self.H))
@@ -138,6 +140,8 @@ class FusedLlamaStep:
             cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
         if self.attention != "hip":
             torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
+        kvl = self.L if kv_len is None else min(int(kv_len), self.L)
+        mask = self.mask[..., :kvl]
         delta = None
         for b in self.blocks:
             at = b["attn"]
@@ -148,7 +152,7 @@ class FusedLlamaStep:
                 att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling)
             else:
                 ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
-                att, _ = self.attn_fn(at, b["qr"], b["kc"].unsqueeze(0), b["vc"].unsqueeze(0), self.mask, dropout=0.0, scaling=at.scaling)
+                att, _ = self.attn_fn(at, b["qr"], b["kc"][:, :kvl].unsqueeze(0), b["vc"][:, :kvl].unsqueeze(0), mask, dropout=0.0, scaling=at.scaling)
             o = b["o"]
             ops.gemv(att.reshape(1, -1), o.W_q, o.scale, o.zero, None, o.out_features, o.in_features, o.group_size, o.nbits, out=self.delta,
                      opts=ops.layer_opts(o.opts))

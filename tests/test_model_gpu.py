@@ -376,3 +376,30 @@ def test_fused_decoder_bf16():
     want = ref_logits[0, ids.shape[1]:ids.shape[1] + 20]
     torch.testing.assert_close(logits["sdpa"], want, rtol=4e-2, atol=4e-2)
     torch.testing.assert_close(logits["hip"], logits["sdpa"], rtol=4e-2, atol=4e-2)
+
+
+def test_cache_buckets_change_no_bit():
+    """the default attention mode attends over a bucket of the static cache just above the position (one captured graph per bucket) instead of
+    the whole masked cache: same logits bit for bit at every bucket length, and the same tokens across a bucket boundary"""
+    from transformers import StaticCache
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    from hqq_amd.utils.llama_fused import FusedLlamaStep
+    model = _toy_llama_hip(nbits=4)
+    ids = torch.randint(0, model.config.vocab_size, (1, 9), generator=torch.Generator().manual_seed(11)).cuda()
+    cache = StaticCache(config=model.config, max_cache_len=128)
+    with torch.no_grad():
+        out = model(ids, past_key_values=cache, cache_position=torch.arange(9, device="cuda"), use_cache=True)
+    step = FusedLlamaStep(model, cache, 128)
+    tok = out.logits[:, -1].argmax(-1, keepdim=True)
+    pos = torch.tensor([9], device="cuda")
+    whole = step(tok, pos).clone()
+    for kv in (16, 32, 64, 128):
+        assert torch.equal(step(tok, pos, kv), whole), kv
+    # across a boundary: the buckets are 256 * 2^k, so a 250-token prompt crosses the first one within a few steps
+    model.config.max_position_embeddings = 1024
+    long_ids = torch.randint(0, model.config.vocab_size, (1, 250), generator=torch.Generator().manual_seed(12)).cuda()
+    a = GraphedGreedyDecoder(model, max_cache_len=1024, bucket_cache=False).generate(long_ids, 16)
+    dec = GraphedGreedyDecoder(model, max_cache_len=1024)
+    b = dec.generate(long_ids, 16)
+    assert sorted(dec.graphs) == [256, 512]
+    assert torch.equal(a, b)
