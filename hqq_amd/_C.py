@@ -31,8 +31,9 @@ SYMBOLS = {
     "hqq_hip_add_rmsnorm": (_i32, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _i32, _vp]),
     "hqq_hip_rope_cache": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_silu_mul": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
-    "hqq_hip_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _vp]),
-    "hqq_hip_rope_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _vp]),
+    "hqq_hip_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _i64, _vp, _sz, _vp]),
+    "hqq_hip_rope_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _i64, _vp, _sz, _vp]),
+    "hqq_hip_attn_decode_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),

@@ -203,7 +203,8 @@ template <int HD, bool ROPE, bool BF>
 __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc_in, const uint16_t* __restrict__ vc_in,
                                                           const int64_t* __restrict__ pos, uint16_t* __restrict__ out, int n_heads, int n_kv, int L, float scaling,
                                                           const uint16_t* __restrict__ k_raw, const uint16_t* __restrict__ v_raw, const uint16_t* __restrict__ cosv,
-                                                          const uint16_t* __restrict__ sinv, uint16_t* __restrict__ kc_out, uint16_t* __restrict__ vc_out) {
+                                                          const uint16_t* __restrict__ sinv, uint16_t* __restrict__ kc_out, uint16_t* __restrict__ vc_out,
+                                                          int S, float* __restrict__ ws) {
   using E = El<BF>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [16] reduction scratch
@@ -212,10 +213,15 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   float* sc = part + 8 * HD;                                    // [n] scores, then probabilities
   uint16_t* knew = qs + HD;
   uint16_t* vnew = qs + 2 * HD;
-  const int h = blockIdx.x, rep = n_heads / n_kv, kvh = h / rep;
+  const int h = blockIdx.x, sp = blockIdx.y, rep = n_heads / n_kv, kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p0 = static_cast<int>(pos[0]);
   const int n = p0 + 1;
+  // S > 1 (long caches): workgroup (h, sp) attends over keys [k0, k1), a 1 / S share of the pos + 1 visible ones, and parks (max, sum,
+  // unnormalised output) in the workspace; attn_combine_kernel merges the S shares in split order.  One workgroup per head streams 0.8 TB/s:
+  // 76 us at 4096 keys; eight per head 14
+  const int chunk = (n + S - 1) / S;
+  const int k0 = sp * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
   const uint16_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;
   const uint16_t* V = vc_in + static_cast<int64_t>(kvh) * L * HD;
   if constexpr (ROPE) {
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       uint16_t* dst = is_k ? knew : qs;
       dst[i] = o1;
       dst[i + half] = o2;
-      if (is_k && h % rep == 0) {
+      if (is_k && h % rep == 0 && sp == 0) {
         uint16_t* kd = kc_out + (static_cast<int64_t>(kvh) * L + p0) * HD;
         kd[i] = o1;
         kd[i + half] = o2;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       const int c = tid - HD;
       const u32x4 vv = reinterpret_cast<const u32x4*>(v_raw + static_cast<int64_t>(kvh) * HD)[c];
       reinterpret_cast<u32x4*>(vnew)[c] = vv;
-      if (h % rep == 0) reinterpret_cast<u32x4*>(vc_out + (static_cast<int64_t>(kvh) * L + p0) * HD)[c] = vv;
+      if (h % rep == 0 && sp == 0) reinterpret_cast<u32x4*>(vc_out + (static_cast<int64_t>(kvh) * L + p0) * HD)[c] = vv;
     }
   } else {
     if (tid < HD / 8) reinterpret_cast<u32x4*>(qs)[tid] = reinterpret_cast<const u32x4*>(q + static_cast<int64_t>(h) * HD)[tid];
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   typedef __bf16 b2 __attribute__((ext_vector_type(2)));
   // phase 1
   float mx = -INFINITY;
-  for (int j = tid; j < n; j += 512) {
+  for (int j = k0 + tid; j < k1; j += 512) {
     const u32x4* kr = reinterpret_cast<const u32x4*>(K + static_cast<int64_t>(j) * HD);
     const bool fresh = ROPE && j == p0;   // the new key: from LDS, the cache row is being written by another workgroup
     float acc = 0.f;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       }
     }
     const float sv = acc * scaling;
-    sc[j] = sv;
+    sc[j - k0] = sv;
     mx = fmaxf(mx, sv);
   }
 #pragma unroll
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   for (int w = 1; w < 8; ++w) mx = fmaxf(mx, red[w]);
   // phase 2
   float sum = 0.f;
-  for (int j = tid; j < n; j += 512) {
+  for (int j = tid; j < k1 - k0; j += 512) {
     const float pj = __expf(sc[j] - mx);
     sc[j] = pj;
     sum += pj;
@@ -292,8 +298,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   float o[DPL];
 #pragma unroll
   for (int d = 0; d < DPL; ++d) o[d] = 0.f;
-  int j = wave;
-  for (; j + 24 < n; j += 32) {   // four keys of this wave in flight
+  int j = k0 + wave;
+  for (; j + 24 < k1; j += 32) {   // four keys of this wave in flight
     uint16_t v4[4][DPL];
     float p4[4];
 #pragma unroll
@@ -301,16 +307,16 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       const uint16_t* vr = (ROPE && j + 8 * u == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
 #pragma unroll
       for (int d = 0; d < DPL; ++d) v4[u][d] = vr[d];
-      p4[u] = sc[j + 8 * u];
+      p4[u] = sc[j + 8 * u - k0];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], E::f(v4[u][d]), o[d]);
   }
-  for (; j < n; j += 8) {
+  for (; j < k1; j += 8) {
     const uint16_t* vr = (ROPE && j == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j) * HD + DPL * lane;
-    const float pj = sc[j];
+    const float pj = sc[j - k0];
 #pragma unroll
     for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, E::f(vr[d]), o[d]);
   }
@@ -321,8 +327,33 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) t += part[w * HD + tid];
-    out[static_cast<int64_t>(h) * HD + tid] = E::r(t / sum);
+    if (S == 1) {
+      out[static_cast<int64_t>(h) * HD + tid] = E::r(t / sum);
+    } else {
+      float* rec = ws + (static_cast<int64_t>(h) * S + sp) * (HD + 2);   // (an empty share leaves max = -inf, sum = 0, output 0)
+      rec[2 + tid] = t;
+      if (tid == 0) { rec[0] = mx; rec[1] = sum; }
+    }
   }
+}
+
+// ---- the S shares of a head, merged in split order: out = sum_s e^(m_s - m) o_s / sum_s e^(m_s - m) l_s ----
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, uint16_t* __restrict__ out, int S, int HD) {
+  using E = El<BF>;
+  const int h = blockIdx.x, d = threadIdx.x;
+  if (d >= HD) return;
+  const float* rec = ws + static_cast<int64_t>(h) * S * (HD + 2);
+  float m = -INFINITY;
+  for (int s_ = 0; s_ < S; ++s_) m = fmaxf(m, rec[s_ * (HD + 2)]);
+  float num = 0.f, den = 0.f;
+  for (int s_ = 0; s_ < S; ++s_) {
+    const float* r_ = rec + s_ * (HD + 2);
+    const float w = r_[1] > 0.f ? __expf(r_[0] - m) : 0.f;
+    num = fmaf(w, r_[2 + d], num);
+    den = fmaf(w, r_[1], den);
+  }
+  out[static_cast<int64_t>(h) * HD + d] = E::r(num / den);
 }
 
 }  // namespace hqq
@@ -390,7 +421,7 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
 
 static int attn_decode_run(const char* who, bool rope, const void* q, const void* k_raw, const void* v_raw, const void* cosv, const void* sinv, const int64_t* pos_dev,
                            void* k_cache, void* v_cache, void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype,
-                           void* stream) {
+                           int64_t splits, void* workspace, size_t workspace_bytes, void* stream) {
   clear_stale_error();
   if (!block_dtype_ok(dtype, who)) return HQQ_ERR_UNSUPPORTED;
   if (!q || !k_cache || !v_cache || !pos_dev || !out || (rope && (!k_raw || !v_raw || !cosv || !sinv)) || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads ||
@@ -404,8 +435,15 @@ static int attn_decode_run(const char* who, bool rope, const void* q, const void
     return HQQ_ERR_ALIGN;
   }
   const int HD = static_cast<int>(head_dim);
-  const int lds = 64 + HD * 6 + 8 * HD * 4 + static_cast<int>(cache_len) * 4;
-  const dim3 grid(static_cast<unsigned>(n_heads)), block(512);
+  if (splits < 1 || splits > 64) { set_error("%s: splits must be 1..64 (got %lld)", who, (long long)splits); return HQQ_ERR_SHAPE; }
+  const int S = static_cast<int>(splits);
+  if (S > 1 && (!workspace || workspace_bytes < static_cast<size_t>(n_heads) * S * (HD + 2) * sizeof(float))) {
+    set_error("%s: %lld splits need a workspace of hqq_hip_attn_decode_workspace_bytes(...) bytes", who, (long long)splits);
+    return HQQ_ERR_SHAPE;
+  }
+  float* wsf = static_cast<float*>(workspace);
+  const int lds = 64 + HD * 6 + 8 * HD * 4 + static_cast<int>((cache_len + S - 1) / S + 8) * 4;
+  const dim3 grid(static_cast<unsigned>(n_heads), static_cast<unsigned>(S)), block(512);
   static LdsRaised raised[12];
   constexpr int LDS_MAX = 64 + 256 * 6 + 8 * 256 * 4 + 30000 * 4;
 #define HQQ_ATTN_GO(HDV, RP, BFV, IDX)                                                                                                     \
@@ -415,7 +453,7 @@ static int attn_decode_run(const char* who, bool rope, const void* q, const void
     hipLaunchKernelGGL((attn_decode_kernel<HDV, RP, BFV>), grid, block, lds, as_stream(stream), static_cast<cu16>(q), static_cast<cu16>(k_cache), \
                        static_cast<cu16>(v_cache), pos_dev, static_cast<u16>(out), static_cast<int>(n_heads), static_cast<int>(n_kv_heads),  \
                        static_cast<int>(cache_len), scaling, static_cast<cu16>(k_raw), static_cast<cu16>(v_raw),                            \
-                       static_cast<cu16>(cosv), static_cast<cu16>(sinv), static_cast<u16>(k_cache), static_cast<u16>(v_cache));             \
+                       static_cast<cu16>(cosv), static_cast<cu16>(sinv), static_cast<u16>(k_cache), static_cast<u16>(v_cache), S, wsf);    \
   } while (0)
 #define HQQ_ATTN_HD(RP, BFV, BASE)                                                                                                         \
   do {                                                                                                                                     \
@@ -430,18 +468,28 @@ static int attn_decode_run(const char* who, bool rope, const void* q, const void
   else HQQ_ATTN_HD(false, false, 9);
 #undef HQQ_ATTN_HD
 #undef HQQ_ATTN_GO
+  if (S > 1) {
+    if (bf) hipLaunchKernelGGL(attn_combine_kernel<true>, dim3(static_cast<unsigned>(n_heads)), dim3(256), 0, as_stream(stream), wsf, static_cast<u16>(out), S, HD);
+    else hipLaunchKernelGGL(attn_combine_kernel<false>, dim3(static_cast<unsigned>(n_heads)), dim3(256), 0, as_stream(stream), wsf, static_cast<u16>(out), S, HD);
+  }
   return check_launch(who);
 }
 
+size_t hqq_hip_attn_decode_workspace_bytes(int64_t n_heads, int64_t head_dim, int64_t splits) {
+  return splits > 1 ? static_cast<size_t>(n_heads) * static_cast<size_t>(splits) * static_cast<size_t>(head_dim + 2) * sizeof(float) : 0;
+}
+
 int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
-                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
+                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, int64_t splits, void* workspace, size_t workspace_bytes, void* stream) {
   return attn_decode_run("hqq_hip_attn_decode", false, q, nullptr, nullptr, nullptr, nullptr, pos_dev, const_cast<void*>(k_cache), const_cast<void*>(v_cache), out,
-                         n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, stream);
+                         n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, splits, workspace, workspace_bytes, stream);
 }
 
 int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache, void* out,
-                             int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream) {
-  return attn_decode_run("hqq_hip_rope_attn_decode", true, q, k, v, cos, sin, pos_dev, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype, stream);
+                             int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, int64_t splits, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return attn_decode_run("hqq_hip_rope_attn_decode", true, q, k, v, cos, sin, pos_dev, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype,
+                         splits, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

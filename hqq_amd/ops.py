@@ -583,27 +583,45 @@ def rope_cache(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: T
     return q_out
 
 
-def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, pos: Tensor, out: Tensor, scaling: float) -> Tensor:
-    """one query per head against the static KV cache's first pos + 1 positions (fp16; within rounding of SDPA, not bit-identical):
-    q [n_heads, hd] (any view of n_heads * hd contiguous values), k_cache / v_cache [n_kv, cache_len, hd], pos int64[1] on the device, out [n_heads * hd]"""
+def attn_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, pos: Tensor, out: Tensor, scaling: float, splits: int = 1, workspace: Tensor | None = None) -> Tensor:
+    """one query per head against the static KV cache's first pos + 1 positions (fp16 / bf16; within rounding of SDPA, not bit-identical):
+    q [n_heads, hd] (any view of n_heads * hd contiguous values), k_cache / v_cache [n_kv, cache_len, hd], pos int64[1] on the device, out [n_heads * hd];
+    splits > 1: the keys of a head shared out over that many workgroups + a merging launch (long caches; attn_splits / attn_workspace)"""
     _dev(q, k_cache, v_cache, pos, out)
     n_kv, L, hd = k_cache.shape
     n_heads = q.numel() // hd
+    if splits > 1 and workspace is None:
+        workspace = attn_workspace(q.device, n_heads, hd, splits)
     with torch.cuda.device(q.device):
-        rc = _C.lib().hqq_hip_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(pos), _p(out), n_heads, n_kv, hd, L, float(scaling), _dt(q.dtype), _stream())
+        rc = _C.lib().hqq_hip_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(pos), _p(out), n_heads, n_kv, hd, L, float(scaling), _dt(q.dtype),
+                                          int(splits), _p(workspace), 0 if workspace is None else workspace.numel(), _stream())
     _C.check(rc, "hqq_hip_attn_decode")
     return out
 
 
-def rope_attn_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: Tensor, k_cache: Tensor, v_cache: Tensor, out: Tensor, scaling: float) -> Tensor:
+def attn_splits(kv_len: int) -> int:
+    """how many workgroups share a head's keys in the decode-attention kernel when up to kv_len of them are visible (1: no second launch)"""
+    return 1 if kv_len <= 1024 else min(16, int(kv_len) // 512)
+
+
+def attn_workspace(device, n_heads: int, head_dim: int, splits: int):
+    """the (uninitialised) record buffer of a split launch, or None"""
+    nb = int(_C.lib().hqq_hip_attn_decode_workspace_bytes(int(n_heads), int(head_dim), int(splits)))
+    return torch.empty(nb, dtype=torch.uint8, device=device) if nb else None
+
+
+def rope_attn_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, pos: Tensor, k_cache: Tensor, v_cache: Tensor, out: Tensor, scaling: float,
+                     splits: int = 1, workspace: Tensor | None = None) -> Tensor:
     """rope_cache + attn_decode in one launch: raw q / k / v projections in, rotary applied in the kernel, the new key / value used from on-chip
     memory and written to the cache at `pos` for the following steps (the cache ends up bit-identical to rope_cache's)"""
     _dev(q, k, v, cos, sin, pos, k_cache, v_cache, out)
     n_kv, L, hd = k_cache.shape
     n_heads = q.numel() // hd
+    if splits > 1 and workspace is None:
+        workspace = attn_workspace(q.device, n_heads, hd, splits)
     with torch.cuda.device(q.device):
         rc = _C.lib().hqq_hip_rope_attn_decode(_p(q), _p(k), _p(v), _p(cos), _p(sin), _p(pos), _p(k_cache), _p(v_cache), _p(out), n_heads, n_kv, hd, L,
-                                                float(scaling), _dt(q.dtype), _stream())
+                                                float(scaling), _dt(q.dtype), int(splits), _p(workspace), 0 if workspace is None else workspace.numel(), _stream())
     _C.check(rc, "hqq_hip_rope_attn_decode")
     return out
 

@@ -33,10 +33,11 @@ class GraphedGreedyDecoder:
     def _kv_len(self, p: int) -> int:
         """how much of the static cache a step at position p attends over.  HF's attention function costs what it is given (the whole masked cache:
         304 tok/s at 1024 positions, 119 at 4096, against 500 at 256), so the fused step hands it the smallest bucket 256 * 2^k above the
-        position and keeps one captured graph per bucket; the kernel attention reads pos + 1 keys by itself: one graph"""
-        if self.step is None or self.attention == "hip" or not self.bucket_cache:
+        position and keeps one captured graph per bucket; the kernel attention reads pos + 1 keys by itself and uses the bucket only to decide
+        how many workgroups share a head's keys (one up to 1024 keys)"""
+        if self.step is None or not self.bucket_cache:
             return self.max_cache_len
-        b = 256
+        b = 1024 if self.attention == "hip" else 256   # (the kernel attention only changes its launch shape beyond 1024 visible keys)
         while b < p + 1:
             b *= 2
         return min(b, self.max_cache_len)

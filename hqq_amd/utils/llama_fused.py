@@ -105,6 +105,7 @@ class FusedLlamaStep:
         self.xn = torch.empty(1, self.H, dtype=dt, device=dev)      # its normalised copy, input of the next linears
         self.delta = torch.empty(1, self.H, dtype=dt, device=dev)   # output of o / down, added by the next add_rmsnorm
         self.att = torch.empty(1, self.n_heads * self.hd, dtype=dt, device=dev)   # attention output (attention="hip")
+        self.attn_ws = {}                                                          # splits -> record buffer of the split attention launches
         # the causal mask of one query over the static cache, in the additive form SDPA turns a boolean mask into on every call
         # (where(mask, 0, -inf) in the query dtype): built once per token here instead of once per decoder block inside the attention function
         self.mask = torch.zeros(1, 1, 1, max_cache_len, dtype=dt, device=dev)
@@ -142,6 +143,9 @@ class FusedLlamaStep:
             torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
         kvl = self.L if kv_len is None else min(int(kv_len), self.L)
         mask = self.mask[..., :kvl]
+        splits = ops.attn_splits(kvl) if self.attention == "hip" else 1   # (kernel attention: kv_len only picks how many workgroups share a head)
+        if splits > 1 and splits not in self.attn_ws:
+            self.attn_ws[splits] = ops.attn_workspace(self.device, self.n_heads, self.hd, splits)
         delta = None
         for b in self.blocks:
             at = b["attn"]
@@ -149,7 +153,8 @@ class FusedLlamaStep:
             K = self.H
             ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
             if self.attention == "hip":   # rotary + cache write + attention: one launch
-                att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling)
+                att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling, splits=splits,
+                                           workspace=self.attn_ws.get(splits))
             else:
                 ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
                 att, _ = self.attn_fn(at, b["qr"], b["kc"][:, :kvl].unsqueeze(0), b["vc"][:, :kvl].unsqueeze(0), mask, dropout=0.0, scaling=at.scaling)

@@ -193,13 +193,18 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
  * q [n_heads, head_dim] (rotary already applied), k_cache / v_cache [n_kv_heads, cache_len, head_dim], out [n_heads, head_dim]; fp16 / bf16;
  * head_dim 64 / 128 / 256; cache_len <= 30000; pos_dev: the query's position in device memory (graph-replay safe). */
 int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
-                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
+                        int64_t head_dim, int64_t cache_len, float scaling, int dtype, int64_t splits, void* workspace, size_t workspace_bytes, void* stream);
+/* splits: 1 = one workgroup per query head (caches of up to ~1000 positions: 3.5-5.5 us); > 1 (at most 64): every head's visible keys are shared
+ * out over `splits` workgroups whose (max, sum, output) records a second small launch merges in split order (long caches: 77 -> 14 us at 4096
+ * positions with 8) — `workspace` then holds hqq_hip_attn_decode_workspace_bytes(n_heads, head_dim, splits) bytes (caller-owned, no initialisation). */
+size_t hqq_hip_attn_decode_workspace_bytes(int64_t n_heads, int64_t head_dim, int64_t splits);
 /* The same with hqq_hip_rope_cache folded in: q / k / v are the RAW projections ([n_heads, head_dim], [n_kv_heads, head_dim] twice), cos / sin
  * [head_dim]; every workgroup rotates its query and its KV head's new key (hqq_hip_rope_cache's arithmetic, rounding for rounding), takes the new
  * key / value from on-chip memory for position pos and reads the cache only below it; the new key / value are written to the cache (by one workgroup
  * per KV head) for the following steps: the cache ends up bit-identical to what hqq_hip_rope_cache writes. */
 int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* k_cache, void* v_cache,
-                             void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, void* stream);
+                             void* out, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, float scaling, int dtype, int64_t splits,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* workspace of hqq_hip_forward / hqq_hip_gemm for one layer at M rows (0 = none needed, workspace may be NULL): the decode kernels'
  * (hqq_hip_gemv_workspace_bytes) up to HQQ_GEMV_MAX_M_SKINNY rows, the split-K fused GEMM's fp32 partial tiles beyond.  Same contract. */

@@ -403,3 +403,49 @@ def test_cache_buckets_change_no_bit():
     b = dec.generate(long_ids, 16)
     assert sorted(dec.graphs) == [256, 512]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n_heads,n_kv,hd,L,pos,splits", [(32, 32, 128, 4096, 4000, 8), (32, 8, 128, 4096, 37, 8), (8, 8, 64, 2048, 2047, 4), (8, 2, 256, 1024, 700, 3),
+                                                         (4, 4, 128, 512, 0, 16)])
+def test_decode_attention_with_the_keys_shared_out_over_workgroups(n_heads, n_kv, hd, L, pos, splits, dt):
+    """splits > 1: a head's visible keys shared out over several workgroups and merged by a second launch — against float64 softmax attention, against
+    the one-workgroup form, with most shares empty (pos << cache), and the rotary form against rope_cache + attn_decode at the same split count"""
+    from hqq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(pos + splits)
+    q = torch.randn(n_heads, hd, device="cuda", generator=g).to(dt)
+    kc = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
+    vc = torch.randn(n_kv, L, hd, device="cuda", generator=g).to(dt)
+    kc[:, pos + 1:] = float("nan")
+    vc[:, pos + 1:] = float("nan")
+    p = torch.tensor([pos], device="cuda")
+    scaling = hd ** -0.5
+    one = torch.empty(n_heads * hd, dtype=dt, device="cuda")
+    many = torch.full_like(one, float("nan"))
+    ops.attn_decode(q, kc, vc, p, one, scaling)
+    ops.attn_decode(q, kc, vc, p, many, scaling, splits=splits)
+    rep = n_heads // n_kv
+    kk = kc[:, :pos + 1].repeat_interleave(rep, 0).double()
+    vv = vc[:, :pos + 1].repeat_interleave(rep, 0).double()
+    want = torch.einsum("hj,hjd->hd", torch.softmax(torch.einsum("hd,hjd->hj", q.double(), kk) * scaling, -1), vv)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    tol = 1e-3 + 1e-3 * want.abs() + want.abs() * ulp
+    assert torch.isfinite(many).all()
+    assert bool(((many.view(n_heads, hd).double() - want).abs() <= tol).all())
+    assert bool(((many.double() - one.double()).abs() <= 2 * ulp * one.double().abs() + 1e-3).all())
+    # the rotary form at the same split count
+    qraw = torch.randn(1, n_heads * hd, device="cuda", generator=g).to(dt)
+    kraw = torch.randn(1, n_kv * hd, device="cuda", generator=g).to(dt)
+    vraw = torch.randn(1, n_kv * hd, device="cuda", generator=g).to(dt)
+    ang = torch.rand(hd // 2, device="cuda", generator=g) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()]).to(dt), torch.cat([ang.sin(), ang.sin()]).to(dt)
+    kc[:, pos:] = float("nan")
+    vc[:, pos:] = float("nan")
+    kc1, vc1, kc2, vc2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    qr = torch.empty(1, n_heads, 1, hd, dtype=dt, device="cuda")
+    ops.rope_cache(qraw, kraw, vraw, cos, sin, p, kc1, vc1, qr)
+    a = torch.empty_like(one)
+    b = torch.empty_like(one)
+    ops.attn_decode(qr, kc1, vc1, p, a, scaling, splits=splits)
+    ops.rope_attn_decode(qraw, kraw, vraw, cos, sin, p, kc2, vc2, b, scaling, splits=splits)
+    assert torch.equal(a, b) and torch.equal(kc1[:, :pos + 1], kc2[:, :pos + 1]) and torch.equal(vc1[:, :pos + 1], vc2[:, :pos + 1])
