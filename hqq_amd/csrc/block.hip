@@ -293,35 +293,44 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   if (lane == 0) red[8 + wave] = sum;
   __syncthreads();
   sum = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
-  // phase 3: lane -> dims [DPL lane, DPL lane + DPL), DPL = HD / 64
-  constexpr int DPL = HD / 64;
-  float o[DPL];
+  // phase 3: a wave instruction covers KPW = 512 / HD value rows: LPK = HD / 8 lanes per row, 16 bytes (8 dims) per lane; a wave takes rows
+  //          k0 + KPW wave + sub, stepping 8 KPW, four instructions in flight; the KPW row groups of a wave are added by shuffles
+  constexpr int LPK = HD / 8, KPW = 64 / LPK;
+  const int sub = lane / LPK, ch = lane - sub * LPK;
+  float o8[8];
 #pragma unroll
-  for (int d = 0; d < DPL; ++d) o[d] = 0.f;
-  int j = k0 + wave;
-  for (; j + 24 < k1; j += 32) {   // four keys of this wave in flight
-    uint16_t v4[4][DPL];
+  for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+  auto vrow = [&](int j) -> u32x4 {
+    const uint16_t* vr = (ROPE && j == p0) ? vnew : V + static_cast<int64_t>(j) * HD;
+    return reinterpret_cast<const u32x4*>(vr)[ch];
+  };
+  auto fold = [&](const u32x4& v, float pj) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = v[e];   // (element copied to a scalar before its halves are taken)
+      o8[2 * e] = fmaf(pj, E::f(static_cast<uint16_t>(w & 0xFFFFu)), o8[2 * e]);
+      o8[2 * e + 1] = fmaf(pj, E::f(static_cast<uint16_t>(w >> 16)), o8[2 * e + 1]);
+    }
+  };
+  constexpr int STEP = 8 * KPW;
+  int j = k0 + wave * KPW + sub;
+  for (; j + 3 * STEP < k1; j += 4 * STEP) {
+    u32x4 v4[4];
     float p4[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint16_t* vr = (ROPE && j + 8 * u == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j + 8 * u) * HD + DPL * lane;
+    for (int u = 0; u < 4; ++u) { v4[u] = vrow(j + u * STEP); p4[u] = sc[j + u * STEP - k0]; }
 #pragma unroll
-      for (int d = 0; d < DPL; ++d) v4[u][d] = vr[d];
-      p4[u] = sc[j + 8 * u - k0];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int d = 0; d < DPL; ++d) o[d] = fmaf(p4[u], E::f(v4[u][d]), o[d]);
+    for (int u = 0; u < 4; ++u) fold(v4[u], p4[u]);
   }
-  for (; j < k1; j += 8) {
-    const uint16_t* vr = (ROPE && j == p0) ? vnew + DPL * lane : V + static_cast<int64_t>(j) * HD + DPL * lane;
-    const float pj = sc[j - k0];
+  for (; j < k1; j += STEP) fold(vrow(j), sc[j - k0]);
 #pragma unroll
-    for (int d = 0; d < DPL; ++d) o[d] = fmaf(pj, E::f(vr[d]), o[d]);
+  for (int off = LPK; off < 64; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] += __shfl_xor(o8[e], off, 64);
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave * HD + ch * 8 + e] = o8[e];
   }
-#pragma unroll
-  for (int d = 0; d < DPL; ++d) part[wave * HD + DPL * lane + d] = o[d];
   __syncthreads();
   if (tid < HD) {
     float t = 0.f;
