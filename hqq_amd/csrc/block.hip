@@ -253,26 +253,51 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   __syncthreads();
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  // phase 1
-  float mx = -INFINITY;
-  for (int j = k0 + tid; j < k1; j += 512) {
-    const u32x4* kr = reinterpret_cast<const u32x4*>(K + static_cast<int64_t>(j) * HD);
-    const bool fresh = ROPE && j == p0;   // the new key: from LDS, the cache row is being written by another workgroup
+  // phase 1: like phase 3 below, a wave instruction covers KPW = 512 / HD whole key rows (LPK = HD / 8 lanes per row, 16 bytes per lane:
+  //          1 KiB of consecutive memory) — a lane per key read 64 different lines per instruction and thrashed the L1;
+  //          the LPK partial dot products of a row are added by shuffles
+  constexpr int LPK = HD / 8, KPW = 64 / LPK, STEP = 8 * KPW;
+  const int sub = lane / LPK, ch = lane - sub * LPK;
+  const u32x4 qf = reinterpret_cast<const u32x4*>(qs)[ch];
+  auto krow = [&](int j) -> u32x4 {
+    const uint16_t* kr = (ROPE && j == p0) ? knew : K + static_cast<int64_t>(j) * HD;   // the new key: from LDS, its cache row is being written by another workgroup
+    return reinterpret_cast<const u32x4*>(kr)[ch];
+  };
+  auto score = [&](const u32x4& kv) -> float {
     float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      const u32x4 kv = fresh ? reinterpret_cast<const u32x4*>(knew)[c] : kr[c];
-      const u32x4 qv = reinterpret_cast<const u32x4*>(qs)[c];
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t qe = qf[e], ke = kv[e];   // (a bit_cast of an ext-vector ELEMENT reads element 0: copy to a scalar first)
+      if constexpr (BF) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, qe), __builtin_bit_cast(b2, ke), acc, false);
+      else acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qe), __builtin_bit_cast(h2, ke), acc, false);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t qe = qv[e], ke = kv[e];   // (a bit_cast of an ext-vector ELEMENT reads element 0: copy to a scalar first)
-        if constexpr (BF) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, qe), __builtin_bit_cast(b2, ke), acc, false);
-        else acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, qe), __builtin_bit_cast(h2, ke), acc, false);
+    for (int off = 1; off < LPK; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    return acc * scaling;
+  };
+  float mx = -INFINITY;
+  {
+    int j = k0 + wave * KPW + sub;
+    for (; j + 3 * STEP < k1; j += 4 * STEP) {
+      u32x4 k4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k4[u] = krow(j + u * STEP);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float sv = score(k4[u]);
+        if (ch == 0) sc[j + u * STEP - k0] = sv;
+        mx = fmaxf(mx, sv);
       }
     }
-    const float sv = acc * scaling;
-    sc[j - k0] = sv;
-    mx = fmaxf(mx, sv);
+    // (the shuffles of score() need every lane of a row group: rows past the end are computed on row k1 - 1 and dropped)
+    for (; j - sub < k1; j += STEP) {
+      const bool live = j < k1;
+      const float sv = score(krow(live ? j : k1 - 1));
+      if (live) {
+        if (ch == 0) sc[j - k0] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -295,8 +320,6 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   sum = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
   // phase 3: a wave instruction covers KPW = 512 / HD value rows: LPK = HD / 8 lanes per row, 16 bytes (8 dims) per lane; a wave takes rows
   //          k0 + KPW wave + sub, stepping 8 KPW, four instructions in flight; the KPW row groups of a wave are added by shuffles
-  constexpr int LPK = HD / 8, KPW = 64 / LPK;
-  const int sub = lane / LPK, ch = lane - sub * LPK;
   float o8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o8[e] = 0.f;
@@ -312,7 +335,6 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       o8[2 * e + 1] = fmaf(pj, E::f(static_cast<uint16_t>(w >> 16)), o8[2 * e + 1]);
     }
   };
-  constexpr int STEP = 8 * KPW;
   int j = k0 + wave * KPW + sub;
   for (; j + 3 * STEP < k1; j += 4 * STEP) {
     u32x4 v4[4];
