@@ -32,14 +32,22 @@ class GraphedGreedyDecoder:
 
     def _kv_len(self, p: int) -> int:
         """how much of the static cache a step at position p attends over.  HF's attention function costs what it is given (the whole masked cache:
-        304 tok/s at 1024 positions, 119 at 4096, against 500 at 256), so the fused step hands it the smallest bucket 256 * 2^k above the
-        position and keeps one captured graph per bucket; the kernel attention reads pos + 1 keys by itself and uses the bucket only to decide
+        304 tok/s at 1024 positions, 119 at 4096, against 500 at 256), so the fused step hands it a bucket just above the position (64, then
+        multiples of 128 to 1024, then multiples of 512) and keeps one captured graph per bucket; the kernel attention reads pos + 1 keys by itself and uses the bucket only to decide
         how many workgroups share a head's keys (one up to 1024 keys)"""
         if self.step is None or not self.bucket_cache:
             return self.max_cache_len
-        b = 1024 if self.attention == "hip" else 256   # (the kernel attention only changes its launch shape beyond 1024 visible keys)
-        while b < p + 1:
-            b *= 2
+        n = p + 1
+        if self.attention == "hip":   # (the kernel attention only changes its launch shape beyond 1024 visible keys: powers of two from there)
+            b = 1024
+            while b < n:
+                b *= 2
+        elif n <= 64:                 # SDPA over 64 / 128 / 256 / 512 keys: 6.4 / 9.0 / 14.4 / 24.8 us per block
+            b = 64
+        elif n <= 1024:
+            b = -(-n // 128) * 128
+        else:
+            b = -(-n // 512) * 512
         return min(b, self.max_cache_len)
 
     @torch.no_grad()
