@@ -882,7 +882,7 @@ def main():
                             lp[mode] = {"tok_s": round(r4["tok_s"], 2), "ms_per_token": round(r4["ms_per_token"], 4)}
                             del d4
                         out["end_to_end"]["at_position_3000"] = {"default_sdpa": lp["sdpa"], "with_decode_attention_kernel": lp["hip"],
-                                                                 "note": "HF's attention function runs one workgroup per head over the 4096-position bucket; the kernel shares a head's "
+                                                                 "note": "HF's attention function runs one workgroup per head over the cache bucket above the position (3072 keys); the kernel shares a head's "
                                                                          "3000 keys out over 8 workgroups (hqq_hip_rope_attn_decode, splits = 8) and is at the cache's HBM read time"}
                     except Exception as e:
                         out["end_to_end"]["at_position_3000"] = {"error": repr(e)}
