@@ -194,3 +194,28 @@ def test_set_gemv_mode_combines_with_a_layers_own_option_bits():
         assert ops.layer_opts(ops.OPT_W3S | ops.OPT_META_SCALABLE) == ops.OPT_W3S | ops.OPT_FACTORED
     finally:
         ops.set_gemv_mode(ops.GEMV_EXACT)
+
+
+def test_cache_buckets_and_attention_splits_host_logic():
+    """GraphedGreedyDecoder._kv_len (which part of the static cache a decode step attends over) and ops.attn_splits (workgroups per head of the
+    decode-attention kernel): pure host logic — a bucket always covers the position, never exceeds the cache, and grows monotonically"""
+    from hqq_amd import ops
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    d = GraphedGreedyDecoder.__new__(GraphedGreedyDecoder)
+    d.step, d.bucket_cache, d.max_cache_len = object(), True, 4096
+    for mode in ("sdpa", "hip"):
+        d.attention = mode
+        last = 0
+        for p in range(0, 4096):
+            b = d._kv_len(p)
+            assert p + 1 <= b <= 4096 and b >= last
+            last = b
+    d.attention = "sdpa"
+    assert [d._kv_len(p) for p in (0, 63, 64, 127, 128, 255, 256, 1023, 1024, 1536, 4095)] == [64, 64, 128, 128, 256, 256, 384, 1024, 1536, 2048, 4096]
+    d.attention = "hip"
+    assert [d._kv_len(p) for p in (0, 1023, 1024, 2047, 2048, 4095)] == [1024, 1024, 2048, 2048, 4096, 4096]
+    d.bucket_cache = False
+    assert d._kv_len(5) == 4096
+    d.bucket_cache, d.step = True, None      # the generic (non-fused) loop attends over the whole cache
+    assert d._kv_len(5) == 4096
+    assert [ops.attn_splits(n) for n in (64, 1024, 1025, 2048, 4096, 8192, 30000)] == [1, 1, 2, 4, 8, 16, 16]
