@@ -97,7 +97,38 @@ class ShardedHQQForward:
         self.Wq, self.scale, self.zero, self.bias, self.n_loc = shard_packed(W_q, scale, zero, bias, N, K, group_size, nbits, self.rank, self.world)
         self._local = local_forward or (lambda x: ops.forward(x, self.Wq, self.scale, self.zero, self.bias, self.n_loc, K, group_size, nbits))
 
+    # rows per chunk of a long prompt: the shard's GEMM of chunk c + 1 runs while chunk c's outputs are gathered (at
+    # M = 65,536 a rank receives 896 MiB per layer — the gather is as long as the GEMM unless it overlaps it).  0 disables chunking
+    OVERLAP_ROWS = 4096
+
+    def _forward_chunked(self, x2: Tensor, rows: int) -> Tensor:
+        """long prompts: per chunk of `rows` activation rows, the local GEMM on the current stream, then an ASYNC all-gather of its [rows, N / P]
+        outputs (the collective library runs it on its own stream behind an event: the next chunk's GEMM overlaps it), un-permuted into the
+        reference's column order once it has arrived"""
+        M = x2.shape[0]
+        out = torch.empty((M, self.N), dtype=x2.dtype, device=x2.device)
+        pending = []
+        for c0 in range(0, M, rows):
+            y_c = self._local(x2[c0:c0 + rows]).reshape(-1, self.n_loc).contiguous()
+            buf = torch.empty((self.world * y_c.shape[0], self.n_loc), dtype=y_c.dtype, device=y_c.device)
+            work = self.dist.all_gather_into_tensor(buf, y_c, group=self.group, async_op=True)
+            pending.append((work, buf, y_c, c0))            # (y_c is kept alive until its gather has completed)
+            if len(pending) > 1:                            # at most two chunks in flight: drain the older one
+                self._drain(pending.pop(0), out)
+        while pending:
+            self._drain(pending.pop(0), out)
+        return out
+
+    def _drain(self, item, out: Tensor) -> None:
+        work, buf, y_c, c0 = item
+        work.wait()
+        mc = y_c.shape[0]
+        out[c0:c0 + mc] = unpermute(buf.view(self.world, mc, self.n_loc), self.N, self.nbits, self.world)
+
     def forward(self, x: Tensor) -> Tensor:
+        rows_in = x.numel() // self.K
+        if self.OVERLAP_ROWS and rows_in >= 2 * self.OVERLAP_ROWS and self.world > 1:
+            return self._forward_chunked(x.reshape(-1, self.K), self.OVERLAP_ROWS).reshape(*x.shape[:-1], self.N)
         y_loc = self._local(x).reshape(-1, self.n_loc).contiguous()
         M = y_loc.shape[0]
         if M == 1 and self.peer is not None:

@@ -86,6 +86,13 @@ def _worker(rank, world, port, nbits, q):
         # one activation row: per-slab gathers straight into the reference's column order (shard.gather_columns), no un-permute
         y1 = sh(x[:1])
         ok = ok and tuple(y1.shape) == (1, N) and torch.allclose(y1, x[:1] @ Wfull.t() + bias, atol=1e-5)
+        # a long prompt: chunks of OVERLAP_ROWS rows, each chunk's gather issued asynchronously behind its local GEMM (ragged last chunk)
+        sh.OVERLAP_ROWS = 5
+        xl = torch.randn(23, K, generator=g)
+        yl = sh(xl)
+        ok = ok and tuple(yl.shape) == (23, N) and torch.allclose(yl, xl @ Wfull.t() + bias, atol=1e-5)
+        yl3 = sh(xl.reshape(1, 23, K))
+        ok = ok and tuple(yl3.shape) == (1, 23, N) and torch.equal(yl3[0], yl)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
