@@ -218,8 +218,8 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   const int p0 = static_cast<int>(pos[0]);
   const int n = p0 + 1;
   // S > 1 (long caches): workgroup (h, sp) attends over keys [k0, k1), a 1 / S share of the pos + 1 visible ones, and parks (max, sum,
-  // unnormalised output) in the workspace; attn_combine_kernel merges the S shares in split order.  One workgroup per head streams 0.8 TB/s:
-  // 76 us at 4096 keys; eight per head 14
+  // unnormalised output) in the workspace; attn_combine_kernel merges the S shares in split order.  One workgroup per head streams 1.3 TB/s:
+  // 48 us at 4096 keys; eight per head 19 (the 64 MB of cache at 3.4 TB/s + the two launches)
   const int chunk = (n + S - 1) / S;
   const int k0 = sp * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
   const uint16_t* K = kc_in + static_cast<int64_t>(kvh) * L * HD;

@@ -195,7 +195,7 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
 int hqq_hip_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int64_t* pos_dev, void* out, int64_t n_heads, int64_t n_kv_heads,
                         int64_t head_dim, int64_t cache_len, float scaling, int dtype, int64_t splits, void* workspace, size_t workspace_bytes, void* stream);
 /* splits: 1 = one workgroup per query head (caches of up to ~1000 positions: 3.5-5.5 us); > 1 (at most 64): every head's visible keys are shared
- * out over `splits` workgroups whose (max, sum, output) records a second small launch merges in split order (long caches: 77 -> 14 us at 4096
+ * out over `splits` workgroups whose (max, sum, output) records a second small launch merges in split order (long caches: 48 -> 19 us at 4096
  * positions with 8) — `workspace` then holds hqq_hip_attn_decode_workspace_bytes(n_heads, head_dim, splits) bytes (caller-owned, no initialisation). */
 size_t hqq_hip_attn_decode_workspace_bytes(int64_t n_heads, int64_t head_dim, int64_t splits);
 /* The same with hqq_hip_rope_cache folded in: q / k / v are the RAW projections ([n_heads, head_dim], [n_kv_heads, head_dim] twice), cos / sin
