@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const uint16_t* __restr
     q_out[static_cast<int64_t>(head) * hd + i + half] = o2;
   } else {
     const int64_t p = pos[0];
+    if (p < 0 || p >= cache_len) return;   // a position outside the cache writes nothing (HF's StaticCache index_copy_ raises a device assert there)
     const int kh = head - n_heads;
     uint16_t* kd = k_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
     uint16_t* vd = v_cache + (static_cast<int64_t>(kh) * cache_len + p) * hd;
@@ -215,7 +216,10 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
   uint16_t* vnew = qs + 2 * HD;
   const int h = blockIdx.x, sp = blockIdx.y, rep = n_heads / n_kv, kvh = h / rep;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p0 = static_cast<int>(pos[0]);
+  // a position outside [0, L) must not index the cache or the score buffer (sized from L): attend as if at the last slot, write nothing
+  const int64_t p_raw = pos[0];
+  const bool p_ok = p_raw >= 0 && p_raw < L;
+  const int p0 = p_ok ? static_cast<int>(p_raw) : L - 1;
   const int n = p0 + 1;
   // S > 1 (long caches): workgroup (h, sp) attends over keys [k0, k1), a 1 / S share of the pos + 1 visible ones, and parks (max, sum,
   // unnormalised output) in the workspace; attn_combine_kernel merges the S shares in split order.  One workgroup per head streams 1.3 TB/s:
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       uint16_t* dst = is_k ? knew : qs;
       dst[i] = o1;
       dst[i + half] = o2;
-      if (is_k && h % rep == 0 && sp == 0) {
+      if (is_k && h % rep == 0 && sp == 0 && p_ok) {
         uint16_t* kd = kc_out + (static_cast<int64_t>(kvh) * L + p0) * HD;
         kd[i] = o1;
         kd[i + half] = o2;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const uint16_t* __rest
       const int c = tid - HD;
       const u32x4 vv = reinterpret_cast<const u32x4*>(v_raw + static_cast<int64_t>(kvh) * HD)[c];
       reinterpret_cast<u32x4*>(vnew)[c] = vv;
-      if (h % rep == 0 && sp == 0) reinterpret_cast<u32x4*>(vc_out + (static_cast<int64_t>(kvh) * L + p0) * HD)[c] = vv;
+      if (h % rep == 0 && sp == 0 && p_ok) reinterpret_cast<u32x4*>(vc_out + (static_cast<int64_t>(kvh) * L + p0) * HD)[c] = vv;
     }
   } else {
     if (tid < HD / 8) reinterpret_cast<u32x4*>(qs)[tid] = reinterpret_cast<const u32x4*>(q + static_cast<int64_t>(h) * HD)[tid];

@@ -562,6 +562,23 @@ size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
                hipStream_t st);
+#ifdef HQQ_LAB_KWAVE   // lab (tools/lab_kwave/: 5..64 rows without a K split across workgroups — built, bit-exact, measured slower)
+bool kwave_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
+int kwave_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
+              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, hipStream_t st);
+#define HQQ_OPT_BATCH_SPLITK 2048u
+#define HQQ_OPT_ALL_GEMV (HQQ_OPT_ALL | HQQ_OPT_BATCH_SPLITK)
+static bool kw_serves(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  if (!N || (opts & HQQ_OPT_BATCH_SPLITK) || (dtype != HQQ_F16 && dtype != HQQ_BF16) || M < 5) return false;
+  if (nbits == 3 && !(opts & HQQ_OPT_W3S)) return false;
+  return kwave_covers(nbits, M, K, group_size, N, n_layers);
+}
+#else
+#define HQQ_OPT_ALL_GEMV HQQ_OPT_ALL
+static bool kw_serves(int, int, const int64_t*, int64_t, int64_t, int64_t, int, uint32_t) { return false; }
+static int kwave_run(int, int, const void*, const void* const*, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
+                     int64_t, int, uint32_t, hipStream_t) { return HQQ_ERR_UNSUPPORTED; }
+#endif
 int gemv_w3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
                  void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, hipStream_t st);
 size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts);
@@ -621,12 +638,13 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
                                     int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                                     void* stream) {
   clear_stale_error();
-  if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
+  if (opts & ~HQQ_OPT_ALL_GEMV) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL_GEMV); return HQQ_ERR_SHAPE; }
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
   if ((opts & HQQ_OPT_W3S) && nbits != 3) { set_error("hqq_hip_gemv: HQQ_OPT_W3S is a 3-bit layout (nbits=%d)", nbits); return HQQ_ERR_SHAPE; }
   const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);   // the 3-bit stream layout runs through the 4-bit container's kernels (w3s.h)
-  const bool skinny_ok = N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(w3s ? 4 : nbits, M, K, group_size, N, n_layers);
+  const bool kw_ok = kw_serves(nbits, n_layers, N, M, K, group_size, dtype, opts);   // (lab builds only)
+  const bool skinny_ok = kw_ok || (N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(w3s ? 4 : nbits, M, K, group_size, N, n_layers));
   if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
     set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 8-/4-/2-bit, group_size 64, K %% 256 == 0)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
     return HQQ_ERR_SHAPE;
@@ -644,6 +662,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
+    if (kw_ok) return kwave_run(3, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, as_stream(stream));
     return skinny_run(3, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
   }
   if (nbits == 3) {   // int32 containers, ten slabs: its own kernel (gemv3.hip), fp16, exact weights
@@ -687,6 +706,7 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    if (kw_ok) return kwave_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, as_stream(stream));
     if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }
@@ -745,6 +765,7 @@ extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void
 
 extern "C" size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
   if (!N || n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || M < 1 || K <= 0 || group_size <= 0) return 0;
+  if (kw_serves(nbits, n_layers, N, M, K, group_size, dtype, opts)) return 0;   // (lab builds only)
   if (nbits == 3 && (opts & HQQ_OPT_W3S)) {
     if (M <= GV_EXACT_ROWWISE_MAX_M) return 0;
     return ((dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(4, M, K, group_size, N, n_layers)) ? skinny_workspace_bytes(3, n_layers, N, M, K, opts) : 0;

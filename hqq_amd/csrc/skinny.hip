@@ -447,6 +447,18 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         b0[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
         b1[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
       }
+#ifdef SK_LAB_NOARITH   // lab (tools/r5_bs32_probe.sh: the floor of this launch shape): every loaded / staged register is touched, nothing is rebuilt or contracted
+      {
+        float f = __uint_as_float((cur.w[jl].x ^ cur.w[jl].y ^ cur.w[jl].z ^ cur.w[jl].w ^ zs[0] ^ zs[PER - 1]) & 0x3F800000u);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const u32x4 u0 = __builtin_bit_cast(u32x4, b0[t]), u1 = __builtin_bit_cast(u32x4, b1[t]);
+          f += __uint_as_float((u0.x ^ u0.y ^ u0.z ^ u0.w ^ u1.x ^ u1.y ^ u1.z ^ u1.w) & 0x3F800000u);
+          acc[0][t][0] += f;
+        }
+        continue;
+      }
+#endif
       if constexpr (W3) SkSlabW3s<MT, BF16, SUB>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else

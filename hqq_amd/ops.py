@@ -24,6 +24,7 @@ GEMV_MAX_GROUP = 4
 # per-call option bits of the C ABI (include/hqq_hip.h HQQ_OPT_*)
 OPT_FACTORED, OPT_META_SCALABLE, OPT_GEMV3_ROWWISE, OPT_GEMV3_SLABS, OPT_GEMM_REGTILE, OPT_GEMM_CLASSIC, OPT_GEMM_NARROW, OPT_GEMM_WIDE, OPT_GEMM_NOHYBRID, OPT_SKINNY_WIDE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 OPT_W3S = 1024   # nbits = 3: W_q is the 3-bit stream layout of w3s_pack(), not the reference container
+OPT_BATCH_SPLITK = 2048   # LAB builds only (tools/lab_kwave/build.sh): force the split-K kernel where the quarantined no-split kernel would serve
 
 
 def OPT_SKINNY_KS(n: int) -> int:
@@ -447,7 +448,7 @@ def forward(x, W_q, scale, zero, bias, N, K, group_size, nbits, out=None, fused=
         # the 3-bit stream layout: the 4-bit container's kernels (1..4 rows: row-per-wave GEMV; 5..64: the skinny GEMM); beyond, the reference
         # container is restored on the fly for the dequantise kernel + dense GEMM (long prompts of a patched 3-bit layer)
         if M <= 4 or (M <= SKINNY_MAX_M and group_size == 64 and K % 256 == 0 and K >= 512 and x.dtype in (torch.float16, torch.bfloat16)) or fused or \
-                (fused is None and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(4, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):   # (asked as a 4-bit layer: same kernels, same plan)
+                (fused is None and M > SKINNY_MAX_M and x.dtype in _DT and bool(_C.lib().hqq_hip_forward_prefers_fused(4, M, int(N), int(K), int(group_size or 0), _dt(x.dtype)))):   # (asked as a 4-bit layer: same kernels, same plan; 5..64 rows outside the batched-decode kernels' shapes compose below)
             return _fwd("hqq_hip_forward", x, W_q, scale, zero, bias, N, K, group_size, nbits, out, opts)
         W = dequantize(w3s_unpack(W_q, N, K), scale.reshape(-1), zero.reshape(-1), N, K, group_size, 3, 1)
         return _compose(x, W, bias, out, N, K, library_gemm)

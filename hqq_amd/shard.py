@@ -252,6 +252,27 @@ class PeerExchange:
 
     ALIGN = 256
 
+    @staticmethod
+    def _release(raw_ptr, opened, device) -> None:
+        import ctypes
+        rt = _hip_runtime()
+        if rt is None:
+            return
+        try:
+            with torch.cuda.device(device):
+                torch.cuda.synchronize(device)
+                for p in opened:
+                    rt.hipIpcCloseMemHandle(ctypes.c_void_p(p))
+                if raw_ptr:
+                    rt.hipFree(ctypes.c_void_p(raw_ptr))
+        except Exception:   # noqa: BLE001  (interpreter shutdown: the driver reclaims the process's memory anyway)
+            pass
+
+    def close(self) -> None:
+        """Give the arena and the peers' IPC mappings back to the runtime.  Collective in spirit: call it on every rank once no rank's kernels
+        can still store into this rank's arena (after a barrier); the object — and every tensor full() / rows handed out — is unusable afterwards."""
+        self._closer()
+
     def __init__(self, points, nbits: int, dtype, device, group=None, spin_limit: int = 0, _arenas=None, _rank=None, _world=None):
         import torch.distributed as dist
         self.nbits, self.dtype, self.device = int(nbits), dtype, torch.device(device)
@@ -335,6 +356,9 @@ class PeerExchange:
                 if not all(oks):
                     bad = [p for p, o in enumerate(oks) if not o]
                     raise RuntimeError(f"hqq_amd: PeerExchange: rank(s) {bad} could not map their peers' arenas" + (f" ({type(err).__name__}: {err})" if err else ""))
+        # what this object took from the runtime itself goes back when it dies (or on close()): the peers' IPC mappings, then its own arena
+        self._opened = [int(a.data_ptr()) for p, a in enumerate(self._arenas) if self._raw_ptr is not None and self.world > 1 and p != self.rank]
+        self._closer = __import__("weakref").finalize(self, PeerExchange._release, self._raw_ptr, list(self._opened), self.device)
         if any(a.numel() < self.arena_bytes for a in self._arenas):
             raise ValueError("hqq_amd: PeerExchange arenas are smaller than the layout (ranks disagree about the points)")
         self._base = [a.data_ptr() for a in self._arenas]

@@ -70,7 +70,12 @@ class GraphedGreedyDecoder:
         self.tok = out.logits[:, -1].argmax(-1, keepdim=True)
         self.next_tok = torch.empty_like(self.tok)
         self.pos = torch.tensor([T], device=self.device)
-        self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention) if self.fused else None
+        self.step = None
+        if self.fused:
+            try:
+                self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention)
+            except ValueError:   # a cache layout / attention configuration the fused step does not restate: the model's own forward serves
+                self.step = None
         toks = [self.tok.clone()]
         self.graph = None
         self.graphs = {}

@@ -24,9 +24,37 @@ def _hip(layer):
     return layer.layer if isinstance(layer, _GroupedMember) else layer
 
 
+def arch_supported(model) -> bool:
+    """The allow-list half of supports(): the step restates LlamaDecoderLayer's arithmetic (transformers models/llama, models/mistral) and nothing
+    else.  Models that merely LOOK like it (same attribute names) would decode wrong tokens without an error: Qwen3 (per-head q_norm / k_norm),
+    Granite (residual / embedding / logits / attention multipliers), Gemma (soft-capping, (1 + w) norms), Cohere, OLMo ..."""
+    try:
+        cfg = model.config
+        if getattr(cfg, "model_type", None) not in ("llama", "mistral"):
+            return False
+        if getattr(cfg, "sliding_window", None) or getattr(cfg, "attn_logit_softcapping", None) or getattr(cfg, "final_logit_softcapping", None):
+            return False
+        if getattr(cfg, "attention_bias", False) or getattr(cfg, "mlp_bias", False):
+            return False
+        for odd in ("residual_multiplier", "embedding_multiplier", "logits_scaling", "attention_multiplier"):
+            if getattr(cfg, odd, None) not in (None, 1, 1.0):
+                return False
+        for blk in model.model.layers:
+            at = blk.self_attn
+            if any(hasattr(at, n) for n in ("q_norm", "k_norm", "qk_norm", "sinks")) or getattr(at, "sliding_window", None):
+                return False
+            if type(getattr(blk.mlp, "act_fn", None)).__name__ not in ("SiLUActivation", "SiLU"):
+                return False
+        return True
+    except AttributeError:
+        return False
+
+
 def supports(model) -> bool:
-    """a LlamaForCausalLM-shaped model (model.model.layers[*].self_attn.{q,k,v,o}_proj, .mlp.{gate,up,down}_proj, RMSNorm without bias),
-    fp16 or bf16, every decoder linear an HQQLinearHIP without bias whose group can share one launch"""
+    """a LlamaForCausalLM-shaped model of an allow-listed architecture (arch_supported) — model.model.layers[*].self_attn.{q,k,v,o}_proj,
+    .mlp.{gate,up,down}_proj, RMSNorm without bias —, fp16 or bf16, every decoder linear an HQQLinearHIP without bias whose group can share one launch"""
+    if not arch_supported(model):
+        return False
     try:
         inner = model.model
         dt = inner.norm.weight.dtype
@@ -133,6 +161,8 @@ class FusedLlamaStep:
         (masked beyond pos as before) — its cost follows the length it is given, so a caller that knows the position passes a bucket just above it"""
         inner = self.inner
         h = self.h
+        # (the position itself is device memory — the step is graph-replayed —: the kernels that index the cache with it skip their
+        #  writes beyond the cache's last slot, csrc/block.hip; callers that know the position on the host check it there, generation.py)
         h.copy_(inner.embed_tokens(tok).view(1, self.H))
         if self.cos_tab is not None:
             cos, sin = self.cos_tab.index_select(0, pos).view(-1), self.sin_tab.index_select(0, pos).view(-1)

@@ -219,3 +219,33 @@ def test_cache_buckets_and_attention_splits_host_logic():
     d.bucket_cache, d.step = True, None      # the generic (non-fused) loop attends over the whole cache
     assert d._kv_len(5) == 4096
     assert [ops.attn_splits(n) for n in (64, 1024, 1025, 2048, 4096, 8192, 30000)] == [1, 1, 2, 4, 8, 16, 16]
+
+
+def test_fused_decode_step_is_allow_listed_by_model_type():
+    """llama_fused.supports() must say no to models that only LOOK like a Llama (same attribute names, other arithmetic): Qwen3 normalises
+    q / k per head, Granite scales the residual stream, the embeddings and the logits — the fused step would decode wrong tokens silently.
+    arch_supported() is the allow-list half (config.model_type + the absence of those modules); it reads no weights, so it runs here."""
+    transformers = pytest.importorskip("transformers")
+    from hqq_amd.utils import llama_fused
+    kw = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    rejected = []
+    for name in ("Qwen3", "Granite", "Gemma2", "Qwen2"):
+        cfg_cls, model_cls = getattr(transformers, name + "Config", None), getattr(transformers, name + "ForCausalLM", None)
+        if cfg_cls is None or model_cls is None:
+            continue
+        extra = dict(head_dim=16) if name in ("Qwen3", "Gemma2") else {}
+        model = model_cls(cfg_cls(**kw, **extra)).half()
+        assert not llama_fused.arch_supported(model) and not llama_fused.supports(model), name
+        rejected.append(name)
+    assert rejected, "no look-alike architecture in this transformers build"
+    llama = transformers.LlamaForCausalLM(transformers.LlamaConfig(**kw)).half()
+    assert llama_fused.arch_supported(llama)
+    assert not llama_fused.supports(llama)          # (its linears are not HQQLinearHIP layers)
+    if hasattr(transformers, "MistralForCausalLM"):
+        assert llama_fused.arch_supported(transformers.MistralForCausalLM(transformers.MistralConfig(**kw, sliding_window=None)).half())
+        assert not llama_fused.arch_supported(transformers.MistralForCausalLM(transformers.MistralConfig(**kw, sliding_window=32)).half())
+    # a Llama whose config asks for what the step does not restate is refused too
+    for bad in (dict(attention_bias=True), dict(mlp_bias=True)):
+        assert not llama_fused.arch_supported(transformers.LlamaForCausalLM(transformers.LlamaConfig(**kw, **bad)).half())
+    llama.model.layers[0].self_attn.q_norm = torch.nn.Identity()
+    assert not llama_fused.arch_supported(llama)
