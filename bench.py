@@ -839,6 +839,8 @@ def main():
                 finally:
                     torch.set_default_dtype(dflt)
                 quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device=str(dev))
+                import copy
+                ref_model = copy.deepcopy(model)       # the same quantised model, left on HQQLinear: decodes under HQQBackend.PYTORCH_FORWARD for the identity check below
                 prepare_for_inference(model, backend="hip")
                 ngrp = group_llama_projections(model)
                 torch.cuda.synchronize()
@@ -854,7 +856,38 @@ def main():
                                      "loop": "hqq_amd.utils.generation.GraphedGreedyDecoder, fused step (hqq_amd.utils.llama_fused): per decoder block add_rmsnorm -> q|k|v (grouped GEMV) -> "
                                              "rope_cache -> HF's attention function on the static cache -> o -> add_rmsnorm (residual add inside) -> gate|up (grouped GEMV) -> silu_mul -> down; "
                                              "csrc/block.hip restates the HF modules rounding for rounding; one captured hipGraph per token, argmax fed back on the device",
-                                     "fused_step": bool(dec.fused)}
+                                     "fused_step": bool(dec.fused), "glue": ("folded into the GEMV launches (csrc/gemv_block.hip): 5 launches + attention per block" if (dec.step is not None and dec.step.folded)
+                                                                             else "separate kernels (csrc/block.hip): 8 launches + attention per block")}
+                if dec.step is not None and dec.step.folded:
+                    out["end_to_end"]["loop"] = ("hqq_amd.utils.generation.GraphedGreedyDecoder, fused step (hqq_amd.utils.llama_fused, glue folded): per decoder block q|k|v (grouped GEMV, RMSNorm in its "
+                                                 "prologue) -> rope_cache -> HF's attention function on the static cache -> o (residual add in its epilogue) -> gate|up as ONE paired layer (RMSNorm "
+                                                 "prologue, SiLU * up epilogue) -> down (residual add in its epilogue); one captured hipGraph per token, argmax fed back on the device")
+                # not against itself: the first 8 greedy tokens of this loop against the SAME quantised model decoding with HF's generate under HQQBackend.PYTORCH_FORWARD
+                # (dequantise + dense matmul: the reference's arithmetic, hqq/core/quantize.py:894-898)
+                try:
+                    from hqq_amd.core.quantize import HQQBackend, HQQLinear
+                    HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+                    try:
+                        with torch.no_grad():
+                            want = ref_model.generate(ids, max_new_tokens=8, min_new_tokens=8, do_sample=False)
+                    finally:
+                        HQQLinear.set_backend(HQQBackend.HIP)
+                    got = dec.generate(ids, 8, use_graph=True)
+                    n_same = int((got[0, ids.shape[1]:] == want[0, ids.shape[1]:]).to(torch.int32).cumprod(0).sum())
+                    out["end_to_end"]["identity_check"] = {"tokens": 8, "identical_prefix": n_same, "identical": bool(n_same == 8),
+                                                           "against": "HF generate() of the same quantised 7B-shaped model under HQQBackend.PYTORCH_FORWARD"}
+                except Exception as e:
+                    out["end_to_end"]["identity_check"] = {"error": repr(e)}
+                del ref_model
+                torch.cuda.empty_cache()
+                # the same loop with round 4's separate glue kernels (same box, same model): what the folding buys
+                try:
+                    dec1 = GraphedGreedyDecoder(model, max_cache_len=256, glue="kernels")
+                    r1 = dec1.benchmark(ids, new_tokens=64, warmup=8)
+                    out["end_to_end"]["with_separate_glue_kernels"] = {"tok_s": round(r1["tok_s"], 2), "ms_per_token": round(r1["ms_per_token"], 4)}
+                    del dec1
+                except Exception as e:
+                    out["end_to_end"]["with_separate_glue_kernels"] = {"error": repr(e)}
                 # the same loop with the decode-attention kernel in place of HF's SDPA call (opt-in: within rounding of SDPA, not bit-identical to it)
                 try:
                     dec2 = GraphedGreedyDecoder(model, max_cache_len=256, attention="hip")

@@ -37,6 +37,7 @@ SYMBOLS = {
     "hqq_hip_gemv_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
+    "hqq_hip_gemv_block": (_i32, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _u32, _u32, _vp]),
     "hqq_hip_exchange": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u32, _vp]),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemm_dense": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
@@ -54,7 +55,7 @@ SYMBOLS = {
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -16,30 +16,9 @@
 //                 12-15 us the library's prefill-shaped kernel takes for a single query (profiles/r04_e2e_kernel_times.txt)
 // Compiled with -ffp-contract=off: a fused multiply-add would remove a rounding HF's separate ops make.
 #include "hqq_common.h"
+#include "block_math.h"
 
 namespace hqq {
-
-// element arithmetic on raw 16-bit values, with the roundings torch's elementwise ops make
-template <bool BF>
-struct El {
-  static __device__ __forceinline__ float f(uint16_t a) {
-    if constexpr (BF) return bf16_to_f32(a);
-    else return static_cast<float>(__builtin_bit_cast(half_t, a));
-  }
-  static __device__ __forceinline__ uint16_t r(float v) {   // round to nearest even
-    if constexpr (BF) return f32_to_bf16(v);
-    else return __builtin_bit_cast(uint16_t, static_cast<half_t>(v));
-  }
-  static __device__ __forceinline__ uint16_t add(uint16_t a, uint16_t b) {
-    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) + bf16_to_f32(b));
-    else { const half_t s = __builtin_bit_cast(half_t, a) + __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
-  }
-  static __device__ __forceinline__ uint16_t mul(uint16_t a, uint16_t b) {
-    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) * bf16_to_f32(b));
-    else { const half_t s = __builtin_bit_cast(half_t, a) * __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
-  }
-  static __device__ __forceinline__ uint16_t neg(uint16_t a) { return static_cast<uint16_t>(a ^ 0x8000u); }
-};
 
 // ---- h (+= delta), xn = weight * T(float(h) * rsqrt(mean(float(h)^2) + eps)): one workgroup of 512 threads per row.
 //      Rows of up to 512 * 8 * RPT elements stay in registers between the two passes (every load is issued before the reduction: the kernel is
@@ -187,8 +166,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restric
   uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float x = E::f(gp[j]);
-    op[j] = E::mul(E::r(x / (1.0f + expf(-x))), up[j]);
+    op[j] = silu_mul_el<BF>(gp[j], up[j]);
   }
   *reinterpret_cast<u32x4*>(out + i) = ov;
 }

@@ -1,0 +1,39 @@
+// block_math.h — element arithmetic of the decode step's glue (block.hip) with the roundings torch's elementwise ops make; shared with the
+// decode kernels that fold those steps into their prologue / epilogue (gemv_block.hip).  Translation units that use it are compiled with
+// -ffp-contract=off: a fused multiply-add would remove a rounding HF's separate ops make.
+#pragma once
+#include "hqq_common.h"
+
+namespace hqq {
+
+// element arithmetic on raw 16-bit values, with the roundings torch's elementwise ops make
+template <bool BF>
+struct El {
+  static __device__ __forceinline__ float f(uint16_t a) {
+    if constexpr (BF) return bf16_to_f32(a);
+    else return static_cast<float>(__builtin_bit_cast(half_t, a));
+  }
+  static __device__ __forceinline__ uint16_t r(float v) {   // round to nearest even
+    if constexpr (BF) return f32_to_bf16(v);
+    else return __builtin_bit_cast(uint16_t, static_cast<half_t>(v));
+  }
+  static __device__ __forceinline__ uint16_t add(uint16_t a, uint16_t b) {
+    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) + bf16_to_f32(b));
+    else { const half_t s = __builtin_bit_cast(half_t, a) + __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
+  }
+  static __device__ __forceinline__ uint16_t mul(uint16_t a, uint16_t b) {
+    if constexpr (BF) return f32_to_bf16(bf16_to_f32(a) * bf16_to_f32(b));
+    else { const half_t s = __builtin_bit_cast(half_t, a) * __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
+  }
+  static __device__ __forceinline__ uint16_t neg(uint16_t a) { return static_cast<uint16_t>(a ^ 0x8000u); }
+};
+
+// LlamaMLP: act_fn(gate) * up — silu in fp32 (x / (1 + exp(-x))), rounded to T, then the product in T (transformers models/llama/modeling_llama.py LlamaMLP.forward)
+template <bool BF>
+__device__ __forceinline__ uint16_t silu_mul_el(uint16_t gate, uint16_t up) {
+  using E = El<BF>;
+  const float x = E::f(gate);
+  return E::mul(E::r(x / (1.0f + expf(-x))), up);
+}
+
+}  // namespace hqq

@@ -72,50 +72,7 @@ struct SlabLoop {
   }
 };
 
-// bf16 compute dtype: the reference's two roundings are to bf16 (quantize.py:198 on bf16 tensors).  gfx950 has no packed
-// bf16 arithmetic, so the weight goes through fp32: v_cvt_f32_ubyteN lifts the masked byte F q, one fma forms q - z,
-// v_cvt_pk_bf16_f32 rounds it (RNE), v_dot2_f32_bf16 against (s, 0) / (0, s) forms the exact product with s, a second v_cvt_pk rounds again.
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-template <int B>
-__device__ __forceinline__ float ubyte_f32(uint32_t v) { return static_cast<float>((v >> (8 * B)) & 0xFFu); }   // v_cvt_f32_ubyteB
-template <int NBITS, int M, int S, int PER>
-struct SlabExactBF16 {
-  static __device__ __forceinline__ void run(const u32x4& w, const uint32_t (&zs)[PER], const bf16x8_t (&b0)[M], const bf16x8_t (&b1)[M],
-                                             f32x4 (&acc)[M][PER], uint32_t magic) {
-    constexpr int sh = NBITS * (PER - 1 - S);
-    constexpr float inv = 1.0f / static_cast<float>(1 << sh);
-    const float zf = __uint_as_float(zs[S] << 16);
-    const bf16x2_t s_lo = __builtin_bit_cast(bf16x2_t, zs[S] >> 16);          // (s, 0)
-    const bf16x2_t s_hi = __builtin_bit_cast(bf16x2_t, zs[S] & 0xFFFF0000u);  // (0, s)
-    constexpr uint32_t m1 = ((1u << NBITS) - 1u) << sh;
-    uint32_t o[8];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const uint32_t fq = NBITS == 8 ? w[d] : (w[d] & (m1 * 0x01010101u));   // the word's four bytes reduced to slab S's field (F q each)
-      // fma(F q, 1 / F, -z) is q - z with ONE fp32 rounding (none unless z is below 2^-15): a bias folded into the addend
-      // (-(1024 / F) - z) would itself round when z is small and cost an ulp after rounding 1
-      const f32x2_t dq[2] = {{__builtin_fmaf(ubyte_f32<0>(fq), inv, -zf), __builtin_fmaf(ubyte_f32<2>(fq), inv, -zf)},    // bytes (4d+0, 4d+2)
-                             {__builtin_fmaf(ubyte_f32<1>(fq), inv, -zf), __builtin_fmaf(ubyte_f32<3>(fq), inv, -zf)}};   // bytes (4d+1, 4d+3)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const bf16x2_t dr = __builtin_convertvector(dq[h], bf16x2_t);                 // rounding 1
-        const f32x2_t pw = {__builtin_amdgcn_fdot2_f32_bf16(dr, s_lo, 0.f, false), __builtin_amdgcn_fdot2_f32_bf16(dr, s_hi, 0.f, false)};
-        o[2 * d + h] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pw, bf16x2_t));   // rounding 2
-      }
-    }
-    const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, u32x4{o[0], o[1], o[2], o[3]});
-    const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, u32x4{o[4], o[5], o[6], o[7]});
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[m], acc[m][S], 0, 0, 0);
-      acc[m][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[m], acc[m][S], 0, 0, 0);
-    }
-    if constexpr (S + 1 < PER) SlabExactBF16<NBITS, M, S + 1, PER>::run(w, zs, b0, b1, acc, magic);
-  }
-};
-
+// (SlabExactBF16 — the bf16 exact rebuild — lives in decode_common.h: gemv_block.hip compiles the same kernel text)
 template <int NBITS, int S, int PER>
 struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the raw fp16 bit patterns
   static __device__ __forceinline__ void run(const uint32_t* z, const uint32_t* sc, float (&c1)[PER], float (&c2)[PER]) {

@@ -327,6 +327,55 @@ def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=No
     return [o.reshape(*x.shape[:-1], L[4]) for o, L in zip(outs, layers)]
 
 
+BLOCK_NORM, BLOCK_RESID, BLOCK_SILU = 1, 2, 4   # HQQ_BLOCK_* (include/hqq_hip.h)
+
+
+def block_covers(dtype, K: int, group_size, nbits: int, w3s: bool, norm: bool) -> bool:
+    """what hqq_hip_gemv_block serves: one activation row, fp16 / bf16, 4- / 2-bit or the 3-bit stream layout, group_size 64; K <= 8192 with the RMSNorm prologue"""
+    return (dtype in (torch.float16, torch.bfloat16) and group_size == 64 and K % 64 == 0 and (nbits in (4, 2) or (nbits == 3 and w3s))
+            and (not norm or K <= 8192) and K * 2 <= 144 * 1024 - 4096)
+
+
+def gemv_block(x: Tensor, norm_weight, eps: float, layers, K: int, group_size: int, nbits: int, outs, flags: int, opts=None):
+    """The decoder block's launches with the glue folded in (csrc/gemv_block.hip; include/hqq_hip.h hqq_hip_gemv_block), ONE activation row:
+      BLOCK_NORM               x = the residual stream; layers (W_q, scale, zero, N) like gemv_grouped's; outs[i] [1, N_i]
+      BLOCK_NORM | BLOCK_SILU  ONE layer from pair_layers(gate, up): outs[0] [1, N / 2] = silu(gate) * up
+      BLOCK_RESID              ONE layer; outs[0] is the residual stream, updated in place: h += layer(x)"""
+    import ctypes
+    n = len(layers)
+    _dev(x, norm_weight, *[t for L in layers for t in L[:3]], *outs)
+    if x.numel() != K:
+        raise ValueError(f"hqq_amd: gemv_block serves one activation row of {K} features, got {tuple(x.shape)}")
+    VP = ctypes.c_void_p * n
+    o = _opts(opts)
+    with torch.cuda.device(x.device):
+        rc = _C.lib().hqq_hip_gemv_block(int(nbits), n, _p(x), _p(norm_weight), float(eps), VP(*[_p(L[0]) for L in layers]), VP(*[_p(L[1]) for L in layers]),
+                                         VP(*[_p(L[2]) for L in layers]), VP(*[_p(t) for t in outs]), (ctypes.c_int64 * n)(*[int(L[-1]) for L in layers]),
+                                         int(K), int(group_size), _dt(x.dtype), o, int(flags), _stream())
+    _C.check(rc, "hqq_hip_gemv_block")
+    return outs
+
+
+def pair_layers(gate, up, K: int, group_size: int, nbits: int, w3s: bool = False):
+    """The PAIRED layout of two layers of equal shape that read the same input (LlamaMLP's gate_proj / up_proj): the level matrix of `gate` on top of
+    the level matrix of `up`, packed as ONE layer of 2 N rows — BitPack's row slabs then put gate row n and up row n into the same packed row
+    (4-bit: byte (n, k) = gate level << 4 | up level), which is what lets hqq_hip_gemv_block's epilogue form silu(gate[n]) * up[n] inside one wave.
+    gate / up: (W_q, scale, zero, N) as the layers hold them (3-bit: the stream layout when w3s).  Returns (W_q, scale, zero, 2 N); the originals are
+    untouched (state_dict() and the prefill path keep using them).  Levels, scale and zero are the layers' own: the same weights bit for bit."""
+    (Wg, sg, zg, N), (Wu, su, zu, Nu) = gate, up
+    if N != Nu or sg.dtype != su.dtype:
+        raise ValueError("hqq_amd: pair_layers needs two layers of the same shape and compute dtype")
+    if w3s:
+        Wg, Wu = w3s_unpack(Wg, N, K), w3s_unpack(Wu, N, K)
+    R = N * K // group_size
+    Ug = unpack(nbits, Wg)[:R]          # level matrix [N K / gs, gs], row (n, g)
+    Uu = unpack(nbits, Wu)[:R]
+    W = pack(nbits, torch.cat([Ug, Uu], dim=0))
+    if w3s:
+        W = w3s_pack(W, 2 * N, K)
+    return W, torch.cat([sg.reshape(-1), su.reshape(-1)]).contiguous(), torch.cat([zg.reshape(-1), zu.reshape(-1)]).contiguous(), 2 * N
+
+
 EXCHANGE_MAX_RANKS = 16
 
 

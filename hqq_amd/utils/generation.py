@@ -13,15 +13,17 @@ from torch import Tensor
 class GraphedGreedyDecoder:
     """fused=True (default): a Llama-shaped model whose decoder linears are HQQLinearHIP layers decodes through hqq_amd.utils.llama_fused —
     RMSNorm (+ the residual adds), rotary + KV-cache write and SiLU * up as one HIP kernel each around the grouped GEMVs, HF's own attention
-    function on HF's cache: the same tokens in a third of the launches.  Any other model, or fused=False: the model's own forward."""
+    function on HF's cache: the same tokens in a third of the launches; since round 5 (glue="auto") the RMSNorms, the residual adds and SiLU * up
+    ride inside the GEMV launches themselves: 5 launches + attention per decoder block.  Any other model, or fused=False: the model's own forward."""
 
-    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa", bucket_cache: bool = True):
+    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa", bucket_cache: bool = True, glue: str = "auto"):
         from transformers import StaticCache
         from . import llama_fused
         self.model = model.eval()
         self.fused = bool(fused) and llama_fused.supports(model)
         self._fused_mod = llama_fused
         self.attention = attention   # "sdpa": HF's attention function (token-identical to model(...)); "hip": the decode-attention kernel (faster, within rounding)
+        self.glue = glue             # "auto" / "folded": RMSNorm, residual adds and SiLU * up inside the GEMV launches (csrc/gemv_block.hip); "kernels": round 4's separate glue kernels
         self.bucket_cache = bucket_cache   # attention="sdpa": attend over a bucket of the static cache just above the position (False: all of it)
         self.step = None
         self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
@@ -73,7 +75,7 @@ class GraphedGreedyDecoder:
         self.step = None
         if self.fused:
             try:
-                self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention)
+                self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention, glue=self.glue)
             except ValueError:   # a cache layout / attention configuration the fused step does not restate: the model's own forward serves
                 self.step = None
         toks = [self.tok.clone()]

@@ -5,7 +5,9 @@ HF's decoder block around the seven linears is ~25 eager kernels per block at ba
 residual adds 2, ...): 79 % of a token once the linears are fused.  Here a block is
     add_rmsnorm -> q|k|v (one grouped GEMV) -> rope_cache -> attention (HF's own attention function on the static cache) -> o ->
     add_rmsnorm (the residual add of o rides in it) -> gate|up (one grouped GEMV) -> silu_mul -> down (its residual add rides in the next block's add_rmsnorm)
-= 8 launches + the attention's.  The three glue kernels (csrc/block.hip) restate the HF modules rounding for rounding and the attention is
+= 8 launches + the attention's (glue="kernels").  Round 5 folds the glue into the launches either side of it (glue="folded", the default where
+csrc/gemv_block.hip covers the model): q|k|v with the RMSNorm in its prologue -> rope_cache -> attention -> o with the residual add in its epilogue ->
+ONE paired gate|up layer (RMSNorm prologue, SiLU * up epilogue) -> down with the residual add in its epilogue = 5 launches + the attention's.  The three glue kernels (csrc/block.hip) restate the HF modules rounding for rounding and the attention is
 HF's function on HF's cache tensors, so the step emits the same tokens as `model(...)` does on the same kernels — and as the same model
 under HQQBackend.PYTORCH_FORWARD does on the reference's arithmetic (tests/test_model_gpu.py).
 
@@ -85,10 +87,13 @@ def supports(model) -> bool:
 class FusedLlamaStep:
     """decode step t -> logits of token t + 1, on the model's own weights and an HF StaticCache that a prefill has filled"""
 
-    def __init__(self, model, cache, max_cache_len: int, attention: str = "sdpa"):
+    def __init__(self, model, cache, max_cache_len: int, attention: str = "sdpa", glue: str = "auto"):
         """attention: "sdpa" — HF's own attention function on the cache tensors (the step then emits the tokens `model(...)` would);
         "hip" — csrc/block.hip's decode-attention kernel (one query per head, fp32 softmax): within rounding of SDPA, not bit-identical,
-        3-4 us instead of 12-15 per block"""
+        3-4 us instead of 12-15 per block.
+        glue: "folded" — RMSNorm in the q|k|v / gate|up launches' prologue, the residual adds in o's / down's epilogue, SiLU * up in the epilogue of ONE
+        paired gate|up layer (csrc/gemv_block.hip: 4 launches + rotary / attention per block; costs a second copy of gate / up's packed levels in the
+        paired layout); "kernels" — round 4's separate glue kernels (9 launches per block); "auto": folded where hqq_hip_gemv_block covers the model."""
         from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
         from transformers.models.llama.modeling_llama import eager_attention_forward
         self.model = model
@@ -109,6 +114,14 @@ class FusedLlamaStep:
                                    or max_cache_len > 30000):
             raise ValueError("hqq_amd: the decode-attention kernel covers plain softmax attention with head_dim 64 / 128 / 256 and caches of <= 30000 positions")
         self.attention = attention
+        if glue not in ("auto", "folded", "kernels"):
+            raise ValueError("glue: 'auto', 'folded' or 'kernels'")
+        lins = [_hip(getattr(b.self_attn, n)) for b in inner.layers for n in ("q_proj", "o_proj")] + [_hip(getattr(b.mlp, n)) for b in inner.layers for n in ("gate_proj", "down_proj")]
+        can_fold = all(ops.block_covers(dt, L.in_features, L.group_size, L.nbits, L.w3s, norm=(i % 2 == 0)) for i, L in enumerate(lins)) and \
+            all(_hip(b.mlp.gate_proj).out_features == _hip(b.mlp.up_proj).out_features for b in inner.layers) and not (ops._default_opts & ops.OPT_FACTORED)
+        if glue == "folded" and not can_fold:
+            raise ValueError("hqq_amd: glue='folded' needs fp16 / bf16 layers of 4 / 2 bits or the 3-bit stream layout, group_size 64, hidden size <= 8192")
+        self.folded = can_fold and glue != "kernels"
         self.blocks = []
         dev = self.device
         for li, blk in enumerate(inner.layers):
@@ -129,6 +142,18 @@ class FusedLlamaStep:
                 "g": torch.empty(1, g.out_features, dtype=dt, device=dev), "u": torch.empty(1, u.out_features, dtype=dt, device=dev),
                 "a": torch.empty(1, g.out_features, dtype=dt, device=dev),
             })
+            if self.folded:   # gate|up as ONE paired layer: a packed row holds gate row n and up row n (ops.pair_layers); the layers' own tensors stay as they are
+                pair = ops.pair_layers((g.W_q, g.scale, g.zero, g.out_features), (u.W_q, u.scale, u.zero, u.out_features), g.in_features, g.group_size, g.nbits, w3s=g.w3s)
+                # the three-op rebuild's condition depends on the slab a row sits in (J = 9 - the slab's bit offset), and the pairing moves rows between
+                # slabs: checked again on the paired tensors, never inherited from the two layers
+                if dt != torch.float16:
+                    sub = False
+                elif g.w3s:
+                    sub = ops.w3s_meta_scalable(pair[1], pair[2], pair[3], g.in_features)
+                else:
+                    sub = ops.meta_scalable(pair[1], pair[2], pair[3], g.in_features, g.group_size, g.nbits)
+                self.blocks[-1]["gu_pair"] = [pair]
+                self.blocks[-1]["gu_pair_opts"] = ops.layer_opts((ops.OPT_META_SCALABLE if sub else 0) | (ops.OPT_W3S if g.w3s else 0))
         self.h = torch.empty(1, self.H, dtype=dt, device=dev)       # the residual stream
         self.xn = torch.empty(1, self.H, dtype=dt, device=dev)      # its normalised copy, input of the next linears
         self.delta = torch.empty(1, self.H, dtype=dt, device=dev)   # output of o / down, added by the next add_rmsnorm
@@ -179,22 +204,31 @@ class FusedLlamaStep:
         delta = None
         for b in self.blocks:
             at = b["attn"]
-            ops.add_rmsnorm(h, delta, b["n1"].weight, b["n1"].variance_epsilon, out=self.xn)
             K = self.H
-            ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
+            if self.folded:   # RMSNorm in the launch's prologue: every workgroup normalises h itself while its first weights are in flight
+                ops.gemv_block(h, b["n1"].weight, b["n1"].variance_epsilon, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], [b["q"], b["k"], b["v"]], ops.BLOCK_NORM, opts=b["qkv_opts"])
+            else:
+                ops.add_rmsnorm(h, delta, b["n1"].weight, b["n1"].variance_epsilon, out=self.xn)
+                ops.gemv_grouped(self.xn, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], outs=[b["q"], b["k"], b["v"]], opts=b["qkv_opts"])
             if self.attention == "hip":   # rotary + cache write + attention: one launch
                 att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling, splits=splits,
                                            workspace=self.attn_ws.get(splits))
             else:
                 ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
                 att, _ = self.attn_fn(at, b["qr"], b["kc"][:, :kvl].unsqueeze(0), b["vc"][:, :kvl].unsqueeze(0), mask, dropout=0.0, scaling=at.scaling)
-            o = b["o"]
+            o, d = b["o"], b["d"]
+            if self.folded:
+                # o: h += o(att) in the epilogue; gate|up: RMSNorm prologue + silu(gate) * up epilogue on the paired layer; down: h += down(a) in the epilogue
+                ops.gemv_block(att.reshape(1, -1), None, 0.0, [(o.W_q, o.scale, o.zero, o.out_features)], o.in_features, o.group_size, o.nbits, [h], ops.BLOCK_RESID,
+                               opts=ops.layer_opts(o.opts))
+                ops.gemv_block(h, b["n2"].weight, b["n2"].variance_epsilon, b["gu_pair"], K, b["gu_gs"], b["gu_nbits"], [b["a"]], ops.BLOCK_NORM | ops.BLOCK_SILU, opts=b["gu_pair_opts"])
+                ops.gemv_block(b["a"], None, 0.0, [(d.W_q, d.scale, d.zero, d.out_features)], d.in_features, d.group_size, d.nbits, [h], ops.BLOCK_RESID, opts=ops.layer_opts(d.opts))
+                continue
             ops.gemv(att.reshape(1, -1), o.W_q, o.scale, o.zero, None, o.out_features, o.in_features, o.group_size, o.nbits, out=self.delta,
                      opts=ops.layer_opts(o.opts))
             ops.add_rmsnorm(h, self.delta, b["n2"].weight, b["n2"].variance_epsilon, out=self.xn)
             ops.gemv_grouped(self.xn, b["gu"], K, b["gu_gs"], b["gu_nbits"], outs=[b["g"], b["u"]], opts=b["gu_opts"])
             ops.silu_mul(b["g"], b["u"], out=b["a"])
-            d = b["d"]
             ops.gemv(b["a"], d.W_q, d.scale, d.zero, None, d.out_features, d.in_features, d.group_size, d.nbits, out=self.delta, opts=ops.layer_opts(d.opts))
             delta = self.delta
         ops.add_rmsnorm(h, delta, inner.norm.weight, inner.norm.variance_epsilon, out=self.xn)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 5
+#define HQQ_HIP_ABI_VERSION 6
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -184,6 +184,27 @@ int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float ep
 int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* q_out, void* k_cache,
                        void* v_cache, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, int dtype, void* stream);
 int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The decoder block's launches with those steps FOLDED IN (ABI 6; csrc/gemv_block.hip): hqq_hip_gemv_grouped for ONE activation row whose
+ * prologue / epilogue does what hqq_hip_add_rmsnorm / hqq_hip_silu_mul / the residual add did as launches of their own — LlamaDecoderLayer.forward
+ * (transformers models/llama/modeling_llama.py) around HQQLinear.forward (hqq/core/quantize.py:880-898) becomes 4 launches + rotary / attention:
+ *   HQQ_BLOCK_NORM                   x is the RESIDUAL STREAM h [1, K]; every workgroup computes norm_weight * T(float(h) * rsqrt(mean(h^2) + eps))
+ *                                    itself (LlamaRMSNorm, hqq_hip_add_rmsnorm's roundings; fp32 sum of squares in a fixed order) and contracts the
+ *                                    layers with that; y[i] [1, N[i]] as hqq_hip_gemv_grouped writes them (q|k|v)
+ *   HQQ_BLOCK_NORM | HQQ_BLOCK_SILU  one layer in the PAIRED layout — the level matrix of gate on top of the level matrix of up, packed as ONE layer of
+ *                                    N = 2 x intermediate rows (hqq_amd.ops.pair_layers), so that a packed row holds gate row n and up row n —:
+ *                                    y[0] [1, N / 2] = T(silu(T(gate[n]))) * T(up[n]) (LlamaMLP.forward; hqq_hip_silu_mul's roundings); gate / up are not stored
+ *   HQQ_BLOCK_RESID                  one layer, x its input as usual; y[0] is the residual stream: h[n] = h[n] + T(result[n]) (o_proj, down_proj)
+ * fp16 / bf16; nbits 4 / 2, or 3 with HQQ_OPT_W3S; group_size 64; exact weights (HQQ_OPT_META_SCALABLE honoured); K <= 8192 for the NORM forms.
+ * No bias (the Llama linears have none), no workspace.  Same streaming loop, launch geometry and weights as hqq_hip_gemv.
+ * ------------------------------------------------------------------------------------------- */
+#define HQQ_BLOCK_NORM  1u
+#define HQQ_BLOCK_RESID 2u
+#define HQQ_BLOCK_SILU  4u
+int hqq_hip_gemv_block(int nbits, int n_layers, const void* x, const void* norm_weight, float eps, const void* const* Wq, const void* const* scale,
+                       const void* const* zero, void* const* y, const int64_t* N, int64_t K, int64_t group_size, int dtype, uint32_t opts, uint32_t flags,
+                       void* stream);
 
 /* Decode attention for ONE query per head over a static KV cache (opt-in: hqq_amd.utils.llama_fused.FusedLlamaStep(attention="hip")).
  * Replaces, in the reference's generate loop (hqq/utils/generation_hf.py:117-540), HF's call of F.scaled_dot_product_attention for a decode step:

@@ -180,8 +180,9 @@ def test_block_glue_kernels_restate_the_hf_modules(dt):
     assert torch.equal(ops.silu_mul(gt, up), F.silu(gt) * up)
 
 
+@pytest.mark.parametrize("glue", ["folded", "kernels"])
 @pytest.mark.parametrize("nbits", [4, 3])
-def test_fused_decoder_emits_the_tokens_of_the_pytorch_backend(nbits):
+def test_fused_decoder_emits_the_tokens_of_the_pytorch_backend(nbits, glue):
     """SURVEY.md §8 f3, not against itself: the graph-replayed fused decode loop (grouped GEMVs + csrc/block.hip + HF's attention function) against
     the SAME quantised model decoding with HF's generate under HQQBackend.PYTORCH_FORWARD (dequantise + dense matmul: the reference's
     arithmetic, hqq/core/quantize.py:894-898) — 32 greedy tokens, identical"""
@@ -205,10 +206,10 @@ def test_fused_decoder_emits_the_tokens_of_the_pytorch_backend(nbits):
     prepare_for_inference(model, backend="hip")
     group_llama_projections(model)
     assert llama_fused.supports(model)
-    dec = GraphedGreedyDecoder(model, max_cache_len=64)
+    dec = GraphedGreedyDecoder(model, max_cache_len=64, glue=glue)
     assert dec.fused
     got = dec.generate(ids, 32, use_graph=True)
-    assert dec.graph is not None and dec.step is not None
+    assert dec.graph is not None and dec.step is not None and dec.step.folded == (glue == "folded")
     assert torch.equal(got, want), (got.tolist(), want.tolist())
     # teacher-forced logits of the two paths on the reference's tokens: the forward tolerance, not only the argmax
     HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
