@@ -70,7 +70,7 @@ def test_rmsnorm_prologue(ops, dt, nbits, NK):
     if N % 8: N += 8 - N % 8
     Ls, Wds, opts = [], [], None
     for i in range(3):                                   # q | k | v: three layers, one launch
-        L, o, Wd = _layer(ops, N if i == 0 else max(N // 4, 8), K, nbits, seed=N + K + nbits + i, dt=dt, sub_friendly=(i < 3))
+        L, o, Wd = _layer(ops, N if i == 0 else max(N // 4 // 8 * 8, 8), K, nbits, seed=N + K + nbits + i, dt=dt, sub_friendly=(i < 3))
         Ls.append(L); Wds.append(Wd)
         opts = o if opts is None else (opts & o) | (o & ops.OPT_W3S)
     g = torch.Generator(device="cuda").manual_seed(K)
