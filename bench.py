@@ -856,11 +856,11 @@ def main():
                                      "loop": "hqq_amd.utils.generation.GraphedGreedyDecoder, fused step (hqq_amd.utils.llama_fused): per decoder block add_rmsnorm -> q|k|v (grouped GEMV) -> "
                                              "rope_cache -> HF's attention function on the static cache -> o -> add_rmsnorm (residual add inside) -> gate|up (grouped GEMV) -> silu_mul -> down; "
                                              "csrc/block.hip restates the HF modules rounding for rounding; one captured hipGraph per token, argmax fed back on the device",
-                                     "fused_step": bool(dec.fused), "glue": ("folded into the GEMV launches (csrc/gemv_block.hip): 5 launches + attention per block" if (dec.step is not None and dec.step.folded)
+                                     "fused_step": bool(dec.fused), "glue": ("folded into the GEMV launches (csrc/gemv_block.hip): 4 launches + attention per block" if (dec.step is not None and dec.step.folded)
                                                                              else "separate kernels (csrc/block.hip): 8 launches + attention per block")}
                 if dec.step is not None and dec.step.folded:
                     out["end_to_end"]["loop"] = ("hqq_amd.utils.generation.GraphedGreedyDecoder, fused step (hqq_amd.utils.llama_fused, glue folded): per decoder block q|k|v (grouped GEMV, RMSNorm in its "
-                                                 "prologue) -> rope_cache -> HF's attention function on the static cache -> o (residual add in its epilogue) -> gate|up as ONE paired layer (RMSNorm "
+                                                 "prologue, rotary embedding + KV-cache write in its epilogue) -> HF's attention function on the static cache -> o (residual add in its epilogue) -> gate|up as ONE paired layer (RMSNorm "
                                                  "prologue, SiLU * up epilogue) -> down (residual add in its epilogue); one captured hipGraph per token, argmax fed back on the device")
                 # not against itself: the first 8 greedy tokens of this loop against the SAME quantised model decoding with HF's generate under HQQBackend.PYTORCH_FORWARD
                 # (dequantise + dense matmul: the reference's arithmetic, hqq/core/quantize.py:894-898)

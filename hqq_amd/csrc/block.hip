@@ -112,14 +112,6 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(uint16_t* __restrict__
   }
 }
 
-// q_embed = (q * cos) + (rotate_half(q) * sin), rotate_half = cat(-x2, x1): every product and the sum round to T
-template <bool BF>
-__device__ __forceinline__ void rope_pair(uint16_t x1, uint16_t x2, uint16_t c1, uint16_t c2, uint16_t s1, uint16_t s2, uint16_t& o1, uint16_t& o2) {
-  using E = El<BF>;
-  o1 = E::add(E::mul(x1, c1), E::mul(E::neg(x2), s1));
-  o2 = E::add(E::mul(x2, c2), E::mul(x1, s2));
-}
-
 // ---- rotary embedding of q and k, KV-cache write.  One thread per (head, i < hd / 2): elements i and i + hd / 2 of a head ----
 template <bool BF>
 __global__ __launch_bounds__(256) void rope_cache_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,

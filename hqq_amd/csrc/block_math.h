@@ -28,6 +28,14 @@ struct El {
   static __device__ __forceinline__ uint16_t neg(uint16_t a) { return static_cast<uint16_t>(a ^ 0x8000u); }
 };
 
+// q_embed = (q * cos) + (rotate_half(q) * sin), rotate_half = cat(-x2, x1): every product and the sum round to T
+template <bool BF>
+__device__ __forceinline__ void rope_pair(uint16_t x1, uint16_t x2, uint16_t c1, uint16_t c2, uint16_t s1, uint16_t s2, uint16_t& o1, uint16_t& o2) {
+  using E = El<BF>;
+  o1 = E::add(E::mul(x1, c1), E::mul(E::neg(x2), s1));
+  o2 = E::add(E::mul(x2, c2), E::mul(x1, s2));
+}
+
 // LlamaMLP: act_fn(gate) * up — silu in fp32 (x / (1 + exp(-x))), rounded to T, then the product in T (transformers models/llama/modeling_llama.py LlamaMLP.forward)
 template <bool BF>
 __device__ __forceinline__ uint16_t silu_mul_el(uint16_t gate, uint16_t up) {

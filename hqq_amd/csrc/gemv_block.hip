@@ -8,11 +8,13 @@
 // (csrc/block.hip: add_rmsnorm x 2, rope_cache, silu_mul + 4 GEMV launches + attention); every glue launch is a dependent boundary of
 // ~2.3 us around ~0.2 us of arithmetic.  Here:
 //   q|k|v      prologue: LlamaRMSNorm(h) * w1 computed by every workgroup while its first weights are in flight   (HQQ_BLOCK_NORM)
+//              epilogue (q and k in the rotary-paired row order, hqq_amd.ops.rotary_pair_layout): apply_rotary_pos_emb on q and k,
+//              k / v written into the static cache at the position                                              (... | HQQ_BLOCK_ROPE)
 //   o          epilogue: h[n] += y[n]                                                                             (HQQ_BLOCK_RESID)
 //   gate|up    ONE paired layer (hqq_amd.ops.pair_layers: packed row p = gate row p | up row p), prologue as q|k|v,
 //              epilogue: a[n] = silu(gate[n]) * up[n] — gate and up never reach memory                           (HQQ_BLOCK_NORM | HQQ_BLOCK_SILU)
 //   down       epilogue: h[n] += y[n]                                                                             (HQQ_BLOCK_RESID)
-// = 4 launches + rope_cache + attention per block.  Arithmetic: block.hip's, rounding for rounding (block_math.h; this file is compiled with
+// = 4 launches + attention per block (5 with hqq_hip_rope_cache as a launch of its own).  Arithmetic: block.hip's, rounding for rounding (block_math.h; this file is compiled with
 // -ffp-contract=off like block.hip); the norm's fp32 sum of squares has its own fixed order (thread's elements, wave_sum, waves in order).
 // The streaming loop is the decode kernel's, unchanged: each variant is its own compilation of the kernel text (gemv_kernel.inc).
 #include <type_traits>
@@ -32,6 +34,7 @@ template <int NBITS, int M, int S, int PER> struct SlabLoop;
 template <int NBITS, int S, int PER> struct GroupConst;
 
 #define GV_KERNEL_EARLY_B 0
+#define GV_KERNEL_ROPE 0
 // ---- RMSNorm prologue (one / two passes of the workgroup over the row) ----
 #define GV_KERNEL_XPASS2 0
 #define GV_KERNEL_RESID 0
@@ -46,6 +49,21 @@ template <int NBITS, int S, int PER> struct GroupConst;
 #include "gemv_kernel.inc"
 #undef GV_KERNEL_NAME
 #undef GV_KERNEL_NORM
+// ---- RMSNorm prologue + rotary / cache-write epilogue (q|k|v with q, k in the rotary-paired row order) ----
+#undef GV_KERNEL_ROPE
+#define GV_KERNEL_ROPE 1
+#define GV_KERNEL_NORM 1
+#define GV_KERNEL_NAME gb_norm1_rope_kernel
+#include "gemv_kernel.inc"
+#undef GV_KERNEL_NAME
+#undef GV_KERNEL_NORM
+#define GV_KERNEL_NORM 2
+#define GV_KERNEL_NAME gb_norm2_rope_kernel
+#include "gemv_kernel.inc"
+#undef GV_KERNEL_NAME
+#undef GV_KERNEL_NORM
+#undef GV_KERNEL_ROPE
+#define GV_KERNEL_ROPE 0
 #undef GV_KERNEL_SILU
 // ---- RMSNorm prologue + SiLU * up epilogue (the paired gate|up layer) ----
 #define GV_KERNEL_SILU 1
@@ -77,6 +95,7 @@ template <int NBITS, int S, int PER> struct GroupConst;
 #undef GV_KERNEL_RESID
 #undef GV_KERNEL_SILU
 #undef GV_KERNEL_NORM
+#undef GV_KERNEL_ROPE
 #undef GV_KERNEL_EARLY_B
 
 namespace gb {
@@ -91,11 +110,11 @@ static int num_cus() {
   return n_cus;
 }
 
-struct Extra { const half_t* norm_w; float eps; };
+struct Extra { const half_t* norm_w; float eps; GbRope rope; };
 
 // launch geometry as gemv.hip's launch_gemv_f16 (the same persistent grid, the same 8 x 2 shape for single layers of at most one packed
 // row per wave, the same few-rows / long-K row sharing): the folded variants must not stream differently from the kernels they replace
-template <int KIND /* 0 norm, 1 norm + silu, 2 resid */, bool BF16, bool SUB, int WPG = GV_WAVES>
+template <int KIND /* 0 norm, 1 norm + silu, 2 resid, 3 norm + rope */, bool BF16, bool SUB, int WPG = GV_WAVES>
 static int launch(const GvArgs& args, const Extra& ex, hipStream_t st) {
   constexpr int NB = GB_NBITS;
   constexpr int PER = NB == 3 ? 2 : 8 / NB;
@@ -115,6 +134,7 @@ static int launch(const GvArgs& args, const Extra& ex, hipStream_t st) {
   const void* kern;
   int variant = two_pass ? 1 : 0;
   if constexpr (KIND == 0) kern = two_pass ? reinterpret_cast<const void*>(gb_norm2_kernel<NB, 1, true, true, BF16, SUB, WPG>) : reinterpret_cast<const void*>(gb_norm1_kernel<NB, 1, true, true, BF16, SUB, WPG>);
+  else if constexpr (KIND == 3) kern = two_pass ? reinterpret_cast<const void*>(gb_norm2_rope_kernel<NB, 1, true, true, BF16, SUB, WPG>) : reinterpret_cast<const void*>(gb_norm1_rope_kernel<NB, 1, true, true, BF16, SUB, WPG>);
   else if constexpr (KIND == 1) kern = two_pass ? reinterpret_cast<const void*>(gb_norm2_silu_kernel<NB, 1, true, true, BF16, SUB, WPG>) : reinterpret_cast<const void*>(gb_norm1_silu_kernel<NB, 1, true, true, BF16, SUB, WPG>);
   else kern = two_pass ? reinterpret_cast<const void*>(gb_resid_xp2_kernel<NB, 1, true, true, BF16, SUB, WPG>) : reinterpret_cast<const void*>(gb_resid_kernel<NB, 1, true, true, BF16, SUB, WPG>);
   int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
@@ -156,6 +176,9 @@ static int launch(const GvArgs& args, const Extra& ex, hipStream_t st) {
   if constexpr (KIND == 0) {
     if (two_pass) hipLaunchKernelGGL((gb_norm2_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
     else hipLaunchKernelGGL((gb_norm1_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
+  } else if constexpr (KIND == 3) {
+    if (two_pass) hipLaunchKernelGGL((gb_norm2_rope_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps, ex.rope);
+    else hipLaunchKernelGGL((gb_norm1_rope_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps, ex.rope);
   } else if constexpr (KIND == 1) {
     if (two_pass) hipLaunchKernelGGL((gb_norm2_silu_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
     else hipLaunchKernelGGL((gb_norm1_silu_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
@@ -177,12 +200,13 @@ static int by_dtype(const GvArgs& a, const Extra& ex, int dtype, uint32_t opts, 
 
 #define GB_CAT2(a, b) a##b
 #define GB_CAT(a, b) GB_CAT2(a, b)
-// one object per bit width (Makefile): gemv_block_run_4 / _3 / _2.  kind: 0 norm, 1 norm + silu, 2 resid
-int GB_CAT(gemv_block_run_, GB_NBITS)(int kind, const GvArgs& a, const half_t* norm_w, float eps, int dtype, uint32_t opts, hipStream_t st) {
-  const gb::Extra ex{norm_w, eps};
+// one object per bit width (Makefile): gemv_block_run_4 / _3 / _2.  kind: 0 norm, 1 norm + silu, 2 resid, 3 norm + rope
+int GB_CAT(gemv_block_run_, GB_NBITS)(int kind, const GvArgs& a, const half_t* norm_w, float eps, const GbRope& rope, int dtype, uint32_t opts, hipStream_t st) {
+  const gb::Extra ex{norm_w, eps, rope};
   switch (kind) {
     case 0: return gb::by_dtype<0>(a, ex, dtype, opts, st);
     case 1: return gb::by_dtype<1>(a, ex, dtype, opts, st);
+    case 3: return gb::by_dtype<3>(a, ex, dtype, opts, st);
     default: return gb::by_dtype<2>(a, ex, dtype, opts, st);
   }
 }
@@ -191,22 +215,32 @@ int GB_CAT(gemv_block_run_, GB_NBITS)(int kind, const GvArgs& a, const half_t* n
 
 #if GB_NBITS == 4
 namespace hqq {
-int gemv_block_run_3(int kind, const GvArgs& a, const half_t* norm_w, float eps, int dtype, uint32_t opts, hipStream_t st);
-int gemv_block_run_2(int kind, const GvArgs& a, const half_t* norm_w, float eps, int dtype, uint32_t opts, hipStream_t st);
+int gemv_block_run_3(int kind, const GvArgs& a, const half_t* norm_w, float eps, const GbRope& rope, int dtype, uint32_t opts, hipStream_t st);
+int gemv_block_run_2(int kind, const GvArgs& a, const half_t* norm_w, float eps, const GbRope& rope, int dtype, uint32_t opts, hipStream_t st);
 }
 using namespace hqq;
 
 extern "C" int hqq_hip_gemv_block(int nbits, int n_layers, const void* x, const void* norm_weight, float eps, const void* const* Wq, const void* const* scale,
                                   const void* const* zero, void* const* y, const int64_t* N, int64_t K, int64_t group_size, int dtype, uint32_t opts, uint32_t flags,
-                                  void* stream) {
+                                  const hqq_rope_t* rope_args, void* stream) {
   clear_stale_error();
   if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemv_block: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
-  const bool norm = flags & HQQ_BLOCK_NORM, resid = flags & HQQ_BLOCK_RESID, silu = flags & HQQ_BLOCK_SILU;
-  if ((flags & ~(HQQ_BLOCK_NORM | HQQ_BLOCK_RESID | HQQ_BLOCK_SILU)) || !(norm || resid) || (resid && (norm || silu)) || (silu && !norm)) {
-    set_error("hqq_hip_gemv_block: flags 0x%x: HQQ_BLOCK_NORM, HQQ_BLOCK_NORM | HQQ_BLOCK_SILU or HQQ_BLOCK_RESID", flags);
+  const bool norm = flags & HQQ_BLOCK_NORM, resid = flags & HQQ_BLOCK_RESID, silu = flags & HQQ_BLOCK_SILU, rope = flags & HQQ_BLOCK_ROPE;
+  if ((flags & ~(HQQ_BLOCK_NORM | HQQ_BLOCK_RESID | HQQ_BLOCK_SILU | HQQ_BLOCK_ROPE)) || !(norm || resid) || (resid && (norm || silu || rope)) || ((silu || rope) && !norm) || (silu && rope)) {
+    set_error("hqq_hip_gemv_block: flags 0x%x: HQQ_BLOCK_NORM, HQQ_BLOCK_NORM | HQQ_BLOCK_ROPE, HQQ_BLOCK_NORM | HQQ_BLOCK_SILU or HQQ_BLOCK_RESID", flags);
     return HQQ_ERR_SHAPE;
   }
-  if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || ((resid || silu) && n_layers != 1)) { set_error("hqq_hip_gemv_block: n_layers=%d (the residual / SiLU epilogues serve ONE layer)", n_layers); return HQQ_ERR_SHAPE; }
+  if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || ((resid || silu) && n_layers != 1) || (rope && n_layers != 3)) {
+    set_error("hqq_hip_gemv_block: n_layers=%d (the residual / SiLU epilogues serve ONE layer, the rotary one q | k | v)", n_layers);
+    return HQQ_ERR_SHAPE;
+  }
+  GbRope gr{nullptr, nullptr, nullptr, 0, 0};
+  if (rope) {
+    if (!rope_args || !rope_args->cos || !rope_args->sin || !rope_args->pos || rope_args->head_dim < 2 || rope_args->head_dim % 2 || rope_args->head_dim > 4096 || rope_args->cache_len < 1 ||
+        rope_args->cache_len > INT32_MAX) { set_error("hqq_hip_gemv_block: HQQ_BLOCK_ROPE needs cos / sin / pos, an even head_dim and a cache length"); return HQQ_ERR_SHAPE; }
+    if (!N || N[0] % rope_args->head_dim || N[1] % rope_args->head_dim || N[1] != N[2]) { set_error("hqq_hip_gemv_block: q / k / v widths must be whole heads, k and v alike"); return HQQ_ERR_SHAPE; }
+    gr = GbRope{static_cast<const uint16_t*>(rope_args->cos), static_cast<const uint16_t*>(rope_args->sin), rope_args->pos, static_cast<int>(rope_args->head_dim), static_cast<int>(rope_args->cache_len)};
+  }
   if (!x || !Wq || !scale || !zero || !y || !N || (norm && !norm_weight)) { set_error("hqq_hip_gemv_block: null argument"); return HQQ_ERR_SHAPE; }
   if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_gemv_block: dtype %d not covered (fp16 / bf16)", dtype); return HQQ_ERR_UNSUPPORTED; }
   const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);
@@ -246,13 +280,13 @@ extern "C" int hqq_hip_gemv_block(int nbits, int n_layers, const void* x, const 
 #ifdef GV_LAB_TS
   a.ts = nullptr;
 #endif
-  const int kind = resid ? 2 : (silu ? 1 : 0);
+  const int kind = resid ? 2 : (silu ? 1 : (rope ? 3 : 0));
   const half_t* nw = static_cast<const half_t*>(norm_weight);
   hipStream_t st = as_stream(stream);
   switch (nbits) {
-    case 4: return gemv_block_run_4(kind, a, nw, eps, dtype, opts, st);
-    case 3: return gemv_block_run_3(kind, a, nw, eps, dtype, opts, st);
-    default: return gemv_block_run_2(kind, a, nw, eps, dtype, opts, st);
+    case 4: return gemv_block_run_4(kind, a, nw, eps, gr, dtype, opts, st);
+    case 3: return gemv_block_run_3(kind, a, nw, eps, gr, dtype, opts, st);
+    default: return gemv_block_run_2(kind, a, nw, eps, gr, dtype, opts, st);
   }
 }
 #endif

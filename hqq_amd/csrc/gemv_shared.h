@@ -102,6 +102,14 @@ static_assert(GV_MAXL == 4, "the scalar parameter list below spells four layers 
 #define GV_IN_PACK \
   GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ GV_IN_TS_PACK }
 
+// gemv_block.hip's rotary epilogue (kernel parameter, read when a row ends): cos / sin [head_dim] of the position, the position itself in device memory
+struct GbRope {
+  const uint16_t* cos;
+  const uint16_t* sin;
+  const int64_t* pos;
+  int hd, cache_len;
+};
+
 // the layer a wave is currently streaming (all wave-uniform -> SGPRs)
 struct LayerCtx {
   const uint8_t* Wq;

@@ -336,13 +336,29 @@ def block_covers(dtype, K: int, group_size, nbits: int, w3s: bool, norm: bool) -
             and (not norm or K <= 8192) and K * 2 <= 144 * 1024 - 4096)
 
 
-def gemv_block(x: Tensor, norm_weight, eps: float, layers, K: int, group_size: int, nbits: int, outs, flags: int, opts=None):
+BLOCK_ROPE = 8
+
+
+def gemv_block(x: Tensor, norm_weight, eps: float, layers, K: int, group_size: int, nbits: int, outs, flags: int, opts=None, rope=None):
     """The decoder block's launches with the glue folded in (csrc/gemv_block.hip; include/hqq_hip.h hqq_hip_gemv_block), ONE activation row:
       BLOCK_NORM               x = the residual stream; layers (W_q, scale, zero, N) like gemv_grouped's; outs[i] [1, N_i]
       BLOCK_NORM | BLOCK_SILU  ONE layer from pair_layers(gate, up): outs[0] [1, N / 2] = silu(gate) * up
-      BLOCK_RESID              ONE layer; outs[0] is the residual stream, updated in place: h += layer(x)"""
+      BLOCK_RESID              ONE layer; outs[0] is the residual stream, updated in place: h += layer(x)
+      BLOCK_NORM | BLOCK_ROPE  q | k | v with q and k from rotary_pair_layout(): outs = [q_out [n_heads, hd], k_cache, v_cache [n_kv, L, hd]];
+                               rope = (cos [hd], sin [hd], pos [1] int64 on the device, head_dim, cache_len): rope_cache() in the launch's epilogue"""
     import ctypes
     n = len(layers)
+    rp = None
+    if flags & BLOCK_ROPE:
+        class _Rope(ctypes.Structure):
+            _fields_ = [("cos", ctypes.c_void_p), ("sin", ctypes.c_void_p), ("pos", ctypes.c_void_p), ("head_dim", ctypes.c_int64), ("cache_len", ctypes.c_int64)]
+        cos, sin, pos, hd, L = rope
+        _dev(cos, sin, pos)
+        if cos.numel() != hd or sin.numel() != hd or pos.dtype != torch.int64 or cos.dtype != x.dtype or sin.dtype != x.dtype:
+            raise ValueError("hqq_amd: rope = (cos [head_dim], sin [head_dim] in the compute dtype, pos int64 on the device, head_dim, cache_len)")
+        if outs[1].shape[-1] != hd or outs[1].shape[-2] != L or outs[1].shape != outs[2].shape or not (outs[1].is_contiguous() and outs[2].is_contiguous()):
+            raise ValueError("hqq_amd: the caches must be contiguous [n_kv_heads, cache_len, head_dim] tensors")
+        rp = ctypes.byref(_Rope(_p(cos), _p(sin), _p(pos), int(hd), int(L)))
     _dev(x, norm_weight, *[t for L in layers for t in L[:3]], *outs)
     if x.numel() != K:
         raise ValueError(f"hqq_amd: gemv_block serves one activation row of {K} features, got {tuple(x.shape)}")
@@ -351,7 +367,7 @@ def gemv_block(x: Tensor, norm_weight, eps: float, layers, K: int, group_size: i
     with torch.cuda.device(x.device):
         rc = _C.lib().hqq_hip_gemv_block(int(nbits), n, _p(x), _p(norm_weight), float(eps), VP(*[_p(L[0]) for L in layers]), VP(*[_p(L[1]) for L in layers]),
                                          VP(*[_p(L[2]) for L in layers]), VP(*[_p(t) for t in outs]), (ctypes.c_int64 * n)(*[int(L[-1]) for L in layers]),
-                                         int(K), int(group_size), _dt(x.dtype), o, int(flags), _stream())
+                                         int(K), int(group_size), _dt(x.dtype), o, int(flags), rp, _stream())
     _C.check(rc, "hqq_hip_gemv_block")
     return outs
 
@@ -374,6 +390,26 @@ def pair_layers(gate, up, K: int, group_size: int, nbits: int, w3s: bool = False
     if w3s:
         W = w3s_pack(W, 2 * N, K)
     return W, torch.cat([sg.reshape(-1), su.reshape(-1)]).contiguous(), torch.cat([zg.reshape(-1), zu.reshape(-1)]).contiguous(), 2 * N
+
+
+def rotary_pair_layout(layer, K: int, group_size: int, nbits: int, head_dim: int, w3s: bool = False):
+    """The ROTARY-PAIRED row order of a q_proj / k_proj layer: element i < head_dim / 2 of head h becomes row h head_dim / 2 + i, its rotary partner
+    i + head_dim / 2 row N / 2 + h head_dim / 2 + i — so that BitPack's row slabs hold both in ONE packed row and hqq_hip_gemv_block's epilogue can apply
+    apply_rotary_pos_emb inside the wave that finishes the row (its outputs are written back in the natural order).  layer: (W_q, scale, zero, N) as the
+    layer holds it; returns a permuted copy (the original is untouched: state_dict() and the prefill path keep using it).  Same levels, scale, zero per row."""
+    W, s, z, N = layer
+    if N % head_dim or head_dim % 2:
+        raise ValueError("hqq_amd: rotary_pair_layout needs whole heads of an even size")
+    G = K // group_size
+    if w3s:
+        W = w3s_unpack(W, N, K)
+    rows = torch.arange(N, device=s.device).view(N // head_dim, head_dim)
+    perm = torch.cat([rows[:, :head_dim // 2].reshape(-1), rows[:, head_dim // 2:].reshape(-1)])
+    U = unpack(nbits, W)[:N * G].reshape(N, G * group_size).index_select(0, perm).reshape(N * G, group_size).contiguous()
+    Wp = pack(nbits, U)
+    if w3s:
+        Wp = w3s_pack(Wp, N, K)
+    return Wp, s.reshape(N, G).index_select(0, perm).reshape(-1).contiguous(), z.reshape(N, G).index_select(0, perm).reshape(-1).contiguous(), N
 
 
 EXCHANGE_MAX_RANKS = 16

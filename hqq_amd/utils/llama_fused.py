@@ -7,7 +7,8 @@ residual adds 2, ...): 79 % of a token once the linears are fused.  Here a block
     add_rmsnorm (the residual add of o rides in it) -> gate|up (one grouped GEMV) -> silu_mul -> down (its residual add rides in the next block's add_rmsnorm)
 = 8 launches + the attention's (glue="kernels").  Round 5 folds the glue into the launches either side of it (glue="folded", the default where
 csrc/gemv_block.hip covers the model): q|k|v with the RMSNorm in its prologue -> rope_cache -> attention -> o with the residual add in its epilogue ->
-ONE paired gate|up layer (RMSNorm prologue, SiLU * up epilogue) -> down with the residual add in its epilogue = 5 launches + the attention's.  The three glue kernels (csrc/block.hip) restate the HF modules rounding for rounding and the attention is
+ONE paired gate|up layer (RMSNorm prologue, SiLU * up epilogue) -> down with the residual add in its epilogue; and with q / k in the rotary-paired row order
+(ops.rotary_pair_layout) the rotary embedding and the cache write ride in the q|k|v launch's epilogue too = 4 launches + the attention's.  The three glue kernels (csrc/block.hip) restate the HF modules rounding for rounding and the attention is
 HF's function on HF's cache tensors, so the step emits the same tokens as `model(...)` does on the same kernels — and as the same model
 under HQQBackend.PYTORCH_FORWARD does on the reference's arithmetic (tests/test_model_gpu.py).
 
@@ -142,6 +143,18 @@ class FusedLlamaStep:
                 "g": torch.empty(1, g.out_features, dtype=dt, device=dev), "u": torch.empty(1, u.out_features, dtype=dt, device=dev),
                 "a": torch.empty(1, g.out_features, dtype=dt, device=dev),
             })
+            if self.folded and attention != "hip" and self.hd % 2 == 0:
+                # q and k in the rotary-paired row order (ops.rotary_pair_layout): the q|k|v launch's epilogue applies the rotary embedding and writes the cache
+                # (the kernel attention folds the rotary embedding into the attention launch instead: it keeps the natural order)
+                def _sub_ok(t, L_):
+                    if dt != torch.float16:
+                        return False
+                    return ops.w3s_meta_scalable(t[1], t[2], t[3], L_.in_features) if L_.w3s else ops.meta_scalable(t[1], t[2], t[3], L_.in_features, L_.group_size, L_.nbits)
+                qp = ops.rotary_pair_layout((q.W_q, q.scale, q.zero, q.out_features), q.in_features, q.group_size, q.nbits, self.hd, w3s=q.w3s)
+                kp = ops.rotary_pair_layout((k.W_q, k.scale, k.zero, k.out_features), k.in_features, k.group_size, k.nbits, self.hd, w3s=k.w3s)
+                sub = _sub_ok(qp, q) and _sub_ok(kp, k) and bool(v.opts & ops.OPT_META_SCALABLE)   # (the permutation moves rows between slabs: checked again)
+                self.blocks[-1]["qkv_rope"] = [qp, kp, (v.W_q, v.scale, v.zero, v.out_features)]
+                self.blocks[-1]["qkv_rope_opts"] = ops.layer_opts((ops.OPT_META_SCALABLE if sub else 0) | (ops.OPT_W3S if q.w3s else 0))
             if self.folded:   # gate|up as ONE paired layer: a packed row holds gate row n and up row n (ops.pair_layers); the layers' own tensors stay as they are
                 pair = ops.pair_layers((g.W_q, g.scale, g.zero, g.out_features), (u.W_q, u.scale, u.zero, u.out_features), g.in_features, g.group_size, g.nbits, w3s=g.w3s)
                 # the three-op rebuild's condition depends on the slab a row sits in (J = 9 - the slab's bit offset), and the pairing moves rows between
@@ -205,7 +218,10 @@ class FusedLlamaStep:
         for b in self.blocks:
             at = b["attn"]
             K = self.H
-            if self.folded:   # RMSNorm in the launch's prologue: every workgroup normalises h itself while its first weights are in flight
+            if self.folded and "qkv_rope" in b:   # RMSNorm in the prologue, rotary embedding + cache write in the epilogue: q|k|v lands rotated in qr / the caches
+                ops.gemv_block(h, b["n1"].weight, b["n1"].variance_epsilon, b["qkv_rope"], K, b["qkv_gs"], b["qkv_nbits"], [b["qr"], b["kc"], b["vc"]],
+                               ops.BLOCK_NORM | ops.BLOCK_ROPE, opts=b["qkv_rope_opts"], rope=(cos, sin, pos, self.hd, self.L))
+            elif self.folded:   # RMSNorm in the launch's prologue: every workgroup normalises h itself while its first weights are in flight
                 ops.gemv_block(h, b["n1"].weight, b["n1"].variance_epsilon, b["qkv"], K, b["qkv_gs"], b["qkv_nbits"], [b["q"], b["k"], b["v"]], ops.BLOCK_NORM, opts=b["qkv_opts"])
             else:
                 ops.add_rmsnorm(h, delta, b["n1"].weight, b["n1"].variance_epsilon, out=self.xn)
@@ -214,7 +230,8 @@ class FusedLlamaStep:
                 att = ops.rope_attn_decode(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], self.att, at.scaling, splits=splits,
                                            workspace=self.attn_ws.get(splits))
             else:
-                ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
+                if not (self.folded and "qkv_rope" in b):
+                    ops.rope_cache(b["q"], b["k"], b["v"], cos, sin, pos, b["kc"], b["vc"], b["qr"])
                 att, _ = self.attn_fn(at, b["qr"], b["kc"][:, :kvl].unsqueeze(0), b["vc"][:, :kvl].unsqueeze(0), mask, dropout=0.0, scaling=at.scaling)
             o, d = b["o"], b["d"]
             if self.folded:

@@ -202,9 +202,22 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
 #define HQQ_BLOCK_NORM  1u
 #define HQQ_BLOCK_RESID 2u
 #define HQQ_BLOCK_SILU  4u
+#define HQQ_BLOCK_ROPE  8u
+/*   HQQ_BLOCK_NORM | HQQ_BLOCK_ROPE  the q | k | v group (n_layers = 3) with hqq_hip_rope_cache in its epilogue.  q and k in the ROTARY-PAIRED row order
+ *                                    (hqq_amd.ops.rotary_pair_layout: element i < head_dim / 2 of head h is row h head_dim / 2 + i, its partner i + head_dim / 2
+ *                                    row N / 2 + h head_dim / 2 + i — BitPack's row slabs then hold both in one packed row), v as it is.  y[0] = q_out
+ *                                    [n_heads, head_dim] (rotated, natural order), y[1] / y[2] = the key / value caches [n_kv_heads, cache_len, head_dim]: the
+ *                                    rotated key and the value are written at position *rope->pos (device memory: graph-replay safe; outside the cache: nothing).
+ *                                    apply_rotary_pos_emb / StaticLayer.update, rounding for rounding as hqq_hip_rope_cache.  rope: NULL without the flag. */
+typedef struct {
+  const void* cos;       /* [head_dim] of the position, the compute dtype */
+  const void* sin;
+  const int64_t* pos;    /* device memory */
+  int64_t head_dim, cache_len;
+} hqq_rope_t;
 int hqq_hip_gemv_block(int nbits, int n_layers, const void* x, const void* norm_weight, float eps, const void* const* Wq, const void* const* scale,
                        const void* const* zero, void* const* y, const int64_t* N, int64_t K, int64_t group_size, int dtype, uint32_t opts, uint32_t flags,
-                       void* stream);
+                       const hqq_rope_t* rope, void* stream);
 
 /* Decode attention for ONE query per head over a static KV cache (opt-in: hqq_amd.utils.llama_fused.FusedLlamaStep(attention="hip")).
  * Replaces, in the reference's generate loop (hqq/utils/generation_hf.py:117-540), HF's call of F.scaled_dot_product_attention for a decode step:

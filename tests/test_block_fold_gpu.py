@@ -168,3 +168,40 @@ def test_gemv_block_argument_errors_are_loud(ops):
         ops.gemv_block(x, x, 0.0, [L], 64, 32, 4, [y], ops.BLOCK_NORM)                    # group_size 32
     with pytest.raises(ValueError):
         ops.gemv_block(torch.zeros(2, 64, dtype=torch.float16, device="cuda"), x, 0.0, [L], 64, 64, 4, [y], ops.BLOCK_NORM)   # one activation row
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+@pytest.mark.parametrize("shape", [(32, 32, 128, 4096), (8, 2, 64, 1024), (4, 4, 64, 256), (16, 4, 128, 8192)])   # (n_heads, n_kv_heads, head_dim, hidden)
+def test_rotary_epilogue_equals_rope_cache_on_the_same_projections(ops, dt, nbits, shape):
+    """q | k | v with q and k in the rotary-paired row order: the launch's epilogue must leave exactly what hqq_hip_rope_cache leaves when it is run on
+    the projections of the launch WITHOUT that epilogue (same kernel text, same prologue: the rows' results are the same bits, permuted) — rotated q,
+    the key / value caches at the position, nothing else touched; and a position outside the cache writes nothing"""
+    nh, nkv, hd, K = shape
+    L = 96
+    q, oq, _ = _layer(ops, nh * hd, K, nbits, seed=11 + nbits + K, dt=dt)
+    k, ok_, _ = _layer(ops, nkv * hd, K, nbits, seed=12 + nbits + K, dt=dt, sub_friendly=False)
+    v, ov, _ = _layer(ops, nkv * hd, K, nbits, seed=13 + nbits + K, dt=dt)
+    w3 = nbits == 3
+    qp = ops.rotary_pair_layout(q, K, 64, nbits, hd, w3s=w3)
+    kp = ops.rotary_pair_layout(k, K, 64, nbits, hd, w3s=w3)
+    base = ops.OPT_W3S if w3 else 0
+    g = torch.Generator(device="cuda").manual_seed(K + nh)
+    h = (torch.randn(1, K, device="cuda", generator=g) * 1.3).to(dt)
+    w = (1 + 0.1 * torch.randn(K, device="cuda", generator=g)).to(dt)
+    cos = torch.randn(hd, device="cuda", generator=g).to(dt)
+    sin = torch.randn(hd, device="cuda", generator=g).to(dt)
+    eps = 1e-5
+    yq = torch.empty(1, nh * hd, dtype=dt, device="cuda"); yk = torch.empty(1, nkv * hd, dtype=dt, device="cuda"); yv = torch.empty_like(yk)
+    ops.gemv_block(h, w, eps, [q, k, v], K, 64, nbits, [yq, yk, yv], ops.BLOCK_NORM, opts=base)
+    for pos_v in (0, 37, L - 1, L, -1):
+        pos = torch.tensor([pos_v], device="cuda")
+        kc1 = torch.full((nkv, L, hd), 7.0, dtype=dt, device="cuda"); vc1 = torch.full((nkv, L, hd), 5.0, dtype=dt, device="cuda")
+        kc2, vc2 = kc1.clone(), vc1.clone()
+        qr1 = torch.empty(1, nh, 1, hd, dtype=dt, device="cuda"); qr2 = torch.full_like(qr1, float("nan"))
+        ops.rope_cache(yq, yk, yv, cos, sin, pos, kc1, vc1, qr1)
+        ops.gemv_block(h, w, eps, [qp, kp, v], K, 64, nbits, [qr2, kc2, vc2], ops.BLOCK_NORM | ops.BLOCK_ROPE, opts=base, rope=(cos, sin, pos, hd, L))
+        assert torch.equal(qr1, qr2), pos_v
+        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), pos_v
+        if not 0 <= pos_v < L:
+            assert bool((kc2 == 7.0).all()) and bool((vc2 == 5.0).all())
