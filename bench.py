@@ -928,6 +928,42 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
+        # one rank's share of the 8-way column-sharded 70B stack (BASELINE.json configs[4]) on THIS GPU alone: the compute side of the scaling
+        # curve DESIGN.md section 6 expects, as a driver-run number.  No exchange, no second GPU: NOT a multi-GPU measurement.
+        if nbits == 4 and os.environ.get("HQQ_BENCH_SHARD8", "1") != "0":
+            try:
+                torch.cuda.empty_cache()
+                P8, nb70 = 8, N_BLOCKS_70B
+                sblocks = [{name: make_layer(ops, name, N_ // P8, K_, 4, dev, seed=50000 + 16 * b + i, random_codes=True, cd=cd)
+                            for i, (name, N_, K_) in enumerate(LLAMA2_70B_BLOCK)} for b in range(nb70)]
+                full_bytes = {m_: nb70 * sum(gemv_bytes(N_, K_, 4, m_) for _, N_, K_ in LLAMA2_70B_BLOCK) for m_ in (1, 32)}
+                shard_bytes = {m_: nb70 * sum(gemv_bytes(N_ // P8, K_, 4, m_) for _, N_, K_ in LLAMA2_70B_BLOCK) for m_ in (1, 32)}
+                res8 = {}
+                for m_ in (1, 32):
+                    xs8 = {K_: torch.randn(m_, K_, device=dev, generator=gx).to(cd) for K_ in sorted({K_ for _, _, K_ in LLAMA2_70B_BLOCK})}
+                    o8 = {grp: [torch.empty(m_, sblocks[0][n].N, device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+
+                    def step8(xs8=xs8, o8=o8):
+                        for blk in sblocks:
+                            for grp in EXCHANGE_GROUPS:
+                                Ls = [blk[n] for n in grp]
+                                ops.gemv_grouped(xs8[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, 4, outs=o8[grp], opts=group_opts(Ls))
+                    r8, g8 = _graphed(step8, use_graph, rank)
+                    w8, d8 = _timed(r8, max(5, a.steps // 2), 3)
+                    res8[f"bs={m_}"] = {"ms_per_step": round(w8 * 1e3, 4), "launches_per_step": nb70 * len(EXCHANGE_GROUPS), "avg_launch_us": round(d8 / (nb70 * len(EXCHANGE_GROUPS)) * 1e6, 3),
+                                        "shard_GB_s": round(shard_bytes[m_] / w8 / 1e9, 1), "roofline_frac_of_this_gpu": round(shard_bytes[m_] / d8 / 1e9 / HBM_PEAK_GBS, 4),
+                                        "if_eight_ranks_computed_like_this_and_exchanged_for_free": {
+                                            "tok_s": round(m_ / w8, 1), "whole_stack_GB_s": round(full_bytes[m_] / w8 / 1e9, 1),
+                                            "frac_of_8_gpu_roofline": round(full_bytes[m_] / w8 / 1e9 / (P8 * HBM_PEAK_GBS), 4)}}
+                    del r8
+                out["shard_of_8"] = {"what": "ONE rank's compute of the Llama-2-70B linear stack column-sharded 8 ways (hqq_amd/shard.py: N / 8 output columns of every layer, 80 blocks, int4 gs=64, "
+                                             "random codes), timed on this single GPU: one rank's compute, NO exchange, nothing measured on more than one GPU", **res8,
+                                     "note": "the per-GPU launches of the 8-way shard (q|k|v 10.9 MB, o 4.7, gate|up 33, down 16.5 MB per launch) are smaller than the 7B stack's: every launch pays the same "
+                                             "~4 us of fixed cost on fewer bytes, so the bs = 1 fraction of the node's roofline can only fall with the rank count (DESIGN.md section 6); the exchange comes on top"}
+                del sblocks
+                torch.cuda.empty_cache()
+            except Exception as e:
+                out["shard_of_8"] = {"error": repr(e)}
         out["legs"] = legs
 
     if rank == 0:

@@ -6,7 +6,8 @@ a rank does not own a contiguous range of output rows but the packed-row block
     packed rows [r*Np/P, (r+1)*Np/P),  Np = N/per          (a zero-copy slice of the reference W_q)
 i.e. the `per` output slabs  slot*N/per + [r*n', (r+1)*n'),  n' = N/(per*P).  Seen on its own that slice is a complete
 packed layer with N/P rows; the all-gather returns [P, M, N/P] in (rank, slab, n') order, and `unpermute` maps it back.
-3-bit containers mix rows of unrelated slabs (step = ceil(R/10)), so the shard is re-packed from the unpacked rows.
+3-bit containers mix rows of unrelated slabs (step = ceil(R/10)), so the shard is re-packed from the unpacked rows — and, on a GPU, kept in the 3-bit
+stream layout (csrc/w3s.h) so that a sharded int3 layer runs the same one-launch kernels as a patched unsharded one (ShardedHQQForward; round 5).
 """
 from __future__ import annotations
 
@@ -95,7 +96,16 @@ class ShardedHQQForward:
         self.rank = dist.get_rank(group)
         self.N, self.K, self.gs, self.nbits = N, K, group_size, nbits
         self.Wq, self.scale, self.zero, self.bias, self.n_loc = shard_packed(W_q, scale, zero, bias, N, K, group_size, nbits, self.rank, self.world)
-        self._local = local_forward or (lambda x: ops.forward(x, self.Wq, self.scale, self.zero, self.bias, self.n_loc, K, group_size, nbits))
+        self.opts = 0
+        if local_forward is None and nbits == 3 and self.Wq.is_cuda and ops.w3s_covers(self.n_loc, K, group_size):
+            # a 3-bit shard is re-packed anyway (the reference container mixes unrelated rows): keep it in the 3-bit STREAM layout (csrc/w3s.h), which
+            # runs through the 4-bit container's kernels — one launch per stage instead of two (0.38 instead of 0.16 of the HBM roofline on the 7B stack)
+            self.Wq = ops.w3s_pack(self.Wq, self.n_loc, K)
+            self.opts = ops.OPT_W3S | (ops.OPT_META_SCALABLE if (self.scale.dtype == torch.float16 and ops.w3s_meta_scalable(self.scale, self.zero, self.n_loc, K)) else 0)
+        elif local_forward is None and nbits in (8, 4, 2) and self.Wq.is_cuda and self.scale.dtype == torch.float16 and group_size and K % group_size == 0 and \
+                ops.meta_scalable(self.scale, self.zero, self.n_loc, K, group_size, nbits):
+            self.opts = ops.OPT_META_SCALABLE   # (the shard is a complete packed layer: its own check decides the three-op rebuild)
+        self._local = local_forward or (lambda x: ops.forward(x, self.Wq, self.scale, self.zero, self.bias, self.n_loc, K, group_size, nbits, opts=ops.layer_opts(self.opts)))
 
     # rows per chunk of a long prompt: the shard's GEMM of chunk c + 1 runs while chunk c's outputs are gathered (at
     # M = 65,536 a rank receives 896 MiB per layer — the gather is as long as the GEMM unless it overlaps it).  0 disables chunking

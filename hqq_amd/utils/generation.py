@@ -16,7 +16,8 @@ class GraphedGreedyDecoder:
     function on HF's cache: the same tokens in a third of the launches; since round 5 (glue="auto") the RMSNorms, the residual adds and SiLU * up
     ride inside the GEMV launches themselves: 5 launches + attention per decoder block.  Any other model, or fused=False: the model's own forward."""
 
-    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa", bucket_cache: bool = True, glue: str = "auto"):
+    def __init__(self, model, max_cache_len: int = 512, fused: bool = True, attention: str = "sdpa", bucket_cache: bool = True, glue: str = "auto",
+                 do_sample: bool = False, temperature: float = 0.6, top_k: int | None = 5):
         from transformers import StaticCache
         from . import llama_fused
         self.model = model.eval()
@@ -24,6 +25,9 @@ class GraphedGreedyDecoder:
         self._fused_mod = llama_fused
         self.attention = attention   # "sdpa": HF's attention function (token-identical to model(...)); "hip": the decode-attention kernel (faster, within rounding)
         self.glue = glue             # "auto" / "folded": RMSNorm, residual adds and SiLU * up inside the GEMV launches (csrc/gemv_block.hip); "kernels": round 4's separate glue kernels
+        # sampling (the reference's HFGenerator(do_sample=True, temperature=0.6, top_k=5), hqq/utils/generation_hf.py:250-311): applied to the logits ON THE
+        # DEVICE inside the captured step — no host round trip, the generator's Philox offset advances per replay —; greedy argmax otherwise
+        self.do_sample, self.temperature, self.top_k = bool(do_sample), float(temperature), (None if top_k is None else int(top_k))
         self.bucket_cache = bucket_cache   # attention="sdpa": attend over a bucket of the static cache just above the position (False: all of it)
         self.step = None
         self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
@@ -52,24 +56,36 @@ class GraphedGreedyDecoder:
             b = -(-n // 512) * 512
         return min(b, self.max_cache_len)
 
+    def _pick(self, logits: Tensor) -> Tensor:
+        """logits [1, vocab] -> the next token [1, 1].  Greedy: argmax.  do_sample: temperature, then the top_k cut, then one draw from the softmax by the
+        exponential-race form of a categorical draw (argmax of p / e, e ~ Exp(1)): elementwise kernels + two reductions, nothing leaves the device"""
+        if not self.do_sample:
+            return logits.argmax(-1, keepdim=True)
+        z = logits.float() / max(self.temperature, 1e-5)
+        if self.top_k is not None:
+            kth = torch.topk(z, min(self.top_k, z.shape[-1])).values[..., -1:]
+            z = torch.where(z < kth, torch.full_like(z, float("-inf")), z)
+        p = torch.softmax(z, dim=-1)
+        return (p / torch.empty_like(p).exponential_(1.0)).argmax(-1, keepdim=True)
+
     @torch.no_grad()
     def _decode_once(self, kv_len=None):
         if self.step is not None:
-            self.next_tok.copy_(self.step(self.tok, self.pos, kv_len).argmax(-1, keepdim=True))
+            self.next_tok.copy_(self._pick(self.step(self.tok, self.pos, kv_len)))
             return
         out = self.model(self.tok, past_key_values=self.cache, cache_position=self.pos, use_cache=True)
-        self.next_tok.copy_(out.logits[:, -1].argmax(-1, keepdim=True))
+        self.next_tok.copy_(self._pick(out.logits[:, -1]))
 
     @torch.no_grad()
     def generate(self, input_ids: Tensor, max_new_tokens: int, use_graph: bool = True) -> Tensor:
-        """greedy continuation of a single sequence [1, T]; returns [1, T + max_new_tokens]"""
+        """continuation of a single sequence [1, T] — greedy, or sampled when the decoder was built with do_sample=True; returns [1, T + max_new_tokens]"""
         assert input_ids.shape[0] == 1, "one sequence (the decode-shaped bs=1 path)"
         T = input_ids.shape[1]
         assert T + max_new_tokens <= self.max_cache_len
         ids = input_ids.to(self.device)
         self.cache = self._StaticCache(config=self.model.config, max_cache_len=self.max_cache_len)
         out = self.model(ids, past_key_values=self.cache, cache_position=torch.arange(T, device=self.device), use_cache=True)   # prefill
-        self.tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        self.tok = self._pick(out.logits[:, -1])
         self.next_tok = torch.empty_like(self.tok)
         self.pos = torch.tensor([T], device=self.device)
         self.step = None

@@ -197,3 +197,39 @@ def test_column_shard_emulated_on_one_gpu(ops, nbits, world):
         torch.testing.assert_close(y.float(), x.float() @ Wd.float().t() + bias.float(), rtol=1e-3, atol=2e-3)
     else:
         assert torch.equal(y, full)   # same weights, same k order per output row -> bit-identical
+
+
+@pytest.mark.parametrize("M", [1, 3, 32])
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_3bit_layer_runs_in_the_stream_layout(ops, world, M):
+    """ShardedHQQForward keeps a re-packed 3-bit shard in the 3-bit STREAM layout (csrc/w3s.h): the sharded layer then takes the same one-launch decode
+    kernels as a patched unsharded one (missing #2).  One process stands in for every rank of a gloo group of size 1 per call is not
+    possible, so the shard objects are built through the class's own constructor path with a stub process group of the right size."""
+    from hqq_amd import shard
+    N, K, gs = 1280, 1024, 64
+    g = torch.Generator().manual_seed(world + M)
+    W = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    Wq, s, z = ops.quantize(W, nbits=3, group_size=gs, round_zero=False)
+    s, z = s.half(), z.half()
+    x = torch.randn(M, K, generator=g).half().cuda()
+    Wd = ops.dequantize(Wq, s.reshape(-1), z.reshape(-1), N, K, gs, 3)
+    want = (x.double() @ Wd.double().t()).float()
+
+    class _Dist:   # the two calls ShardedHQQForward.__init__ makes
+        def __init__(self, r): self.r = r
+        def get_world_size(self, group=None): return world
+        def get_rank(self, group=None): return self.r
+    parts = []
+    for r in range(world):
+        sh = shard.ShardedHQQForward.__new__(shard.ShardedHQQForward)
+        import torch.distributed as real
+        orig = (real.get_world_size, real.get_rank)
+        real.get_world_size, real.get_rank = _Dist(r).get_world_size, _Dist(r).get_rank
+        try:
+            sh.__init__(Wq, s, z, None, N, K, gs, 3)
+        finally:
+            real.get_world_size, real.get_rank = orig
+        assert sh.opts & ops.OPT_W3S and sh.Wq.shape == (N // world // 2, K // 16 * 3)
+        parts.append(sh._local(x).reshape(M, -1))
+    y = shard.unpermute(torch.stack(parts), N, 3, world)
+    torch.testing.assert_close(y.float().cpu(), want.cpu(), rtol=1e-3, atol=1e-3)

@@ -450,3 +450,26 @@ def test_decode_attention_with_the_keys_shared_out_over_workgroups(n_heads, n_kv
     ops.attn_decode(qr, kc1, vc1, p, a, scaling, splits=splits)
     ops.rope_attn_decode(qraw, kraw, vraw, cos, sin, p, kc2, vc2, b, scaling, splits=splits)
     assert torch.equal(a, b) and torch.equal(kc1[:, :pos + 1], kc2[:, :pos + 1]) and torch.equal(vc1[:, :pos + 1], vc2[:, :pos + 1])
+
+
+def test_sampling_inside_the_captured_step():
+    """do_sample (the reference's HFGenerator(do_sample=True, temperature, top_k), hqq/utils/generation_hf.py:250-311) as an epilogue on the logits inside the
+    captured decode step: with top_k = 1 the draw has one candidate and must reproduce the greedy tokens; with top_k = 5 every sampled token is one of the
+    five most likely under the model's own (teacher-forced) logits, and two runs from the same generator state agree"""
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    model = _toy_llama_hip(nbits=4)
+    ids = torch.randint(0, model.config.vocab_size, (1, 10), generator=torch.Generator().manual_seed(11)).cuda()
+    greedy = GraphedGreedyDecoder(model, max_cache_len=64).generate(ids, 24)
+    one = GraphedGreedyDecoder(model, max_cache_len=64, do_sample=True, temperature=0.7, top_k=1).generate(ids, 24)
+    assert torch.equal(greedy, one)
+    torch.manual_seed(123)
+    a = GraphedGreedyDecoder(model, max_cache_len=64, do_sample=True, temperature=0.6, top_k=5).generate(ids, 24)
+    torch.manual_seed(123)
+    b = GraphedGreedyDecoder(model, max_cache_len=64, do_sample=True, temperature=0.6, top_k=5).generate(ids, 24)
+    assert torch.equal(a, b) and a.shape == (1, 34)
+    with torch.no_grad():
+        logits = model(a[:, :-1]).logits[0].float()
+    top5 = logits.topk(5, dim=-1).indices
+    T = ids.shape[1]
+    inside = [(int(a[0, t + 1]) in top5[t].tolist()) for t in range(T - 1, a.shape[1] - 1)]
+    assert sum(inside) >= len(inside) - 1, inside     # (the step's logits and the batched forward's differ in the last bits: a near-tie at rank 5 / 6 may swap)

@@ -35,7 +35,7 @@ for N, K in ((4096, 4096), (12288, 4096), (11008, 4096), (4096, 11008)):
         comp = t(lambda: ops.forward(x, P, s, z, None, N, K, gs, nbits, fused=False))
         row = []
         for name, bits in TILES.items():
-            for ks in (1, 2, 4, 8):
+            for ks in (1, 2, 4, 8, 16):
                 try:
                     row.append(f"{name}/KS{ks} {t(lambda: ops.gemm(x, P, s, z, None, N, K, gs, nbits, out=y, opts=ops.OPT_META_SCALABLE | bits | (ks << 24))):.0f}")
                 except Exception as e:
