@@ -171,8 +171,15 @@ template <int NBITS> struct GdMeta {   // (zero, scale) DMA: one dword = the two
   static constexpr int SLOT = NI * 256;                        // bytes per wave and pair of steps
 };
 
+// 2-bit, 4-wave tile: four slabs x eight token tiles of accumulators (128 registers) + the rebuilt fragments do not fit 256 registers — round 4's build
+// spilled 14-80 dwords into scratch INSIDE the loop.  With one wave per SIMD (a 512-register budget) the accumulators live in AGPRs and nothing spills:
+// 20-30 % faster on every 7B shape at 128..2048 rows (tools/r5_pipe2bit.py: 4096 x 4096 at 128 / 1024 rows 37.3 -> 29.9 / 78.8 -> 63.3 us, 11008 x 4096
+// 43.7 -> 35.3 / 202 -> 141), and ahead of the 8-wave tile (which cannot have that budget) everywhere: 2-bit layers always take the 4-wave tile (gp_plan).
+#ifndef GD_2BIT_ONE_WAVE_PER_SIMD
+#define GD_2BIT_ONE_WAVE_PER_SIMD 1
+#endif
 template <int NBITS, bool SUB, int NW, int BM, bool BF>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
+__global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WAVE_PER_SIMD)) ? 2 : 1) void gemm_pipe_f16_kernel(const GdArgs a) {   // ("2": a 256-register budget keeps the accumulators in VGPRs; with 512 hipcc parks them in AGPRs and copies)
   constexpr bool W3 = NBITS == 3;
   constexpr int PER = gd_per(NBITS);
   constexpr int LB = W3 ? 12 : 16;   // bytes per lane and step (16 k of PER rows)
@@ -617,6 +624,18 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
   const bool both = (opts & HQQ_OPT_GEMM_WIDE) && (opts & HQQ_OPT_GEMM_NARROW);   // both bits: the 256-token tile (8 waves)
   static const int KSS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
   static const int SHAPES[3][2] = {{4, 128}, {8, 128}, {8, 256}};
+  if (nbits == 2) {   // the 4-wave tile only (see GD_2BIT_ONE_WAVE_PER_SIMD): the split is still chosen by the model (or forced)
+    GpPlan b2 = gp_make(2, M, N, K, 4, 128, forced_ks ? forced_ks : 1);
+    double c2 = gp_cost(b2, M, N, nk);
+    for (int ks : KSS) {
+      if (forced_ks) break;
+      GpPlan p = gp_make(2, M, N, K, 4, 128, ks);
+      if (p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
+      const double c = gp_cost(p, M, N, nk);
+      if (c < c2) { b2 = p; c2 = c; }
+    }
+    return b2;
+  }
   GpPlan best = gp_make(nbits, M, N, K, both ? 8 : (forced_nw ? forced_nw : 4), both && nbits != 2 ? 256 : 128, forced_ks ? forced_ks : 1);
   double best_cost = gp_cost(best, M, N, nk);
   for (const auto& sh : SHAPES) {
@@ -719,7 +738,7 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTER_BYTES);
   }
   const bool sub = (opts & HQQ_OPT_META_SCALABLE) != 0 && dtype == HQQ_F16;
-#define GP_GO3(NB, SB, BF_) (p.BM == 256 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 256, BF_>(a, blocks, st) /* (never planned at 2 bits: 256 accumulator registers) */ : p.NW == 8 ? gp_launch<NB, SB, 8, 128, BF_>(a, blocks, st) : gp_launch<NB, SB, 4, 128, BF_>(a, blocks, st))
+#define GP_GO3(NB, SB, BF_) (p.BM == 256 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 256, BF_>(a, blocks, st) /* (never planned at 2 bits: 256 accumulator registers) */ : p.NW == 8 ? gp_launch<(NB == 2 ? 4 : NB), SB, 8, 128, BF_>(a, blocks, st) /* (never planned at 2 bits either: gp_plan) */ : gp_launch<NB, SB, 4, 128, BF_>(a, blocks, st))
 #define GP_GO(NB) (dtype == HQQ_BF16 ? GP_GO3(NB, false, true) : sub ? GP_GO3(NB, true, false) : GP_GO3(NB, false, false))
   if (nbits == 8) return GP_GO(8);
   if (nbits == 4) return GP_GO(4);
