@@ -44,6 +44,11 @@
 #include "gemv_shared.h"
 #include "w3s.h"
 
+#ifdef GV_LAB_PREFETCH   // lab: what the NEXT launch will stream first (set by the caller before every launch; tools/r5_prefetch_lab.py)
+static const uint8_t* g_lab_pf_base = nullptr;
+static int g_lab_pf_rows = 0, g_lab_pf_row_bytes = 0;
+extern "C" void hqq_lab_set_prefetch(const void* base, int rows, int row_bytes) { g_lab_pf_base = static_cast<const uint8_t*>(base); g_lab_pf_rows = rows; g_lab_pf_row_bytes = row_bytes; }
+#endif
 namespace hqq {
 
 // one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
@@ -455,7 +460,11 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
 #ifdef GV_LAB_TS
   in.ts = a.ts;
 #endif
+#ifdef GV_LAB_PREFETCH
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, g_lab_pf_base, g_lab_pf_rows, g_lab_pf_row_bytes);
+#else
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out);
+#endif
   return check_launch("hqq_hip_gemv");
 }
 
