@@ -477,13 +477,13 @@ def main():
     # (csrc/exchange.hip) when it validates against the collective at start-up — opt-in until it has run over xGMI on a real node (advisor,
     # round 3: nothing here has been measured on more than one GPU).  rows1 / gather force one collective form.
     xenv = os.environ.get("HQQ_BENCH_EXCHANGE", "auto")
-    if world > 1 and M == 1 and strong and xenv == "peer":
+    if world > 1 and M <= 64 and strong and xenv == "peer":   # (round 5: a decode batch of up to 64 rows goes through the same kernel: strided slab writes, no un-permute)
         # Build the peer arenas (collective), then VALIDATE three rounds of every exchange point against the collective on fresh random
         # slices; every rank must agree, else the mode is dropped.  Waits are bounded: a peer that never delivers is reported, not hung on.
         from hqq_amd import shard as _shard
         ok, why, px = 1.0, "", None
         try:   # (collective, and consistent: either every rank gets its object or every rank raises — hqq_amd/shard.py)
-            px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in EXCHANGE_GROUPS], nbits, cd, dev)
+            px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in EXCHANGE_GROUPS], nbits, cd, dev, rows=M)
         except Exception as e:   # noqa: BLE001
             ok, why = 0.0, f"{type(e).__name__}: {e}"
         if px is not None:

@@ -38,7 +38,7 @@ SYMBOLS = {
     "hqq_hip_gemv": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemv_block": (_i32, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _u32, _u32, _vp, _vp]),
-    "hqq_hip_exchange": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u32, _vp]),
+    "hqq_hip_exchange": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u32, _vp]),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemm_dense": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_forward_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),

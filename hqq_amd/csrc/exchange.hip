@@ -32,12 +32,12 @@ constexpr int XG_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int XG_MAXP = HQQ_EXCHANGE_MAX_RANKS;
 
 struct XgArgs {
-  const uint16_t* y_loc[XG_MAXL];          // this rank's [1, n_loc[j]] outputs, local (slab-major) order
-  uint16_t* full[XG_MAXP][XG_MAXL];        // rank p's [1, n_loc[j] * world] row of layer j (p == rank: local memory)
+  const uint16_t* y_loc[XG_MAXL];          // this rank's [M, n_loc[j]] outputs, local (slab-major) order inside a row
+  uint16_t* full[XG_MAXP][XG_MAXL];        // rank p's [M, n_loc[j] * world] rows of layer j (p == rank: local memory)
   uint32_t* flags[XG_MAXP];                // rank p's flag block of this point: [world] words
   uint32_t* status;
   int n_loc[XG_MAXL];
-  int n_layers, per, world, rank;
+  int n_layers, per, world, rank, M;     // M activation rows (1..HQQ_EXCHANGE_MAX_ROWS): y_loc[j] is [M, n_loc[j]], a full row set [M, n_loc[j] * world]
   uint32_t spin_limit;
 };
 
@@ -53,13 +53,24 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XgArgs a) {
   for (int j = 0; j < a.n_layers; ++j) {
     const int n1 = a.n_loc[j] / a.per;                    // columns of one slab run
     const int64_t slab_full = static_cast<int64_t>(n1) * a.world;
+    const int64_t row_full = static_cast<int64_t>(a.n_loc[j]) * a.world;   // a full row of the layer
     for (int s = 0; s < a.per; ++s) {
-      const uint16_t* src = a.y_loc[j] + static_cast<int64_t>(s) * n1;
-      uint16_t* dst = a.full[p][j] + s * slab_full + static_cast<int64_t>(a.rank) * n1;
-      if ((n1 & 7) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
-        for (int i = tid; i < n1 / 8; i += 256) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+      // row m of the slab run: n1 columns of y_loc[m] -> columns s N / per + rank n1 of the peer's row m (strided slab writes for M > 1: the rows of a
+      // batch land in the reference's column order too, nothing is permuted afterwards)
+      const uint16_t* src0 = a.y_loc[j] + static_cast<int64_t>(s) * n1;
+      uint16_t* dst0 = a.full[p][j] + s * slab_full + static_cast<int64_t>(a.rank) * n1;
+      const bool vec = (n1 & 7) == 0 && (a.n_loc[j] & 7) == 0 && ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(dst0)) & 15) == 0;
+      if (vec) {
+        const int nv = n1 / 8;
+        for (int q = tid; q < a.M * nv; q += 256) {
+          const int m = q / nv, i = q - m * nv;
+          reinterpret_cast<u32x4*>(dst0 + m * row_full)[i] = reinterpret_cast<const u32x4*>(src0 + static_cast<int64_t>(m) * a.n_loc[j])[i];
+        }
       } else {
-        for (int i = tid; i < n1; i += 256) dst[i] = src[i];
+        for (int q = tid; q < a.M * n1; q += 256) {
+          const int m = q / n1, i = q - m * n1;
+          dst0[m * row_full + i] = src0[static_cast<int64_t>(m) * a.n_loc[j] + i];
+        }
       }
     }
   }
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) void exchange_kernel(const XgArgs a) {
 
 }  // namespace hqq
 
-extern "C" int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int nbits, int dtype, int world, int rank,
+extern "C" int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int64_t M, int nbits, int dtype, int world, int rank,
                                 void* const* full, void* const* flags, void* status, uint32_t spin_limit, void* stream) {
   using namespace hqq;
   clear_stale_error();
@@ -88,6 +99,7 @@ extern "C" int hqq_hip_exchange(int n_layers, const void* const* y_loc, const in
     set_error("hqq_hip_exchange: 1..%d layers and 1..%d ranks per exchange point (got %d layers, rank %d of %d)", XG_MAXL, XG_MAXP, n_layers, rank, world);
     return HQQ_ERR_SHAPE;
   }
+  if (M < 1 || M > HQQ_EXCHANGE_MAX_ROWS) { set_error("hqq_hip_exchange: 1..%d activation rows per exchange (got %lld)", HQQ_EXCHANGE_MAX_ROWS, static_cast<long long>(M)); return HQQ_ERR_SHAPE; }
   if (dtype != HQQ_F16 && dtype != HQQ_BF16) { set_error("hqq_hip_exchange: 2-byte activations only (fp16 / bf16)"); return HQQ_ERR_DTYPE; }
   if (nbits != 8 && nbits != 4 && nbits != 3 && nbits != 2 && nbits != 1) { set_error("hqq_hip_exchange: nbits %d", nbits); return HQQ_ERR_NBITS; }
   if (!y_loc || !N_loc || !full || !flags || !status) { set_error("hqq_hip_exchange: null argument"); return HQQ_ERR_SHAPE; }
@@ -111,7 +123,7 @@ extern "C" int hqq_hip_exchange(int n_layers, const void* const* y_loc, const in
     }
   }
   a.status = static_cast<uint32_t*>(status);
-  a.n_layers = n_layers; a.world = world; a.rank = rank; a.spin_limit = spin_limit;
+  a.n_layers = n_layers; a.world = world; a.rank = rank; a.spin_limit = spin_limit; a.M = static_cast<int>(M);
   hipLaunchKernelGGL(exchange_kernel, dim3(static_cast<unsigned>(world)), dim3(256), 0, as_stream(stream), a);
   return check_launch("hqq_hip_exchange");
 }

@@ -413,6 +413,7 @@ def rotary_pair_layout(layer, K: int, group_size: int, nbits: int, head_dim: int
 
 
 EXCHANGE_MAX_RANKS = 16
+EXCHANGE_MAX_ROWS = 64
 
 
 def exchange(y_loc, N_loc, nbits: int, world: int, rank: int, full_ptrs, flag_ptrs, status_ptr: int, spin_limit: int = 0) -> None:
@@ -425,16 +426,19 @@ def exchange(y_loc, N_loc, nbits: int, world: int, rank: int, full_ptrs, flag_pt
         raise ValueError(f"hqq_amd: an exchange point holds 1..{GEMV_MAX_GROUP} layers, got {n}")
     if not 1 <= world <= EXCHANGE_MAX_RANKS or len(full_ptrs) != world or len(flag_ptrs) != world:
         raise ValueError(f"hqq_amd: 1..{EXCHANGE_MAX_RANKS} ranks, one row set and one flag block per rank")
+    M = y_loc[0].numel() // int(N_loc[0])
+    if not 1 <= M <= EXCHANGE_MAX_ROWS:
+        raise ValueError(f"hqq_amd: exchange takes 1..{EXCHANGE_MAX_ROWS} activation rows")
     for t, nl in zip(y_loc, N_loc):
         _dev(t)
-        if t.numel() != nl or not t.is_contiguous() or t.element_size() != 2:
-            raise ValueError("hqq_amd: exchange takes one dense 2-byte activation row per layer: y_loc[j] is [1, N_loc[j]]")
+        if t.numel() != M * nl or not t.is_contiguous() or t.element_size() != 2:
+            raise ValueError("hqq_amd: exchange takes dense 2-byte activations, the same number of rows for every layer: y_loc[j] is [M, N_loc[j]]")
     dt = _dt(y_loc[0].dtype)
     VPn = ctypes.c_void_p * n
     VPf = ctypes.c_void_p * (world * n)
     VPw = ctypes.c_void_p * world
     with torch.cuda.device(y_loc[0].device):
-        rc = _C.lib().hqq_hip_exchange(n, VPn(*[_p(t) for t in y_loc]), (ctypes.c_int64 * n)(*[int(v) for v in N_loc]), int(nbits), dt, int(world), int(rank),
+        rc = _C.lib().hqq_hip_exchange(n, VPn(*[_p(t) for t in y_loc]), (ctypes.c_int64 * n)(*[int(v) for v in N_loc]), int(M), int(nbits), dt, int(world), int(rank),
                                        VPf(*[int(full_ptrs[p][j]) for p in range(world) for j in range(n)]), VPw(*[int(v) for v in flag_ptrs]),
                                        ctypes.c_void_p(int(status_ptr)), int(spin_limit), _stream())
     _C.check(rc, "hqq_hip_exchange")

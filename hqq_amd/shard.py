@@ -141,10 +141,10 @@ class ShardedHQQForward:
             return self._forward_chunked(x.reshape(-1, self.K), self.OVERLAP_ROWS).reshape(*x.shape[:-1], self.N)
         y_loc = self._local(x).reshape(-1, self.n_loc).contiguous()
         M = y_loc.shape[0]
-        if M == 1 and self.peer is not None:
+        if self.peer is not None and M <= self.peer[0].rows:   # one row, or a decode batch the arena holds: peer-memory stores, nothing to un-permute
             px, e = self.peer
             px.run(e, [y_loc])
-            return px.full(e, 0).reshape(*x.shape[:-1], self.N)
+            return px.full(e, 0, rows=M).reshape(*x.shape[:-1], self.N)
         if M == 1:   # decode: straight into the reference's column order, no un-permute
             full = torch.empty((1, self.N), dtype=y_loc.dtype, device=y_loc.device)
             return gather_columns(y_loc, full, self.N, self.nbits, self.group).reshape(*x.shape[:-1], self.N)
@@ -283,9 +283,12 @@ class PeerExchange:
         can still store into this rank's arena (after a barrier); the object — and every tensor full() / rows handed out — is unusable afterwards."""
         self._closer()
 
-    def __init__(self, points, nbits: int, dtype, device, group=None, spin_limit: int = 0, _arenas=None, _rank=None, _world=None):
+    def __init__(self, points, nbits: int, dtype, device, group=None, spin_limit: int = 0, _arenas=None, _rank=None, _world=None, rows: int = 1):
         import torch.distributed as dist
         self.nbits, self.dtype, self.device = int(nbits), dtype, torch.device(device)
+        self.rows = int(rows)   # activation rows the arena holds per layer (a decode batch of up to ops.EXCHANGE_MAX_ROWS rows; round 5)
+        if not 1 <= self.rows <= ops.EXCHANGE_MAX_ROWS:
+            raise ValueError(f"hqq_amd: PeerExchange serves 1..{ops.EXCHANGE_MAX_ROWS} activation rows")
         if _arenas is None:
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         else:
@@ -312,10 +315,10 @@ class PeerExchange:
             for n in pt:
                 off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
                 offs.append(off)
-                off += 2 * n
+                off += 2 * n * self.rows
             self._row_off.append(offs)
         self.arena_bytes = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-        assert self.arena_bytes == self._layout_bytes(self.points, self.world)
+        assert self.arena_bytes == self._layout_bytes(self.points, self.world, self.rows)
         self.spin_limit = int(spin_limit)
         self._last = None
         self._group = group
@@ -374,32 +377,32 @@ class PeerExchange:
         self._base = [a.data_ptr() for a in self._arenas]
         mine = self._arenas[self.rank]
         elems = {torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}[dtype]
-        self._rows = [[mine[o:o + 2 * n].view(elems).view(1, n) for o, n in zip(offs, pt)] for offs, pt in zip(self._row_off, self.points)]
+        self._rows = [[mine[o:o + 2 * n * self.rows].view(elems).view(self.rows, n) for o, n in zip(offs, pt)] for offs, pt in zip(self._row_off, self.points)]
         # per point: every rank's row addresses and flag-block address (what hqq_hip_exchange takes), computed once
         self._full_ptrs = [[[b + o for o in offs] for b in self._base] for offs in self._row_off]
         self._flag_ptrs = [[b + f for b in self._base] for f in self._flag_off]
         self._n_loc = [[n // self.world for n in pt] for pt in self.points]
 
     @classmethod
-    def local_group(cls, points, nbits: int, dtype, device, world: int, spin_limit: int = 0):
+    def local_group(cls, points, nbits: int, dtype, device, world: int, spin_limit: int = 0, rows: int = 1):
         """`world` ranks inside ONE process (tests): same kernel and layout, the arenas are ordinary tensors.  One process cannot count on
         its ranks' kernels being resident together (streams share hardware queues, and a kernel would wait for one queued behind it):
         pass spin_limit=1 — the waits give up at once, the stores still happen — and clear flags and status between rounds, as
         tests/test_exchange_gpu.py does.  Real waits need one process per rank."""
-        arenas = [torch.zeros(cls._layout_bytes(points, world), dtype=torch.uint8, device=device) for _ in range(world)]
-        return [cls(points, nbits, dtype, device, spin_limit=spin_limit, _arenas=arenas, _rank=r, _world=world) for r in range(world)]
+        arenas = [torch.zeros(cls._layout_bytes(points, world, rows), dtype=torch.uint8, device=device) for _ in range(world)]
+        return [cls(points, nbits, dtype, device, spin_limit=spin_limit, _arenas=arenas, _rank=r, _world=world, rows=rows) for r in range(world)]
 
     @classmethod
-    def _layout_bytes(cls, points, world: int) -> int:
+    def _layout_bytes(cls, points, world: int, rows: int = 1) -> int:
         off = 128 * len(points) + 128
         for pt in points:
             for n in pt:
-                off = (off + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN + 2 * int(n)
+                off = (off + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN + 2 * int(n) * int(rows)
         return (off + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
 
-    def full(self, e: int, j: int = 0) -> Tensor:
-        """this rank's full [1, N] row of layer j of point e (reference column order; complete after run(e, ...) in stream order)"""
-        return self._rows[e][j]
+    def full(self, e: int, j: int = 0, rows: int | None = None) -> Tensor:
+        """this rank's full rows of layer j of point e — [rows, N] (default: all the arena holds), reference column order; complete after run(e, ...) in stream order"""
+        return self._rows[e][j] if rows is None else self._rows[e][j][:rows]
 
     def status(self) -> int:
         """0, or 1 + the rank whose flag a wait gave up on (then the rows of that exchange are undefined)"""
@@ -432,6 +435,8 @@ class PeerExchange:
         pt = self.points[e]
         if len(y_loc) != len(pt):
             raise ValueError(f"hqq_amd: exchange point {e} holds {len(pt)} layers, got {len(y_loc)}")
+        if y_loc[0].numel() // self._n_loc[e][0] > self.rows:
+            raise ValueError(f"hqq_amd: this PeerExchange holds {self.rows} activation rows per layer")
         ops.exchange(list(y_loc), self._n_loc[e], self.nbits, self.world, self.rank, self._full_ptrs[e], self._flag_ptrs[e],
                      self._base[self.rank] + self._status_off, self.spin_limit)
         self._last = e   # (only an exchange that was enqueued counts)

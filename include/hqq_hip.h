@@ -168,7 +168,9 @@ int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* con
  * has four.  Every rank must issue the same sequence of points.  dtype F16 / BF16; nbits picks `per` (3-bit shards: per = 1).
  * ------------------------------------------------------------------------------------------- */
 #define HQQ_EXCHANGE_MAX_RANKS 16
-int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int nbits, int dtype, int world, int rank,
+#define HQQ_EXCHANGE_MAX_ROWS 64   /* ABI 6: M activation rows per exchange (a decode batch): y_loc[j] is [M, N_loc[j]], the full row sets [M, N_loc[j] * world]; row m of a
+                                      rank's slab run lands at the same columns of the peers' row m (strided slab writes), so a batch needs no un-permute either */
+int hqq_hip_exchange(int n_layers, const void* const* y_loc, const int64_t* N_loc, int64_t M, int nbits, int dtype, int world, int rank,
                      void* const* full, void* const* flags, void* status, uint32_t spin_limit, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * The steps either side of the GEMVs in a decode step (ABI 5; csrc/block.hip).  The reference's headline is the

@@ -58,10 +58,11 @@ def test_argument_errors_do_not_need_a_gpu():
     # the peer-memory exchange validates its arguments before it launches anything
     VP1, VP2 = (ctypes.c_void_p * 1)(16), (ctypes.c_void_p * 2)(16, 16)
     st = ctypes.c_void_p(16)
-    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 1, 17, 0, VP2, VP2, st, 0, None) == -2     # more ranks than HQQ_EXCHANGE_MAX_RANKS
-    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(511), 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2      # 511 columns do not split into two slab runs
-    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 0, 2, 0, VP2, VP2, st, 0, None) == -3      # fp32 activations
-    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 4, 1, 2, 2, VP2, VP2, st, 0, None) == -2      # rank 2 of 2
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 1, 4, 1, 17, 0, VP2, VP2, st, 0, None) == -2     # more ranks than HQQ_EXCHANGE_MAX_RANKS
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(511), 1, 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2      # 511 columns do not split into two slab runs
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 1, 4, 0, 2, 0, VP2, VP2, st, 0, None) == -3      # fp32 activations
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 1, 4, 1, 2, 2, VP2, VP2, st, 0, None) == -2      # rank 2 of 2
+    assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 65, 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2     # more rows than HQQ_EXCHANGE_MAX_ROWS
 
 
 def test_the_library_owns_no_device_memory_and_reads_no_environment():

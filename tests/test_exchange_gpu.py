@@ -56,6 +56,35 @@ def test_every_rank_ends_up_with_the_reference_ordered_rows(ops, nbits, world, p
                     assert torch.equal(group[r].full(e, j), f), f"round {rnd}, point {e}, layer {j}, rank {r}"
 
 
+@pytest.mark.parametrize("nbits,world,points", [
+    (4, 8, [[8192, 1024, 1024], [8192]]),
+    (2, 4, [[4096], [11008, 11008]]),
+    (3, 8, [[4096, 4096], [4096]]),
+    (8, 3, [[3 * 40], [3 * 8, 3 * 24]]),          # runs that are not multiples of 16 bytes: the 2-byte copy loop, strided rows
+])
+@pytest.mark.parametrize("M", [2, 32, 64])
+def test_a_decode_batch_lands_in_the_reference_order_without_an_unpermute(ops, nbits, world, points, M):
+    """round 5 (ABI 6): M <= HQQ_EXCHANGE_MAX_ROWS activation rows per exchange — row m of a rank's slab run is stored at the same columns of every peer's
+    row m (strided slab writes), so every rank ends with the full [M, N] outputs in the reference's column order; an arena built for 64 rows serves any
+    smaller batch; a batch larger than the arena is refused"""
+    from hqq_amd.shard import PeerExchange
+    group = PeerExchange.local_group(points, nbits, torch.float16, "cuda", world, spin_limit=1, rows=64)
+    g = torch.Generator().manual_seed(M)
+    for e, pt in enumerate(points):
+        fulls = [torch.randn(M, N, generator=g).half().cuda() for N in pt]
+        parts = [_slices(f, N, nbits, world) for f, N in zip(fulls, pt)]        # [layer][rank]: [M, N / world] each, local order
+        for r in range(world):
+            group[r].run(e, [parts[j][r] for j in range(len(pt))])
+        torch.cuda.synchronize()
+        for r in range(world):
+            group[r]._arenas[r][:group[r]._status_off + 128].zero_()
+            for j, f in enumerate(fulls):
+                assert torch.equal(group[r].full(e, j, rows=M), f), f"point {e}, layer {j}, rank {r}"
+    small = PeerExchange.local_group(points, nbits, torch.float16, "cuda", world, spin_limit=1, rows=1)
+    with pytest.raises(ValueError):
+        small[0].run(0, [torch.zeros(2, N // world, dtype=torch.float16, device="cuda") for N in points[0]])
+
+
 def test_the_reuse_rule_and_the_argument_checks(ops):
     from hqq_amd.shard import PeerExchange
     with pytest.raises(ValueError):
