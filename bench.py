@@ -763,6 +763,32 @@ def main():
                     leg(nm, lambda f=fused: stack128(f), nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * len(BLOCK), kern)
                     legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
                     legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+                # the same rows with q|k|v and gate|up held as ONE layer each (HQQLinear.merge / ops.merge_layers: the layers' own levels and constants,
+                # stacked and packed again): 4 launches per block instead of 7
+                if nbits == 4 and not (blocks[0]["q"].opts & ops.OPT_W3S):
+                    mblocks = []
+                    for blk in blocks:
+                        mb = {}
+                        for key, names in (("qkv", ("q", "k", "v")), ("gu", ("gate", "up"))):
+                            Wm, sm, zm, Nm = ops.merge_layers([(blk[n].Wq, blk[n].scale, blk[n].zero, blk[n].N) for n in names], blk[names[0]].K, 64, nbits)
+                            ok = cd == torch.float16 and a.gemv_mode == "exact" and ops.meta_scalable(sm, zm, Nm, blk[names[0]].K, 64, nbits)
+                            mb[key] = (Wm, sm, zm, Nm, blk[names[0]].K, (ops.OPT_META_SCALABLE if ok else 0) | (base_opts if a.gemv_mode != "exact" else 0) | extra_opts)
+                        for n in ("o", "down"):
+                            mb[n] = (blk[n].Wq, blk[n].scale, blk[n].zero, blk[n].N, blk[n].K, group_opts([blk[n]]))
+                        mblocks.append(mb)
+                    ym = {Nm: torch.empty(128, Nm, device=dev, dtype=cd) for Nm in sorted({v[3] for v in mblocks[0].values()})}
+
+                    def stack128_merged():
+                        for mb in mblocks:
+                            for key in ("qkv", "o", "gu", "down"):
+                                Wm, sm, zm, Nm, Km, om = mb[key]
+                                ops.forward(xs128[Km], Wm, sm, zm, None, Nm, Km, 64, nbits, out=ym[Nm], fused=True, opts=om)
+                    leg("7b-stack bs=128, fused dequant-GEMM, q|k|v and gate|up merged into one layer each (HQQLinear.merge: 4 launches per block)", stack128_merged,
+                        nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * 4, "hqq::gemm_pipe_f16_kernel")
+                    legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
+                    legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+                    del mblocks, ym
+                    torch.cuda.empty_cache()
             except Exception as e:
                 legs.append({"name": "7b-stack bs=128", "error": repr(e)})
         # int3 / int2 (BASELINE.json configs[3]): the same stack quantised at the other bit widths by the HIP solver, one token, stream-ordered launches

@@ -275,6 +275,48 @@ class HQQLinear(nn.Module):
         shell.bias = None if bias is None else nn.Parameter(bias, requires_grad=False)
         return cls(shell, quant_config=quant_config, compute_dtype=compute_dtype, device=device, del_orig=del_orig)
 
+    @classmethod
+    def merge(cls, layers):
+        """ONE HQQLinear holding the rows of `layers` in order — modules that read the same input (q_proj | k_proj | v_proj, gate_proj | up_proj):
+        merged(x) == torch.cat([l(x) for l in layers], -1), from the layers' own levels, scale and zero (hqq_amd.ops.merge_layers: stacked and packed
+        again, nothing re-quantised).  One launch over sum(out_features) rows instead of one per layer — what pays at 65..2560 activation rows
+        (batched decode, speculative verification, short prompts).  The originals are untouched.  The reference has no such
+        helper (its vLLM integration meets merged modules already merged: hqq/utils/vllm.py); the result is an ordinary HQQLinear: state_dict(),
+        dequantize() and every backend work on it."""
+        layers = list(layers)
+        if not layers or any((not l.ready) or l.meta is None for l in layers):
+            raise ValueError("hqq_amd: HQQLinear.merge takes quantised layers")
+        first = layers[0]
+        m0 = first.meta
+        K = int(m0["shape"][1])
+        for l in layers:
+            m = l.meta
+            if (m["axis"] != 1 or not m["packing"] or m["packing"] != m0["packing"] or m["group_size"] != m0["group_size"] or not m["group_size"]
+                    or int(m["shape"][1]) != K or l.compute_dtype != first.compute_dtype or m.get("quant_scale") or m.get("quant_zero")
+                    or (l.bias is None) != (first.bias is None)):
+                raise ValueError("hqq_amd: HQQLinear.merge needs layers quantised along axis 1 with one packing, group size, input width and compute "
+                                 "dtype, and either all or none with a bias")
+        nb = Quantizer._packing_bits[m0["packing"]]
+        parts = []
+        for l in layers:
+            W = l.W_q.data.view(l.meta["unpack_view_dtype"]) if l.meta["view_as_float"] else l.W_q.data
+            parts.append((W, l.meta["scale"], l.meta["zero"], int(l.meta["shape"][0])))
+        W, s, z, N = ops.merge_layers(parts, K, int(m0["group_size"]), nb)
+        out = cls(None, quant_config=dict(copy.deepcopy(first.quant_config), offload_meta=first.offload_meta), compute_dtype=first.compute_dtype,
+                  device=first.device, initialize=False)
+        meta = {k: v for k, v in m0.items() if not isinstance(v, torch.Tensor)}
+        meta.update({"shape": torch.Size([N, K]), "scale": s.reshape(-1, *m0["scale"].shape[1:]), "zero": z.reshape(-1, *m0["zero"].shape[1:])})
+        if m0["view_as_float"]:
+            W = W.view(first.W_q.dtype)
+        out.W_q, out.meta = W, meta
+        out.bias = None if first.bias is None else torch.cat([l.bias.reshape(-1) for l in layers])
+        out.in_features, out.out_features = K, N
+        out.axis, out.channel_wise = first.axis, first.channel_wise
+        out.encoded_state_dict = first.encoded_state_dict
+        out.cuda(first.device)
+        out.ready = True
+        return out
+
     def extra_repr(self) -> str:
         if getattr(self, "meta", None) is None:
             return ""

@@ -392,6 +392,32 @@ def pair_layers(gate, up, K: int, group_size: int, nbits: int, w3s: bool = False
     return W, torch.cat([sg.reshape(-1), su.reshape(-1)]).contiguous(), torch.cat([zg.reshape(-1), zu.reshape(-1)]).contiguous(), 2 * N
 
 
+def merge_layers(layers, K: int, group_size: int, nbits: int, w3s: bool = False):
+    """ONE layer whose rows are the rows of `layers` in order (q_proj | k_proj | v_proj, gate_proj | up_proj: layers that read the same input): the
+    level matrices stacked and packed again, scale / zero concatenated — the same levels and constants bit for bit, so y of the merged layer is the
+    concatenation of the layers' outputs.  What it buys: one launch over sum(N) rows instead of one per layer (at 65..2560 activation rows, where
+    hqq_hip_gemv_grouped does not reach: a 12288 x 4096 launch at 128 rows takes 29-31 us against 3 x 19-20).
+    layers: (W_q, scale, zero, N) as the layers hold them (3-bit: the stream layout when w3s).  Returns (W_q, scale, zero, sum N); the originals are
+    untouched.  (The reference has no such helper; vLLM's merged q|k|v / gate|up modules are the same idea: hqq/utils/vllm.py.)"""
+    if not layers:
+        raise ValueError("hqq_amd: merge_layers needs at least one layer")
+    dt = layers[0][1].dtype
+    U = []
+    for W, s, z, N in layers:
+        if s.dtype != dt or z.dtype != dt:
+            raise ValueError("hqq_amd: merge_layers needs one compute dtype")
+        if (N * K) % group_size or s.numel() != N * K // group_size or z.numel() != s.numel():
+            raise ValueError("hqq_amd: merge_layers takes channel-wise layers quantised along axis 1 (one scale / zero per group of a row)")
+        if w3s:
+            W = w3s_unpack(W, N, K)
+        U.append(unpack(nbits, W)[:N * K // group_size])   # level matrix [N K / gs, gs], row (n, g)
+    Nt = sum(int(l[3]) for l in layers)
+    Wm = pack(nbits, torch.cat(U, dim=0))
+    if w3s:
+        Wm = w3s_pack(Wm, Nt, K)
+    return (Wm, torch.cat([l[1].reshape(-1) for l in layers]).contiguous(), torch.cat([l[2].reshape(-1) for l in layers]).contiguous(), Nt)
+
+
 def rotary_pair_layout(layer, K: int, group_size: int, nbits: int, head_dim: int, w3s: bool = False):
     """The ROTARY-PAIRED row order of a q_proj / k_proj layer: element i < head_dim / 2 of head h becomes row h head_dim / 2 + i, its rotary partner
     i + head_dim / 2 row N / 2 + h head_dim / 2 + i — so that BitPack's row slabs hold both in ONE packed row and hqq_hip_gemv_block's epilogue can apply

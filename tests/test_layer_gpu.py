@@ -233,3 +233,40 @@ def test_sharded_3bit_layer_runs_in_the_stream_layout(ops, world, M):
         parts.append(sh._local(x).reshape(M, -1))
     y = shard.unpermute(torch.stack(parts), N, 3, world)
     torch.testing.assert_close(y.float().cpu(), want.cpu(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("nbits,cd,bias", [(4, torch.float16, False), (4, torch.bfloat16, True), (3, torch.float16, False), (2, torch.float16, True), (8, torch.float16, False)])
+def test_merged_layers_are_the_concatenation(ops, nbits, cd, bias):
+    """HQQLinear.merge (q|k|v, gate|up as one layer): the same weights bit for bit, outputs = the layers' outputs side by side; state_dict round trip."""
+    torch.manual_seed(7 + nbits)
+    K, Ns = 512, (256, 128, 640)
+    cfg = BaseQuantizeConfig(nbits=nbits, group_size=64, axis=1)
+    layers = []
+    for N in Ns:
+        lin = torch.nn.Linear(K, N, bias=bias)
+        layers.append(HQQLinear(lin, cfg, compute_dtype=cd, device="cuda"))
+    merged = HQQLinear.merge(layers)
+    assert (merged.in_features, merged.out_features) == (K, sum(Ns)) and tuple(merged.meta["shape"]) == (sum(Ns), K)
+    assert merged.W_q.dtype == layers[0].W_q.dtype and merged.meta["scale"].shape[1:] == layers[0].meta["scale"].shape[1:]
+    assert torch.equal(merged.dequantize(), torch.cat([l.dequantize() for l in layers], 0))                  # the same weights
+    for l in layers:                                                                                         # the originals are untouched
+        assert tuple(l.meta["shape"]) in [(N, K) for N in Ns]
+    x1 = torch.randn(1, K, device="cuda").to(cd)
+    assert torch.equal(merged(x1), torch.cat([l(x1) for l in layers], -1))                                   # one token: a row's K order does not depend on N
+    for M in (5, 128, 300):
+        x = torch.randn(M, K, device="cuda").to(cd)
+        want = torch.cat([l(x) for l in layers], -1).float()
+        got = merged(x).float()
+        torch.testing.assert_close(got, want, rtol=2e-2 if cd == torch.bfloat16 else 4e-3, atol=(2e-2 if cd == torch.bfloat16 else 4e-3) * float(want.abs().max()))
+    for backend in (HQQBackend.PYTORCH, HQQBackend.PYTORCH_FORWARD):
+        HQQLinear.set_backend(backend)
+        try:
+            y = merged(x1)
+        finally:
+            HQQLinear.set_backend(HQQBackend.HIP)
+        torch.testing.assert_close(y.float(), merged(x1).float(), rtol=1e-2, atol=2e-2)
+    fresh = HQQLinear(None, None, compute_dtype=cd, device="cuda", initialize=False)
+    fresh.load_state_dict(merged.state_dict())
+    assert torch.equal(fresh.W_q.data.view(torch.uint8), merged.W_q.data.view(torch.uint8)) and torch.equal(fresh.dequantize(), merged.dequantize())
+    with pytest.raises(ValueError):
+        HQQLinear.merge([layers[0], HQQLinear(torch.nn.Linear(256, 128, bias=bias), cfg, compute_dtype=cd, device="cuda")])   # another input width

@@ -23,7 +23,7 @@ def t(f, reps=10):
         best = us if best is None or us < best else best
     return best
 TILES = {"4x128": ops.OPT_GEMM_NARROW, "8x128": ops.OPT_GEMM_WIDE, "8x256": ops.OPT_GEMM_NARROW | ops.OPT_GEMM_WIDE}
-for N, K in ((4096, 4096), (12288, 4096), (11008, 4096), (4096, 11008)):
+for N, K in ((4096, 4096), (12288, 4096), (11008, 4096), (22016, 4096), (4096, 11008)):
     R = N * K // gs
     P = ops.pack(nbits, torch.randint(0, 16, (R, gs), generator=g, dtype=torch.uint8).cuda())
     s = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).half().cuda()
@@ -35,7 +35,7 @@ for N, K in ((4096, 4096), (12288, 4096), (11008, 4096), (4096, 11008)):
         comp = t(lambda: ops.forward(x, P, s, z, None, N, K, gs, nbits, fused=False))
         row = []
         for name, bits in TILES.items():
-            for ks in (1, 2, 4, 8, 16):
+            for ks in (1, 2, 3, 4, 6, 8, 16):
                 try:
                     row.append(f"{name}/KS{ks} {t(lambda: ops.gemm(x, P, s, z, None, N, K, gs, nbits, out=y, opts=ops.OPT_META_SCALABLE | bits | (ks << 24))):.0f}")
                 except Exception as e:
