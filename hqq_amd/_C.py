@@ -31,6 +31,8 @@ SYMBOLS = {
     "hqq_hip_add_rmsnorm": (_i32, [_vp, _vp, _vp, _f32, _vp, _i64, _i64, _i32, _vp]),
     "hqq_hip_rope_cache": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_silu_mul": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "hqq_hip_token_prologue": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "hqq_hip_argmax_advance": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "hqq_hip_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _i64, _vp, _sz, _vp]),
     "hqq_hip_rope_attn_decode": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, ctypes.c_float, _i32, _i64, _vp, _sz, _vp]),
     "hqq_hip_attn_decode_workspace_bytes": (_sz, [_i64, _i64, _i64]),
@@ -55,7 +57,7 @@ SYMBOLS = {
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -361,6 +361,61 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   out[static_cast<int64_t>(h) * HD + d] = E::r(num / den);
 }
 
+// ---- the per-token work either side of the decoder blocks (hqq/utils/generation_hf.py:405-540: the embedding lookup, the rotary table row and the causal mask of one
+//      query in front; argmax, token hand-over and position increment behind), one launch each instead of nine small torch kernels.  Pure copies and compares:
+//      bit-identical to the torch ops they replace.
+//      token_prologue: h = embed[tok]; cos = cos_tab[pos]; sin = sin_tab[pos]; mask[i] = i <= pos ? 0 : -inf (mask == null: the caller's attention needs none).
+//      A token / position outside the tables reads the last row (the torch ops would trap; the host checks positions, utils/generation.py) ----
+__global__ __launch_bounds__(256) void token_prologue_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ pos, const uint16_t* __restrict__ embed, int64_t vocab, int H,
+                                                             const uint16_t* __restrict__ cos_tab, const uint16_t* __restrict__ sin_tab, int64_t L, int hd,
+                                                             uint16_t* __restrict__ h, uint16_t* __restrict__ cos_o, uint16_t* __restrict__ sin_o, uint16_t* __restrict__ mask,
+                                                             uint16_t zero_bits, uint16_t ninf_bits) {
+  int64_t t = tok[0], p = pos[0];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const int64_t pr = p < 0 ? 0 : (p >= L ? L - 1 : p);
+  const int nb = static_cast<int>(gridDim.x), b = static_cast<int>(blockIdx.x), tid = static_cast<int>(threadIdx.x);
+  const u32x4* src = reinterpret_cast<const u32x4*>(embed + t * H);
+  for (int i = b * 256 + tid; i < H / 8; i += nb * 256) reinterpret_cast<u32x4*>(h)[i] = src[i];
+  if (b == 0 && cos_tab) {
+    for (int i = tid; i < hd; i += 256) { cos_o[i] = cos_tab[pr * hd + i]; sin_o[i] = sin_tab[pr * hd + i]; }
+  }
+  if (mask) {
+    for (int64_t i = b * 256 + tid; i < L; i += static_cast<int64_t>(nb) * 256) mask[i] = i <= p ? zero_bits : ninf_bits;
+  }
+}
+
+// argmax_advance: next = the FIRST index of the largest logit (torch.argmax's tie rule; logits finite), written to next_tok and tok, pos += 1.  One workgroup:
+// 1024 threads keep (value, index) of their strided share in index order, then a fixed tree in LDS.
+template <bool BF>
+__global__ __launch_bounds__(1024) void argmax_advance_kernel(const uint16_t* __restrict__ logits, int n, int64_t* __restrict__ next_tok, int64_t* __restrict__ tok, int64_t* __restrict__ pos) {
+  using E = El<BF>;
+  __shared__ float bv[1024];
+  __shared__ int bi[1024];
+  const int tid = static_cast<int>(threadIdx.x);
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = tid; i < n; i += 1024) {
+    const float v = E::f(logits[i]);
+    if (v > best || idx == 0x7fffffff) { best = v; idx = i; }   // (strictly greater: the earlier index of a thread's share stays on a tie)
+  }
+  bv[tid] = best; bi[tid] = idx;
+  __syncthreads();
+  for (int s_ = 512; s_ > 0; s_ >>= 1) {
+    if (tid < s_) {
+      const float v = bv[tid + s_];
+      const int j = bi[tid + s_];
+      if (v > bv[tid] || (v == bv[tid] && j < bi[tid])) { bv[tid] = v; bi[tid] = j; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int64_t w = bi[0] == 0x7fffffff ? 0 : bi[0];
+    next_tok[0] = w;
+    if (tok) tok[0] = w;
+    if (pos) pos[0] += 1;
+  }
+}
+
 }  // namespace hqq
 
 using namespace hqq;
@@ -495,6 +550,32 @@ int hqq_hip_rope_attn_decode(const void* q, const void* k, const void* v, const 
                              size_t workspace_bytes, void* stream) {
   return attn_decode_run("hqq_hip_rope_attn_decode", true, q, k, v, cos, sin, pos_dev, k_cache, v_cache, out, n_heads, n_kv_heads, head_dim, cache_len, scaling, dtype,
                          splits, workspace, workspace_bytes, stream);
+}
+
+int hqq_hip_token_prologue(const int64_t* tok_dev, const int64_t* pos_dev, const void* embed, int64_t vocab, int64_t H, const void* cos_tab, const void* sin_tab, int64_t L,
+                           int64_t head_dim, void* h, void* cos, void* sin, void* mask, int dtype, void* stream) {
+  clear_stale_error();
+  if (!block_dtype_ok(dtype, "hqq_hip_token_prologue")) return HQQ_ERR_UNSUPPORTED;
+  if (!tok_dev || !pos_dev || !embed || !h || vocab < 1 || H < 8 || H % 8 || H > INT32_MAX || L < 1 || (cos_tab && (!sin_tab || !cos || !sin || head_dim < 1 || head_dim > INT32_MAX))) {
+    set_error("hqq_hip_token_prologue: bad arguments (H a multiple of 8; cos / sin tables and outputs come together)");
+    return HQQ_ERR_SHAPE;
+  }
+  if (!aligned16(embed) || !aligned16(h)) { set_error("hqq_hip_token_prologue: embed / h must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  const uint16_t ninf = dtype == HQQ_BF16 ? 0xFF80u : 0xFC00u;
+  const int64_t work = (mask ? L : 0) > H / 8 ? (mask ? L : 0) : H / 8;
+  const unsigned blocks = static_cast<unsigned>(work / 256 < 1 ? 1 : (work / 256 > 64 ? 64 : work / 256));
+  hipLaunchKernelGGL(token_prologue_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), tok_dev, pos_dev, static_cast<cu16>(embed), vocab, static_cast<int>(H), static_cast<cu16>(cos_tab),
+                     static_cast<cu16>(sin_tab), L, static_cast<int>(head_dim), static_cast<u16>(h), static_cast<u16>(cos), static_cast<u16>(sin), static_cast<u16>(mask), static_cast<uint16_t>(0), ninf);
+  return check_launch("hqq_hip_token_prologue");
+}
+
+int hqq_hip_argmax_advance(const void* logits, int64_t n, int dtype, int64_t* next_tok_dev, int64_t* tok_dev, int64_t* pos_dev, void* stream) {
+  clear_stale_error();
+  if (!block_dtype_ok(dtype, "hqq_hip_argmax_advance")) return HQQ_ERR_UNSUPPORTED;
+  if (!logits || !next_tok_dev || n < 1 || n > INT32_MAX - 1) { set_error("hqq_hip_argmax_advance: bad arguments"); return HQQ_ERR_SHAPE; }
+  if (dtype == HQQ_BF16) hipLaunchKernelGGL(argmax_advance_kernel<true>, dim3(1), dim3(1024), 0, as_stream(stream), static_cast<cu16>(logits), static_cast<int>(n), next_tok_dev, tok_dev, pos_dev);
+  else hipLaunchKernelGGL(argmax_advance_kernel<false>, dim3(1), dim3(1024), 0, as_stream(stream), static_cast<cu16>(logits), static_cast<int>(n), next_tok_dev, tok_dev, pos_dev);
+  return check_launch("hqq_hip_argmax_advance");
 }
 
 }  // extern "C"

@@ -742,6 +742,42 @@ def rope_attn_decode(q: Tensor, k: Tensor, v: Tensor, cos: Tensor, sin: Tensor, 
     return out
 
 
+def token_prologue(tok: Tensor, pos: Tensor, embed: Tensor, h: Tensor, cos_tab=None, sin_tab=None, cos=None, sin=None, mask=None) -> None:
+    """The front of a decode step in one launch (csrc/block.hip, hqq_hip_token_prologue): h[H] = embed[tok]; cos / sin = row pos of the rotary tables
+    [L, head_dim] (skipped when the tables are None); mask[L] = 0 up to pos, -inf beyond (skipped when None).  tok [1, 1] / pos [1] int64 on the device:
+    graph-replay safe.  Copies and compares only: the same bits as embed_tokens(tok), index_select and torch.where produce."""
+    _dev(tok, pos, embed, h)
+    if tok.dtype != torch.int64 or pos.dtype != torch.int64 or embed.dim() != 2 or not embed.is_contiguous() or h.numel() != embed.shape[1] or h.dtype != embed.dtype:
+        raise ValueError("hqq_amd: token_prologue takes int64 tok / pos, a dense [vocab, H] embedding and h [H] of its dtype")
+    L, hd = 1, 0
+    if cos_tab is not None:
+        _dev(cos_tab, sin_tab, cos, sin)
+        if cos_tab.shape != sin_tab.shape or cos_tab.dim() != 2 or not (cos_tab.is_contiguous() and sin_tab.is_contiguous()) or cos.numel() != cos_tab.shape[1] or \
+                sin.numel() != cos_tab.shape[1] or any(t.dtype != embed.dtype for t in (cos_tab, sin_tab, cos, sin)):
+            raise ValueError("hqq_amd: token_prologue takes dense [L, head_dim] rotary tables and [head_dim] outputs of the compute dtype")
+        L, hd = int(cos_tab.shape[0]), int(cos_tab.shape[1])
+    if mask is not None:
+        _dev(mask)
+        if mask.dtype != embed.dtype or not mask.is_contiguous() or (cos_tab is not None and mask.numel() != L):
+            raise ValueError("hqq_amd: token_prologue's mask is a dense [L] tensor of the compute dtype, L the rotary tables' rows")
+        L = int(mask.numel())
+    with torch.cuda.device(h.device):
+        rc = _C.lib().hqq_hip_token_prologue(_p(tok), _p(pos), _p(embed), int(embed.shape[0]), int(embed.shape[1]), _p(cos_tab), _p(sin_tab), L, hd, _p(h), _p(cos), _p(sin),
+                                             _p(mask), _dt(embed.dtype), _stream())
+    _C.check(rc, "hqq_hip_token_prologue")
+
+
+def argmax_advance(logits: Tensor, next_tok: Tensor, tok: Tensor | None = None, pos: Tensor | None = None) -> None:
+    """The back of a greedy decode step in one launch (hqq_hip_argmax_advance): next_tok[0] = logits.argmax() (the first index of the largest value, as torch.argmax),
+    tok[0] = the same, pos[0] += 1 (each skipped when None).  int64 tensors on the device: graph-replay safe."""
+    _dev(logits, next_tok)
+    if not logits.is_contiguous() or next_tok.dtype != torch.int64 or (tok is not None and tok.dtype != torch.int64) or (pos is not None and pos.dtype != torch.int64):
+        raise ValueError("hqq_amd: argmax_advance takes dense logits and int64 token / position tensors")
+    with torch.cuda.device(logits.device):
+        rc = _C.lib().hqq_hip_argmax_advance(_p(logits), logits.numel(), _dt(logits.dtype), _p(next_tok), _p(tok), _p(pos), _stream())
+    _C.check(rc, "hqq_hip_argmax_advance")
+
+
 def silu_mul(gate: Tensor, up: Tensor, out: Tensor | None = None) -> Tensor:
     """LlamaMLP's act_fn(gate) * up in one kernel (fp16)"""
     _dev(gate, up)

@@ -9,6 +9,8 @@ from __future__ import annotations
 import torch
 from torch import Tensor
 
+from .. import ops
+
 
 class GraphedGreedyDecoder:
     """fused=True (default): a Llama-shaped model whose decoder linears are HQQLinearHIP layers decodes through hqq_amd.utils.llama_fused —
@@ -70,11 +72,18 @@ class GraphedGreedyDecoder:
 
     @torch.no_grad()
     def _decode_once(self, kv_len=None):
+        """one whole transition: logits at self.pos -> next_tok, tok = next_tok, pos += 1 (all on the device, so the captured graph carries the loop state forward by itself)"""
         if self.step is not None:
-            self.next_tok.copy_(self._pick(self.step(self.tok, self.pos, kv_len)))
-            return
-        out = self.model(self.tok, past_key_values=self.cache, cache_position=self.pos, use_cache=True)
-        self.next_tok.copy_(self._pick(out.logits[:, -1]))
+            logits = self.step(self.tok, self.pos, kv_len)
+            if not self.do_sample and self.glue != "kernels" and logits.dtype in (torch.float16, torch.bfloat16) and logits.is_contiguous():
+                ops.argmax_advance(logits, self.next_tok, self.tok, self.pos)   # argmax + hand-over + position increment: one launch (csrc/block.hip)
+                return
+            self.next_tok.copy_(self._pick(logits))
+        else:
+            out = self.model(self.tok, past_key_values=self.cache, cache_position=self.pos, use_cache=True)
+            self.next_tok.copy_(self._pick(out.logits[:, -1]))
+        self.tok.copy_(self.next_tok)
+        self.pos += 1
 
     @torch.no_grad()
     def generate(self, input_ids: Tensor, max_new_tokens: int, use_graph: bool = True) -> Tensor:
@@ -126,8 +135,6 @@ class GraphedGreedyDecoder:
             self.graph = g
         else:
             self._decode_once(kv)
-        self.tok.copy_(self.next_tok)
-        self.pos += 1
 
     @torch.no_grad()
     def benchmark(self, input_ids: Tensor, new_tokens: int = 64, warmup: int = 8) -> dict:

@@ -186,6 +186,12 @@ class FusedLlamaStep:
             self.cos_tab, self.sin_tab = c[0].contiguous(), s_[0].contiguous()   # [max_cache_len, hd]
         self.zero = torch.zeros((), dtype=dt, device=dev)
         self.ninf = torch.full((), float("-inf"), dtype=dt, device=dev)
+        # the front of a step as one launch (ops.token_prologue) where it is a plain table lookup: an ordinary nn.Embedding in the compute dtype and precomputed rotary tables
+        emb = inner.embed_tokens
+        self.one_launch_front = bool(glue != "kernels" and self.cos_tab is not None and type(emb) is torch.nn.Embedding and emb.max_norm is None and emb.weight.dtype == dt
+                                     and emb.weight.is_contiguous() and emb.weight.device == self.h.device and self.H % 8 == 0 and dt in (torch.float16, torch.bfloat16))
+        self.cos_v = torch.empty(self.hd, dtype=dt, device=dev)
+        self.sin_v = torch.empty(self.hd, dtype=dt, device=dev)
 
     @staticmethod
     def _gopts(Ls) -> int:
@@ -201,14 +207,18 @@ class FusedLlamaStep:
         h = self.h
         # (the position itself is device memory — the step is graph-replayed —: the kernels that index the cache with it skip their
         #  writes beyond the cache's last slot, csrc/block.hip; callers that know the position on the host check it there, generation.py)
-        h.copy_(inner.embed_tokens(tok).view(1, self.H))
-        if self.cos_tab is not None:
-            cos, sin = self.cos_tab.index_select(0, pos).view(-1), self.sin_tab.index_select(0, pos).view(-1)
+        if self.one_launch_front:   # embedding row, rotary table row and the causal mask in ONE launch (csrc/block.hip: copies and compares, the same bits as the ops below)
+            ops.token_prologue(tok, pos, inner.embed_tokens.weight, h, self.cos_tab, self.sin_tab, self.cos_v, self.sin_v, None if self.attention == "hip" else self.mask.view(-1))
+            cos, sin = self.cos_v, self.sin_v
         else:
-            cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))   # [1, 1, hd] each, the model's own rotary module
-            cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
-        if self.attention != "hip":
-            torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
+            h.copy_(inner.embed_tokens(tok).view(1, self.H))
+            if self.cos_tab is not None:
+                cos, sin = self.cos_tab.index_select(0, pos).view(-1), self.sin_tab.index_select(0, pos).view(-1)
+            else:
+                cos, sin = inner.rotary_emb(h.view(1, 1, self.H), pos.view(1, 1))   # [1, 1, hd] each, the model's own rotary module
+                cos, sin = cos.reshape(-1).contiguous(), sin.reshape(-1).contiguous()
+            if self.attention != "hip":
+                torch.where(self.ar <= pos, self.zero, self.ninf, out=self.mask.view(-1))   # the causal mask of one query at `pos` over the static cache
         kvl = self.L if kv_len is None else min(int(kv_len), self.L)
         mask = self.mask[..., :kvl]
         splits = ops.attn_splits(kvl) if self.attention == "hip" else 1   # (kernel attention: kv_len only picks how many workgroups share a head)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 6
+#define HQQ_HIP_ABI_VERSION 7
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -186,6 +186,14 @@ int hqq_hip_add_rmsnorm(void* h, const void* delta, const void* weight, float ep
 int hqq_hip_rope_cache(const void* q, const void* k, const void* v, const void* cos, const void* sin, const int64_t* pos_dev, void* q_out, void* k_cache,
                        void* v_cache, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim, int64_t cache_len, int dtype, void* stream);
 int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int dtype, void* stream);
+/* The per-token work either side of the decoder blocks (ABI 7; hqq/utils/generation_hf.py:405-540: embedding lookup, the rotary table's row, the causal mask of one query in
+ * front; argmax, token hand-over, position increment behind) as ONE launch each — copies and compares only, bit-identical to the torch ops they replace:
+ *   hqq_hip_token_prologue  h[H] = embed[*tok_dev]; cos / sin [head_dim] = cos_tab / sin_tab [L, head_dim] row *pos_dev (tables NULL: skipped);
+ *                           mask[L] = i <= *pos_dev ? 0 : -inf (mask NULL: skipped).  A token / position outside the tables reads the last row.
+ *   hqq_hip_argmax_advance  *next_tok_dev = the FIRST index of the largest of logits[n] (torch.argmax; logits finite); *tok_dev = the same (NULL: skipped); *pos_dev += 1 (NULL: skipped) */
+int hqq_hip_token_prologue(const int64_t* tok_dev, const int64_t* pos_dev, const void* embed, int64_t vocab, int64_t H, const void* cos_tab, const void* sin_tab, int64_t L,
+                           int64_t head_dim, void* h, void* cos, void* sin, void* mask, int dtype, void* stream);
+int hqq_hip_argmax_advance(const void* logits, int64_t n, int dtype, int64_t* next_tok_dev, int64_t* tok_dev, int64_t* pos_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The decoder block's launches with those steps FOLDED IN (ABI 6; csrc/gemv_block.hip): hqq_hip_gemv_grouped for ONE activation row whose

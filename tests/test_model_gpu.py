@@ -473,3 +473,51 @@ def test_sampling_inside_the_captured_step():
     T = ids.shape[1]
     inside = [(int(a[0, t + 1]) in top5[t].tolist()) for t in range(T - 1, a.shape[1] - 1)]
     assert sum(inside) >= len(inside) - 1, inside     # (the step's logits and the batched forward's differ in the last bits: a near-tie at rank 5 / 6 may swap)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_token_prologue_and_argmax_advance_equal_the_torch_ops(dt):
+    """the one-launch front and back of a decode step (csrc/block.hip) against the torch ops they replace: bit for bit, graph-replay safe"""
+    from hqq_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    vocab, H, L, hd = 1000, 264, 96, 48
+    emb = torch.randn(vocab, H, device="cuda", generator=g).to(dt)
+    ct, st = torch.randn(L, hd, device="cuda", generator=g).to(dt), torch.randn(L, hd, device="cuda", generator=g).to(dt)
+    ar = torch.arange(L, device="cuda")
+    for t, p in ((0, 0), (999, 95), (417, 31), (5, 64)):
+        tok, pos = torch.tensor([[t]], device="cuda"), torch.tensor([p], device="cuda")
+        h, cos, sin, mask = (torch.full((n,), 7.0, device="cuda", dtype=dt) for n in (H, hd, hd, L))
+        ops.token_prologue(tok, pos, emb, h, ct, st, cos, sin, mask)
+        assert torch.equal(h, emb[t]) and torch.equal(cos, ct[p]) and torch.equal(sin, st[p])
+        want = torch.where(ar <= pos, torch.zeros((), dtype=dt, device="cuda"), torch.full((), float("-inf"), dtype=dt, device="cuda"))
+        assert torch.equal(mask, want)
+        h2 = torch.empty(H, device="cuda", dtype=dt)
+        ops.token_prologue(tok, pos, emb, h2)                      # no tables, no mask (the kernel attention's form with a per-token rotary call)
+        assert torch.equal(h2, emb[t])
+    for n in (1, 7, 1024, 32000, 50257):
+        for trial in range(4):
+            logits = torch.randn(1, n, device="cuda", generator=g).to(dt)
+            if trial == 1 and n > 7:                               # ties: the first of the largest wins, wherever the copies sit
+                top = logits.max()
+                logits[0, [n - 1, n // 2, 5]] = top
+            if trial == 2:
+                logits.fill_(float("-inf"))
+            if trial == 3:
+                logits[0, n - 1] = 1e4
+            nxt, tok, pos = torch.full((1, 1), -1, device="cuda"), torch.full((1, 1), -1, device="cuda"), torch.tensor([41], device="cuda")
+            ops.argmax_advance(logits, nxt, tok, pos)
+            want = logits.argmax(-1, keepdim=True)
+            assert torch.equal(nxt, want) and torch.equal(tok, want) and int(pos) == 42, (n, trial, int(nxt), int(want))
+            ops.argmax_advance(logits, nxt)                         # next token only
+            assert torch.equal(nxt, want)
+    # captured: the state the kernels advance lives on the device
+    logits = torch.randn(1, 333, device="cuda", generator=g).to(dt)
+    nxt, tok, pos = torch.zeros(1, 1, dtype=torch.int64, device="cuda"), torch.zeros(1, 1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.argmax_advance(logits, nxt, tok, pos)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ops.argmax_advance(logits, nxt, tok, pos)
+    for _ in range(5):
+        gr.replay()
+    assert int(pos) == 6 and int(tok) == int(logits.argmax())
