@@ -278,7 +278,7 @@ class HQQLinear(nn.Module):
     @classmethod
     def merge(cls, layers):
         """ONE HQQLinear holding the rows of `layers` in order — modules that read the same input (q_proj | k_proj | v_proj, gate_proj | up_proj):
-        merged(x) == torch.cat([l(x) for l in layers], -1), from the layers' own levels, scale and zero (hqq_amd.ops.merge_layers: stacked and packed
+        merged(x) = torch.cat([l(x) for l in layers], -1) (the same weights bit for bit; outputs within the forward tolerance — how a launch cuts K may depend on its row count), from the layers' own levels, scale and zero (hqq_amd.ops.merge_layers: stacked and packed
         again, nothing re-quantised).  One launch over sum(out_features) rows instead of one per layer — what pays at 65..2560 activation rows
         (batched decode, speculative verification, short prompts).  The originals are untouched.  The reference has no such
         helper (its vLLM integration meets merged modules already merged: hqq/utils/vllm.py); the result is an ordinary HQQLinear: state_dict(),

@@ -56,6 +56,17 @@ def main():
             y = layer(x)
             bad += not close(y, ref, dt, what + " HQQLinear", mag)
             assert y.shape == ref.shape and y.dtype == ref.dtype
+            if rnd.random() < 0.4:
+                # HQQLinear.merge: the layer and one or two more on the same input held as ONE layer — the same weights bit for bit, outputs side by side (within the forward tolerance: a launch's K split may depend on its row count)
+                more = [HQQLinear(nn.Linear(K, 8 * rnd.randint(1, 60), bias=bias), cfg, compute_dtype=dt, device="cuda") for _ in range(rnd.randint(1, 2))]
+                if nbits != 3 or all((m_.out_features * (K // gs) + 9) // 10 >= K // gs for m_ in more):
+                    merged = HQQLinear.merge([layer] + more)
+                    if not torch.equal(merged.dequantize(), torch.cat([l_.dequantize() for l_ in [layer] + more], 0)):
+                        bad += 1
+                        print(f"FAIL {what} merged weights differ")
+                    refm = torch.cat([ref] + [l_.forward_pytorch(x) for l_ in more], -1)
+                    magm = torch.cat([mag] + [(x.reshape(-1, K).float().abs() @ l_.dequantize().float().abs().t()).reshape(*shape, -1) for l_ in more], -1)
+                    bad += not close(merged(x), refm, dt, what + " merged", magm)
             fast = patch_hqq_to_hip(layer, None)
             y2 = fast(x)
             bad += not close(y2, ref, dt, what + f" {type(fast).__name__}", mag)
