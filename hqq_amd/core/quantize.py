@@ -340,6 +340,7 @@ class HQQLinear(nn.Module):
         self.device = device
         self.in_gpu = True
         self._hip_opts = self._meta_opts()
+        self._w3s = None   # (the 3-bit stream-layout copy of _matmul_hip: rebuilt on the next forward)
         return self
 
     def _meta_opts(self) -> int:
@@ -485,11 +486,34 @@ class HQQLinear(nn.Module):
             return _MatmulNoCache.apply(x, self._matmul_hip, self.bias)
         return self._matmul_hip(x, transpose=True, bias=self.bias)
 
+    # 3-bit layers on the set_backend(HQQBackend.HIP) route: the decode / GEMM kernels read the 3-bit STREAM layout (csrc/w3s.h; 2.4x the rate of the
+    # reference container's two-launch path at one row).  W_q stays the reference's container — state_dict(), unpack(), dequantize() are untouched — and
+    # the layer keeps a re-laid-out COPY beside it (3 bits per weight more), built on the first forward and rebuilt when W_q / scale / zero change.
+    # HQQLinear.stream_layout_3bit = False keeps the single copy (and the slower path); prepare_for_inference(backend="hip") holds ONLY the stream layout.
+    stream_layout_3bit = True
+
+    def _w3s_copy(self, W_q: Tensor):
+        m = self.meta
+        N, K = m["shape"]
+        key = (W_q.data_ptr(), W_q._version, m["scale"].data_ptr(), m["scale"]._version, m["zero"].data_ptr(), m["zero"]._version)
+        c = getattr(self, "_w3s", None)
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():   # never built inside a capture (it allocates): the container's own path serves that step
+                return None
+            Ws = ops.w3s_pack(W_q.contiguous(), int(N), int(K))
+            o = ops.OPT_W3S | (ops.OPT_META_SCALABLE if (m["scale"].dtype == float16 and ops.w3s_meta_scalable(m["scale"].reshape(-1), m["zero"].reshape(-1), int(N), int(K))) else 0)
+            c = self._w3s = (key, Ws, o)
+        return c[1], c[2]   # (in-place edits through W_q.data / meta[...].data bypass the version counters: call .cuda(device) again — it drops the copy — after such an edit)
+
     def _matmul_hip(self, x: Tensor, transpose: bool = True, bias=None) -> Tensor:
         if transpose and self._fused_ok(x):
             m = self.meta
             N, K = m["shape"]
             W_q = self.W_q.view(m["unpack_view_dtype"]) if m["view_as_float"] else self.W_q
+            if m["packing"] == "3bit_32" and HQQLinear.stream_layout_3bit and ops.w3s_covers(int(N), int(K), m["group_size"]):
+                got = self._w3s_copy(W_q)
+                if got is not None:
+                    return ops.forward(x, got[0], m["scale"], m["zero"], bias, N, K, m["group_size"], 3, opts=ops.layer_opts(got[1]))
             return ops.forward(x, W_q, m["scale"], m["zero"], bias, N, K, m["group_size"], Quantizer._packing_bits[m["packing"]],
                                opts=ops.layer_opts(getattr(self, "_hip_opts", 0)))
         out = self.matmul(x, transpose=transpose)

@@ -269,3 +269,52 @@ def test_merged_layers_are_the_concatenation(ops, nbits, cd, bias):
     assert torch.equal(fresh.W_q.data.view(torch.uint8), merged.W_q.data.view(torch.uint8)) and torch.equal(fresh.dequantize(), merged.dequantize())
     with pytest.raises(ValueError):
         HQQLinear.merge([layers[0], HQQLinear(torch.nn.Linear(256, 128, bias=bias), cfg, compute_dtype=cd, device="cuda")])   # another input width
+
+
+def test_3bit_hqqlinear_hip_route_reads_the_stream_layout(ops):
+    """set_backend(HQQBackend.HIP) on a 3-bit layer: the forward goes through the stream-layout copy (the same launches a patched layer makes: same bits), W_q / state_dict stay
+    the reference's container, the copy follows the weights (load_state_dict, .cuda), and the class switch turns it off"""
+    from hqq_amd.backends.hip import HQQLinearHIP
+    torch.manual_seed(3)
+    K, N = 1024, 768
+    cfg = BaseQuantizeConfig(nbits=3, group_size=64, axis=1)
+    layer = HQQLinear(torch.nn.Linear(K, N, bias=True), cfg, compute_dtype=torch.float16, device="cuda")
+    sd = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in layer.state_dict().items()}
+    xs = [torch.randn(M, K, device="cuda").half() for M in (1, 3, 32, 200)]
+    ys = [layer(x) for x in xs]
+    assert layer._w3s is not None and layer.W_q.dtype == torch.int32 and tuple(layer.W_q.shape) == tuple(sd["W_q"].shape) and torch.equal(layer.W_q.data, sd["W_q"])
+    ref = layer.dequantize().float()
+    for x, y in zip(xs, ys):
+        torch.testing.assert_close(y.float(), x.float() @ ref.t() + layer.bias.float(), rtol=4e-3, atol=4e-3 * float(ref.abs().max()) * K ** 0.5)
+    HQQLinear.stream_layout_3bit = False
+    try:
+        slow = [layer(x) for x in xs]
+    finally:
+        HQQLinear.stream_layout_3bit = True
+    for y, y0 in zip(ys, slow):   # the same weights through the container's own kernels
+        torch.testing.assert_close(y.float(), y0.float(), rtol=4e-3, atol=4e-3 * float(ref.abs().max()) * K ** 0.5)
+    # another set of weights into the same module: the copy must follow
+    other = HQQLinear(torch.nn.Linear(K, N, bias=True), cfg, compute_dtype=torch.float16, device="cuda")
+    layer.load_state_dict(other.state_dict())
+    assert torch.equal(layer(xs[0]), other(xs[0])) and not torch.equal(layer(xs[0]), ys[0])
+    # the patched layer (which holds ONLY the stream layout) makes the same launches: bit for bit
+    want = [other(x) for x in xs]
+    fast = HQQLinearHIP(other)
+    for x, w in zip(xs, want):
+        assert torch.equal(fast(x), w)
+    # under capture with no copy built yet: the container's path serves, nothing is allocated for the copy
+    fresh = HQQLinear(torch.nn.Linear(K, N, bias=False), cfg, compute_dtype=torch.float16, device="cuda")
+    HQQLinear.stream_layout_3bit = False
+    try:
+        fresh(xs[0])   # (warms the workspace outside the capture)
+    finally:
+        HQQLinear.stream_layout_3bit = True
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        yc = fresh(xs[0])
+    g.replay()
+    torch.cuda.synchronize()
+    assert fresh._w3s is None
+    torch.testing.assert_close(yc.float(), fresh(xs[0]).float(), rtol=4e-3, atol=4e-3 * float(ref.abs().max()) * K ** 0.5)
+    assert fresh._w3s is not None
