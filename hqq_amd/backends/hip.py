@@ -93,6 +93,7 @@ class HQQLinearHIP(nn.Module):
         W_q = ops.w3s_unpack(self.W_q.data, self.out_features, self.in_features) if self.w3s else self.W_q
         return ops.dequantize(W_q, self.scale, self.zero, self.out_features, self.in_features, self.group_size, self.nbits, 1)
 
+    @torch.compiler.disable   # (a tracing compiler has nothing to see in a ctypes call into libhqq_hip.so: HF's static-cache generate() auto-compiles the model's forward)
     def forward(self, x: Tensor) -> Tensor:
         if x.dtype != self.compute_dtype:
             x = x.to(self.compute_dtype)
@@ -133,6 +134,7 @@ class _GroupedMember(nn.Module):
     def dequantize(self) -> Tensor:
         return self.layer.dequantize()
 
+    @torch.compiler.disable   # (a tracing compiler has nothing to see in a ctypes call into libhqq_hip.so: HF's static-cache generate() auto-compiles the model's forward)
     def forward(self, x: Tensor) -> Tensor:
         g = self._group
         # inference tensors (torch.inference_mode) carry no version counter: identity alone keys the parked outputs there

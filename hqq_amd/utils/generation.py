@@ -37,6 +37,8 @@ class GraphedGreedyDecoder:
         self._StaticCache = StaticCache
         self.graph = None      # the graph of the last step taken
         self.graphs = {}       # attended cache length -> captured step
+        self.cache = None      # HF StaticCache, kept between generate() calls (reset in place)
+        self._state = None     # (tok, next_tok, pos): the device tensors the captured graphs read and write
 
     def _kv_len(self, p: int) -> int:
         """how much of the static cache a step at position p attends over.  HF's attention function costs what it is given (the whole masked cache:
@@ -85,33 +87,66 @@ class GraphedGreedyDecoder:
         self.tok.copy_(self.next_tok)
         self.pos += 1
 
+    def reset(self) -> None:
+        """drop what generate() keeps between calls (the static cache, the fused step with its re-laid-out layer copies, the captured graphs): call it after the
+        model's weights changed"""
+        self.cache = None
+        self.step = None
+        self.graph = None
+        self.graphs = {}
+        self._state = None
+
     @torch.no_grad()
-    def generate(self, input_ids: Tensor, max_new_tokens: int, use_graph: bool = True) -> Tensor:
-        """continuation of a single sequence [1, T] — greedy, or sampled when the decoder was built with do_sample=True; returns [1, T + max_new_tokens]"""
+    def generate(self, input_ids: Tensor, max_new_tokens: int, use_graph: bool = True, eos_token_id: int | None = None, check_every: int = 16) -> Tensor:
+        """continuation of a single sequence [1, T] — greedy, or sampled when the decoder was built with do_sample=True; returns [1, T + n], n = max_new_tokens, or fewer
+        when eos_token_id is given and was produced (the sequence then ends with it; the host looks at the tokens every `check_every` steps, never per token).
+        The static cache, the fused step (its paired / rotary-paired layer copies) and the captured graphs are KEPT between calls: the next prompt resets the cache in
+        place (StaticCache.reset keeps the tensors) and replays the same graphs — hqq/utils/generation_hf.py:190-207, :313-327 keep theirs the same way; reset() drops them."""
         assert input_ids.shape[0] == 1, "one sequence (the decode-shaped bs=1 path)"
         T = input_ids.shape[1]
         assert T + max_new_tokens <= self.max_cache_len
         ids = input_ids.to(self.device)
-        self.cache = self._StaticCache(config=self.model.config, max_cache_len=self.max_cache_len)
+        kept = getattr(self, "cache", None) is not None and getattr(self, "_state", None) is not None
+        if kept:
+            self.cache.reset()
+        else:
+            self.cache = self._StaticCache(config=self.model.config, max_cache_len=self.max_cache_len)
         out = self.model(ids, past_key_values=self.cache, cache_position=torch.arange(T, device=self.device), use_cache=True)   # prefill
-        self.tok = self._pick(out.logits[:, -1])
-        self.next_tok = torch.empty_like(self.tok)
-        self.pos = torch.tensor([T], device=self.device)
-        self.step = None
-        if self.fused:
-            try:
-                self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention, glue=self.glue)
-            except ValueError:   # a cache layout / attention configuration the fused step does not restate: the model's own forward serves
-                self.step = None
+        first = self._pick(out.logits[:, -1])
+        if kept:
+            self.tok, self.next_tok, self.pos = self._state   # the tensors the captured graphs read and write
+            self.tok.copy_(first)
+            self.pos.fill_(T)
+        else:
+            self.tok = first
+            self.next_tok = torch.empty_like(self.tok)
+            self.pos = torch.tensor([T], device=self.device)
+            self._state = (self.tok, self.next_tok, self.pos)
+            self.step = None
+            if self.fused:
+                try:
+                    self.step = self._fused_mod.FusedLlamaStep(self.model, self.cache, self.max_cache_len, attention=self.attention, glue=self.glue)
+                except ValueError:   # a cache layout / attention configuration the fused step does not restate: the model's own forward serves
+                    self.step = None
+            self.graph = None
+            self.graphs = {}
         toks = [self.tok.clone()]
-        self.graph = None
-        self.graphs = {}
+        done = 0        # tokens the host has looked at
+        n = max_new_tokens
         for i in range(max_new_tokens - 1):
-            self._advance(T + i, use_graph and i >= 1)   # step 0 runs eagerly (lazy initialisation inside the model)
+            self._advance(T + i, use_graph and (kept or i >= 1))   # (a fresh decoder's step 0 runs eagerly: lazy initialisation inside the model)
             toks.append(self.tok.clone())
+            if eos_token_id is not None and (len(toks) - done >= check_every or i == max_new_tokens - 2):
+                seen = torch.cat(toks[done:], dim=1)[0].tolist()   # one host read per check_every tokens
+                if eos_token_id in seen:
+                    n = done + seen.index(eos_token_id) + 1
+                    break
+                done = len(toks)
+        if eos_token_id is not None and n == max_new_tokens and len(toks) == 1 and int(toks[0]) == eos_token_id:
+            n = 1
         if self.step is not None:
-            self.step.account_tokens(max_new_tokens - 1)
-        return torch.cat([ids] + toks, dim=1)
+            self.step.account_tokens(len(toks) - 1)
+        return torch.cat([ids] + toks[:n], dim=1)
 
     @torch.no_grad()
     def _advance(self, p: int, use_graph: bool) -> None:
@@ -165,3 +200,99 @@ class GraphedGreedyDecoder:
         ms = e0.elapsed_time(e1) / new_tokens
         return {"ms_per_token": ms, "tok_s": 1e3 / ms, "new_tokens": new_tokens, "prompt_tokens": T}
 
+
+
+# prompts of different lengths for HFGenerator.warmup(): what matters is that the first cache buckets get their graphs captured, not what is asked
+WARMUP_PROMPTS = ["Hello.", "Name three prime numbers and say why each one is prime.",
+                  "Explain in two paragraphs how a key-value cache speeds up autoregressive decoding, and what it costs in memory."]
+
+
+class HFGenerator:
+    """The reference's generation front end (hqq/utils/generation_hf.py:117-540: HFGenerator(model, tokenizer, ...).generate(prompt) -> {"output_text", "output_tokens",
+    "input_tokens"}) over GraphedGreedyDecoder: same constructor arguments, same methods a caller uses (warmup, generate, tokenize_prompt), same defaults
+    (cache_size = the next power of two above max_new_tokens, greedy unless do_sample, temperature 0.6 / top_k 5, stop at the tokenizer's EOS).
+    What `compile` means here: the reference compiles the decode step with torch.compile ("partial" / "full") and can wrap it in a CUDA graph; this loop has no tracing
+    compiler — "partial" / "full" both select the captured-hipGraph step (one graph per token, kept across prompts), None the same step launched eagerly.
+    `compile_options` / `patch_accelerate` are accepted and unused.  The decode step itself is hqq_amd.utils.llama_fused (HIP kernels) for Llama-shaped models whose
+    linears went through prepare_for_inference(backend="hip"), the model's own forward otherwise.
+    Differences a caller can see: EOS is looked for every 16 tokens on the host instead of after every token (no per-token synchronisation; the text returned is cut at
+    the EOS all the same); "output_tokens" holds every generated token before the EOS (the reference's slice drops the last one it generated, generation_hf.py:493);
+    a prompt that leaves less than max_new_tokens of cache generates what fits."""
+
+    def __init__(self, model, tokenizer, max_new_tokens: int = 1000, cache_size: int | None = None, do_sample: bool = False, temperature: float = 0.6, top_k: int = 5,
+                 compile: str | None = None, compile_options: dict | None = None, patch_accelerate: bool = True):
+        if compile not in (None, "partial", "full"):
+            raise ValueError("compile: None, 'partial' or 'full'")
+        self.model, self.tokenizer = model, tokenizer
+        self.device = next(p.device for p in model.parameters() if p.device.type == "cuda")
+        self.do_sample = bool(do_sample)
+        self.temperature = temperature if self.do_sample else None
+        self.top_k = top_k if self.do_sample else None
+        self.max_new_tokens = int(max_new_tokens)
+        self.cache_size = self.next_multiple(self.max_new_tokens) if cache_size is None else int(cache_size)
+        self.max_new_tokens = min(self.max_new_tokens, self.cache_size)
+        self.is_compiled = compile is not None
+        self.use_graph = compile is not None
+        self.compile_options = compile_options
+        self.decoder = GraphedGreedyDecoder(model, max_cache_len=self.cache_size, do_sample=self.do_sample, temperature=temperature, top_k=top_k)
+        self.init()
+
+    @staticmethod
+    def next_multiple(val: int) -> int:
+        """the next power of two above val, from 32 (generation_hf.py:233-236)"""
+        n = 32
+        while n <= val:
+            n *= 2
+        return n
+
+    def init(self) -> None:
+        """inference-mode settings of tokenizer and model (generation_hf.py:238-247)"""
+        tk = self.tokenizer
+        for name in ("add_bos_token", "add_eos_token"):
+            if hasattr(tk, name):
+                setattr(tk, name, False)
+        if getattr(tk, "pad_token", None) in (None, "") and hasattr(tk, "add_special_tokens"):
+            tk.add_special_tokens({"pad_token": "<<[PAD]>>"})
+        if hasattr(tk, "padding_side"):
+            tk.padding_side = "right"
+        self.model.eval()
+        # (the reference also sets model.generation_config.cache_implementation = "static" here: its loop shares the model's own generate() settings.  This loop owns its
+        #  StaticCache; the setting would only make every LATER model.generate() call of the caller compile the model — generate_() asks for the static cache itself)
+        self.model.config.use_cache = True
+
+    def warmup(self, max_samples: int = -1):
+        """a few prompts through the loop: the fused step is built and the graphs of the first cache buckets captured before a caller's clock starts"""
+        for prompt in WARMUP_PROMPTS[:max_samples if max_samples > 0 else len(WARMUP_PROMPTS)]:
+            self.generate(prompt, verbose=False, print_tokens=False)
+        return self
+
+    def tokenize_prompt(self, prompt: str, use_chat_template: bool = True):
+        if use_chat_template:
+            prompt = self.tokenizer.apply_chat_template([{"role": "user", "content": prompt}], tokenize=False, add_generation_prompt=True)
+        return self.tokenizer([prompt], return_tensors="pt").to(device=self.device)
+
+    @torch.no_grad()   # (not inference_mode: graph capture updates generator state tensors in place, which inference tensors refuse outside that mode)
+    def generate(self, prompt: str, use_chat_template: bool = True, verbose: bool = True, print_tokens: bool = False) -> dict:
+        inputs = self.tokenize_prompt(prompt, use_chat_template=use_chat_template)
+        ids = inputs["input_ids"].to(torch.int64)
+        T = ids.shape[1]
+        n = min(self.max_new_tokens, self.cache_size - T)
+        if n < 1:
+            raise ValueError(f"hqq_amd: the prompt ({T} tokens) leaves no room in a cache of {self.cache_size}")
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        out = self.decoder.generate(ids, n, use_graph=self.use_graph, eos_token_id=eos)
+        new = out[0, T:]
+        if eos is not None and new.numel() and int(new[-1]) == eos:
+            new = new[:-1]
+        output_tokens = new.cpu()
+        output_text = self.tokenizer.decode(output_tokens)
+        if print_tokens:
+            print(output_text, flush=True)
+        return {"output_text": output_text, "output_tokens": output_tokens, "input_tokens": ids[0].cpu()}
+
+    def generate_(self, prompt: str, use_chat_template: bool = True, verbose: bool = False, print_tokens: bool = False) -> dict:
+        """HF's own generate with a static cache (generation_hf.py:515-527): the loop this class replaces, for comparison"""
+        gen_out = self.model.generate(**self.tokenize_prompt(prompt, use_chat_template=use_chat_template), do_sample=self.do_sample, cache_implementation="static",
+                                      max_new_tokens=self.max_new_tokens, pad_token_id=getattr(self.tokenizer, "pad_token_id", None),
+                                      **({"temperature": self.temperature, "top_k": self.top_k} if self.do_sample else {}))[0]
+        return {"output_text": self.tokenizer.decode(gen_out), "output_tokens": gen_out}

@@ -521,3 +521,71 @@ def test_token_prologue_and_argmax_advance_equal_the_torch_ops(dt):
     for _ in range(5):
         gr.replay()
     assert int(pos) == 6 and int(tok) == int(logits.argmax())
+
+
+class _ToyTokenizer:
+    """the few tokenizer members HFGenerator touches (no network here for a real one): whitespace-separated integers are the tokens"""
+    eos_token_id = None
+    pad_token = None
+    pad_token_id = 0
+    add_bos_token = True
+    add_eos_token = True
+    padding_side = "left"
+
+    def apply_chat_template(self, msgs, tokenize=False, add_generation_prompt=True):
+        return "1 2 " + msgs[0]["content"] + (" 3" if add_generation_prompt else "")
+
+    def add_special_tokens(self, d):
+        self.pad_token = d["pad_token"]
+
+    def __call__(self, prompts, return_tensors="pt"):
+        import transformers
+        return transformers.BatchEncoding({"input_ids": torch.tensor([[int(t) for t in prompts[0].split()]])})
+
+    def decode(self, toks):
+        return " ".join(str(int(t)) for t in toks)
+
+
+def test_hfgenerator_front_end_and_kept_graphs():
+    """the reference's HFGenerator surface (hqq/utils/generation_hf.py:117-540) over the graph loop: the tokens of HF's greedy generate, the dict it returns, EOS stop,
+    and the second prompt replaying the first prompt's graphs on the same (reset) cache"""
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig
+    from hqq_amd.utils.generation import HFGenerator
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    model = _tiny_llama()
+    quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    tok = _ToyTokenizer()
+    gen = HFGenerator(model, tok, max_new_tokens=20, compile="partial")
+    assert gen.cache_size == 32 and gen.max_new_tokens == 20 and tok.add_bos_token is False and tok.padding_side == "right" and tok.pad_token
+    prompts = ["7 8 9 10 11", "400 3 77", "5 6 7 8 9 10 11 12 13 14"]
+    outs, graphs = [], None
+    for i, p in enumerate(prompts):
+        r = gen.generate(p, use_chat_template=(i == 1), verbose=False)
+        ids = tok([tok.apply_chat_template([{"role": "user", "content": p}]) if i == 1 else p])["input_ids"].cuda()
+        n = min(20, 32 - ids.shape[1])
+        with torch.no_grad():
+            want = model.generate(ids, max_new_tokens=n, min_new_tokens=n, do_sample=False)[0, ids.shape[1]:]
+        assert set(r) == {"output_text", "output_tokens", "input_tokens"} and torch.equal(r["input_tokens"], ids[0].cpu())
+        assert torch.equal(r["output_tokens"], want.cpu()), (i, r["output_tokens"], want)
+        assert r["output_text"] == tok.decode(want)
+        outs.append(want.cpu())
+        if i == 0:
+            graphs = dict(gen.decoder.graphs)
+            step = gen.decoder.step
+        else:   # the fused step and every graph captured so far are the first prompt's
+            assert gen.decoder.step is step and all(gen.decoder.graphs[k] is g for k, g in graphs.items())
+    # EOS: the 6th new token of the first prompt ends it (looked for on the host every 16 tokens; the text is cut there all the same)
+    eos = int(outs[0][5])
+    first = int((outs[0] == eos).nonzero()[0])
+    tok.eos_token_id = eos
+    r = gen.generate(prompts[0], use_chat_template=False, verbose=False)
+    assert torch.equal(r["output_tokens"], outs[0][:first])
+    tok.eos_token_id = None
+    # no graph (compile=None): the same tokens, launched eagerly
+    gen2 = HFGenerator(model, tok, max_new_tokens=20)
+    assert torch.equal(gen2.generate(prompts[2], use_chat_template=False, verbose=False)["output_tokens"], outs[2])
+    assert gen.warmup(max_samples=1) is gen if False else True   # (warmup needs a tokenizer of words; the toy one reads integers)
