@@ -859,6 +859,7 @@ def main():
                                    vocab_size=32000, max_position_embeddings=2048)
                 dflt = torch.get_default_dtype()
                 torch.set_default_dtype(torch.float16)
+                torch.manual_seed(20250)   # the same random-init model in every run: the identity check below is then one fixed comparison, not a new draw per run
                 try:
                     with torch.device(dev):
                         model = LlamaForCausalLM(lcfg).eval()
@@ -903,7 +904,23 @@ def main():
                     want_new = want[0, ids.shape[1]:].clone()
                     n_same = int((got[0, ids.shape[1]:] == want[0, ids.shape[1]:]).to(torch.int32).cumprod(0).sum())
                     out["end_to_end"]["identity_check"] = {"tokens": 8, "identical_prefix": n_same, "identical": bool(n_same == 8),
+                                                           "want_tokens": want[0, ids.shape[1]:].tolist(), "got_tokens": got[0, ids.shape[1]:].tolist(),
                                                            "against": "HF generate() of the same quantised 7B-shaped model under HQQBackend.PYTORCH_FORWARD"}
+                    if n_same < 8:
+                        # where the two arithmetics part: the reference's own logits at that step (teacher-forced on the common prefix).  The two paths compute the same
+                        # function in different summation orders (fp16 dequantise + library GEMM there, fused GEMV here: ~1e-3 relative on a logit), so a step whose two
+                        # best logits are closer than that can go either way — on a random-init model (near-uniform logits) that happens now and then
+                        HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+                        try:
+                            with torch.no_grad():
+                                lg = ref_model(torch.cat([ids, want[:, ids.shape[1]:ids.shape[1] + n_same]], dim=1)).logits[0, -1].float()
+                        finally:
+                            HQQLinear.set_backend(HQQBackend.HIP)
+                        top = torch.topk(lg, 2)
+                        out["end_to_end"]["identity_check"]["first_difference"] = {
+                            "at_token": n_same, "reference_top2_tokens": top.indices.tolist(), "reference_top2_logits": [round(float(v), 5) for v in top.values],
+                            "reference_top2_gap": round(float(top.values[0] - top.values[1]), 6), "ours_picked": int(got[0, ids.shape[1] + n_same]),
+                            "fp16_ulp_at_that_logit": float(torch.finfo(torch.float16).eps * abs(float(top.values[0])))}
                 except Exception as e:
                     out["end_to_end"]["identity_check"] = {"error": repr(e)}
                 del ref_model
