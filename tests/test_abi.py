@@ -63,6 +63,14 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 1, 4, 0, 2, 0, VP2, VP2, st, 0, None) == -3      # fp32 activations
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 1, 4, 1, 2, 2, VP2, VP2, st, 0, None) == -2      # rank 2 of 2
     assert L.hqq_hip_exchange(1, VP1, (ctypes.c_int64 * 1)(512), 65, 4, 1, 2, 0, VP2, VP2, st, 0, None) == -2     # more rows than HQQ_EXCHANGE_MAX_ROWS
+    # the per-token ends of the decode step (ABI 7) validate before they launch
+    p16 = ctypes.c_void_p(16)
+    assert L.hqq_hip_token_prologue(p16, p16, p16, 100, 4100, None, None, 1, 0, p16, None, None, None, 1, None) == -2     # H not a multiple of 8
+    assert L.hqq_hip_token_prologue(p16, p16, p16, 100, 4096, p16, None, 64, 128, p16, p16, p16, None, 1, None) == -2     # a cos table without its sin table
+    assert L.hqq_hip_token_prologue(p16, p16, p16, 100, 4096, None, None, 1, 0, p16, None, None, None, 0, None) == -4     # fp32
+    assert L.hqq_hip_token_prologue(p16, p16, ctypes.c_void_p(24), 100, 4096, None, None, 1, 0, p16, None, None, None, 1, None) == -6   # misaligned embedding
+    assert L.hqq_hip_argmax_advance(None, 100, 1, p16, None, None, None) == -2 and L.hqq_hip_argmax_advance(p16, 0, 1, p16, None, None, None) == -2
+    assert L.hqq_hip_argmax_advance(p16, 100, 0, p16, None, None, None) == -4
 
 
 def test_the_library_owns_no_device_memory_and_reads_no_environment():
