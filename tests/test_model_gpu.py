@@ -589,3 +589,40 @@ def test_hfgenerator_front_end_and_kept_graphs():
     gen2 = HFGenerator(model, tok, max_new_tokens=20)
     assert torch.equal(gen2.generate(prompts[2], use_chat_template=False, verbose=False)["output_tokens"], outs[2])
     assert gen.warmup(max_samples=1) is gen if False else True   # (warmup needs a tokenizer of words; the toy one reads integers)
+
+
+@pytest.mark.parametrize("arch", ["llama3-like", "mistral"])
+def test_fused_decoder_on_gqa_models_with_128_wide_heads(arch):
+    """the shapes of today's checkpoints — grouped-query attention (4 query heads per key / value head), 128-wide heads, a large rope base; and MistralForCausalLM, the other
+    model_type the fused step admits — through the folded launches (rotary-paired q / k of unequal size in one launch): the tokens of the same model under PYTORCH_FORWARD"""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
+    from hqq_amd.backends.hip import group_llama_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQBackend, HQQLinear
+    from hqq_amd.utils import llama_fused
+    from hqq_amd.utils.generation import GraphedGreedyDecoder
+    from hqq_amd.utils.model import quantize_model
+    from hqq_amd.utils.patching import prepare_for_inference
+    torch.manual_seed(11)
+    kw = dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=1, vocab_size=1024, max_position_embeddings=256)
+    if arch == "mistral":
+        model = MistralForCausalLM(MistralConfig(sliding_window=None, head_dim=128, **kw))
+    else:
+        model = LlamaForCausalLM(LlamaConfig(rope_theta=500000.0, **kw))
+    model = model.half().cuda().eval()
+    quantize_model(model, BaseQuantizeConfig(nbits=4, group_size=64, axis=1), compute_dtype=torch.float16, device="cuda")
+    ref_model = copy.deepcopy(model)
+    ids = torch.randint(0, 1024, (1, 9), generator=torch.Generator().manual_seed(5)).cuda()
+    HQQLinear.set_backend(HQQBackend.PYTORCH_FORWARD)
+    try:
+        with torch.no_grad():
+            want = ref_model.generate(ids, max_new_tokens=24, do_sample=False, pad_token_id=0)
+    finally:
+        HQQLinear.set_backend(HQQBackend.HIP)
+    prepare_for_inference(model, backend="hip")
+    group_llama_projections(model)
+    assert llama_fused.supports(model)
+    dec = GraphedGreedyDecoder(model, max_cache_len=64)
+    got = dec.generate(ids, 24, use_graph=True)
+    assert dec.fused and dec.step is not None and dec.step.folded and dec.step.one_launch_front
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
