@@ -495,7 +495,9 @@ class HQQLinear(nn.Module):
     def _w3s_copy(self, W_q: Tensor):
         m = self.meta
         N, K = m["shape"]
-        key = (W_q.data_ptr(), W_q._version, m["scale"].data_ptr(), m["scale"]._version, m["zero"].data_ptr(), m["zero"]._version)
+        # (tensors made under torch.inference_mode() carry no version counter: identity alone keys the copy there, as in backends/hip.py)
+        ver = lambda t: None if t.is_inference() else t._version
+        key = (W_q.data_ptr(), ver(W_q), m["scale"].data_ptr(), ver(m["scale"]), m["zero"].data_ptr(), ver(m["zero"]))
         c = getattr(self, "_w3s", None)
         if c is None or c[0] != key:
             if torch.cuda.is_current_stream_capturing():   # never built inside a capture (it allocates): the container's own path serves that step

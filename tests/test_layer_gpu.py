@@ -318,3 +318,21 @@ def test_3bit_hqqlinear_hip_route_reads_the_stream_layout(ops):
     assert fresh._w3s is None
     torch.testing.assert_close(yc.float(), fresh(xs[0]).float(), rtol=4e-3, atol=4e-3 * float(ref.abs().max()) * K ** 0.5)
     assert fresh._w3s is not None
+
+
+def test_3bit_layer_made_under_inference_mode_runs(ops):
+    """tensors created under torch.inference_mode() carry no version counter (reading `_version` raises): a 3-bit layer quantised there
+    must still build and key its stream-layout copy (round-5 advisor finding), and give the bits of a layer made outside it"""
+    torch.manual_seed(5)
+    K, N = 512, 256
+    cfg = BaseQuantizeConfig(nbits=3, group_size=64, axis=1)
+    lin = torch.nn.Linear(K, N, bias=False)
+    x = torch.randn(2, K, device="cuda").half()
+    with torch.inference_mode():
+        layer = HQQLinear(lin, cfg, compute_dtype=torch.float16, device="cuda")
+        assert layer.W_q.is_inference() or layer.meta["scale"].is_inference()
+        y = layer(x)
+        y2 = layer(x)   # the second call finds the copy by its key
+        assert layer._w3s is not None and torch.equal(y, y2)
+    ref = layer.dequantize().float()
+    torch.testing.assert_close(y.float(), x.float() @ ref.t(), rtol=4e-3, atol=4e-3 * float(ref.abs().max()) * K ** 0.5)
