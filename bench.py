@@ -184,6 +184,21 @@ def _graphed(step, use_graph, rank=0):
         return step, False
 
 
+def reference_forward_cpu(Wq, scale, zero, x, nbits, N, K, gs=64):
+    """HQQBackend.PYTORCH's forward restated with the reference's own torch ops on CPU tensors (8 / 4 / 2 bit, axis 1): BitPack.unpack_*
+    (hqq/core/bitpack.py:14-22, 31-38, 53-64: every slab shifted out of the packed bytes into rows [s step, (s + 1) step) of a compute-dtype
+    buffer), Quantizer.dequantize ((W_r - zero) * scale, quantize.py:183-199), torch.matmul(x, W.t()) (quantize.py:880-882).
+    The `cpu_baseline` leg times this; tests/test_host_api.py pins it to the fixtures the imported reference wrote (tests/golden/cfg1_*)."""
+    per = 8 // nbits
+    mask = (1 << nbits) - 1
+    step = Wq.shape[0]
+    tmp = torch.empty([per * step, gs], dtype=scale.dtype)
+    for s_ in range(per):
+        tmp[s_ * step:(s_ + 1) * step] = (Wq >> (nbits * (per - 1 - s_))) & mask
+    W = ((tmp - zero) * scale).reshape(N, K)
+    return torch.matmul(x, W.t())
+
+
 def cpu_baseline(nbits):
     """HQQBackend.PYTORCH's per-call arithmetic on this box's host cores, bounded to ~10 s each:
     (1) restated in torch eager with the reference's own ops — BitPack.unpack (bitpack.py:31-38 / :53-64 / :14-22), Quantizer.dequantize
@@ -197,7 +212,7 @@ def cpu_baseline(nbits):
         cores = os.cpu_count() or 1
     nb = gemv_bytes(N, K, nbits)
     stack_calls = sum(gemv_bytes(n, k, nbits) for _, n, k in LLAMA2_7B_BLOCK) * N_BLOCKS_7B / nb
-    out = {"unit": "GB/s", "cores": cores, "kind": "port"}
+    out = {"unit": "GB/s", "cores": cores, "threads": cores, "host_cores": cores, "kind": "port"}
     # ---- (1) torch eager ----
     if nbits in (8, 4, 2):
         g = torch.Generator().manual_seed(0)
@@ -207,15 +222,9 @@ def cpu_baseline(nbits):
         scale = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).half()
         zero = (torch.rand(R, 1, generator=g) * (2 ** nbits - 1)).half()
         x = torch.randn(1, K, generator=g).half()
-        mask = (1 << nbits) - 1
 
         def fwd():
-            step = Wq.shape[0]
-            tmp = torch.empty([per * step, 64], dtype=torch.float16)
-            for s in range(per):
-                tmp[s * step:(s + 1) * step] = (Wq >> (nbits * (per - 1 - s))) & mask
-            W = ((tmp - zero) * scale).reshape(N, K)
-            return torch.matmul(x, W.t())
+            return reference_forward_cpu(Wq, scale, zero, x, nbits, N, K)
 
         # torch's fp16 CPU kernels do not scale to every core of a big host: try a few thread counts (2 s each) and keep the best
         best = None
@@ -234,7 +243,7 @@ def cpu_baseline(nbits):
                 if best is None or el / reps < best[0]:
                     best = (el / reps, th, reps, el)
         t, th, reps, el = best
-        out["cores"] = th
+        out["cores"] = out["threads"] = th   # the threads actually used (the fastest of the counts tried); host_cores = what the box has
         out.update({"value": round(nb / t / 1e9, 4), "ms_per_layer_call": round(t * 1e3, 3),
                     "tok_s_7b_stack_equiv": round(1.0 / (t * stack_calls), 4),
                     "sample": f"torch {torch.__version__} CPU eager restatement of HQQBackend.PYTORCH's forward (unpack -> (W_r - zero) * scale -> matmul, fp16) on one "
@@ -577,7 +586,8 @@ def main():
         ach = (bytes_per_step_rank / unit_launches) / avg_launch_s / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            # PMC traffic is committed for the configuration it was measured on only (7B, bs=1 fp16, exact mode)
-                           "traffic": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and a.gemv_mode != "factored" and not big) else None,
+                           "traffic": None,   # (not counted in this run; the committed counter run of this configuration follows)
+                           "traffic_committed_pmc": _pmc_traffic(nbits) if (M == 1 and a.dtype == "f16" and a.gemv_mode != "factored" and not big) else None,
                            "kernel": _decode_kernel_name(nbits, M, a.dtype, a.gemv_mode),
                            "avg_launch_us": round(avg_launch_s * 1e6, 3),
                            "bytes_per_launch": bytes_per_step_rank // unit_launches,
@@ -667,6 +677,69 @@ def main():
         ol32 = {grp: [torch.empty(32, dimN[n], device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
         leg("7b-stack bs=32", lambda: step(bs_x=xs32, outs_by_grp=ol32), nblocks * sum(gemv_bytes(N, K, nbits, 32) for _, N, K in BLOCK), 32,
             nblocks * len(EXCHANGE_GROUPS), _decode_kernel_name(nbits, 32, a.dtype, a.gemv_mode))
+        # ---- three legs that carry the argument of DESIGN.md section 3.7 in the driver's own run ----
+        bytes_7b = nblocks * sum(gemv_bytes(N, K, nbits, 1) for _, N, K in BLOCK)
+        n_launch = nblocks * len(EXCHANGE_GROUPS)
+        kname1 = _decode_kernel_name(nbits, 1, a.dtype, a.gemv_mode)
+        # (i) KERNEL STUDY, not a decoder: the same 128 launches dealt over three parallel graph branches — no launch waits for its predecessor.
+        #     What the stream-ordered chain costs is the difference to the headline.
+        if a.gemv_mode == "exact":
+            try:
+                br = [torch.cuda.Stream() for _ in range(2)]
+                ol3 = [{g_: [torch.empty_like(t) for t in ts] for g_, ts in out_local.items()} for _ in range(3)]
+
+                def step_nodep():
+                    main_s = torch.cuda.current_stream()
+                    for st in br:
+                        st.wait_stream(main_s)
+                    i = 0
+                    for blk in blocks:
+                        for grp in EXCHANGE_GROUPS:
+                            b = i % 3
+                            i += 1
+                            with torch.cuda.stream(main_s if b == 0 else br[b - 1]):
+                                Ls = [blk[name] for name in grp]
+                                ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits, outs=ol3[b][grp], opts=group_opts(Ls))
+                    for st in br:
+                        main_s.wait_stream(st)
+                leg("7b-stack bs=1, NO dependency chain: 3 parallel graph branches (kernel study — a decoder's launches depend on each other)", step_nodep, bytes_7b, 1, n_launch, kname1)
+                legs[-1]["study"] = True
+                del ol3
+            except Exception as e:
+                legs.append({"name": "7b-stack bs=1, NO dependency chain", "error": repr(e)})
+            # (ii) HQQ_OPT_FACTORED: the group's affine map taken out of the dot product — NOT the reference's twice-rounded weights (opt-in; tests state its error)
+            if nbits in (4, 2, 8):
+                def step_factored():
+                    for blk in blocks:
+                        for grp in EXCHANGE_GROUPS:
+                            Ls = [blk[name] for name in grp]
+                            ops.gemv_grouped(xs[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits, outs=out_local[grp], opts=ops.OPT_FACTORED)
+                leg("7b-stack bs=1 FACTORED (HQQ_OPT_FACTORED: not reference-exact weights, opt-in)", step_factored, bytes_7b, 1, n_launch, _decode_kernel_name(nbits, 1, a.dtype, "factored"))
+                legs[-1]["reference_exact"] = False
+            # (iii) the Llama-2-70B linear stack (BASELINE.json configs[4]'s shapes, 80 blocks, 35 GB at 4 bits) on THIS ONE GPU: the same kernel with
+            #       launches of 19-264 MB instead of 9-51 MB — the per-launch fixed cost amortised
+            try:
+                free_b, _ = torch.cuda.mem_get_info()
+                need = N_BLOCKS_70B * sum(gemv_bytes(N, K, nbits, 1) for _, N, K in LLAMA2_70B_BLOCK)
+                if free_b > need * 1.15 + (2 << 30):
+                    b70 = [{name: make_layer(ops, name, N, K, nbits, dev, seed=70000 + 16 * b_ + i, random_codes=a.random_codes, cd=cd) for i, (name, N, K) in enumerate(LLAMA2_70B_BLOCK)}
+                           for b_ in range(N_BLOCKS_70B)]
+                    x70 = {K: torch.randn(1, K, device=dev, generator=gx).to(cd) for K in sorted({K for _, _, K in LLAMA2_70B_BLOCK})}
+                    o70 = {grp: [torch.empty(1, b70[0][n].N, device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+
+                    def step70():
+                        for blk in b70:
+                            for grp in EXCHANGE_GROUPS:
+                                Ls = [blk[name] for name in grp]
+                                ops.gemv_grouped(x70[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits, outs=o70[grp], opts=group_opts(Ls))
+                    leg("70b-stack bs=1 on this one GPU (80 blocks, unsharded)", step70, need, 1, N_BLOCKS_70B * len(EXCHANGE_GROUPS), kname1)
+                    legs[-1]["layers_with_three_op_rebuild"] = f"{sum(1 for blk in b70 for L in blk.values() if L.opts & ops.OPT_META_SCALABLE)}/{N_BLOCKS_70B * len(LLAMA2_70B_BLOCK)}"
+                    del b70, x70, o70
+                    torch.cuda.empty_cache()
+                else:
+                    legs.append({"name": "70b-stack bs=1 on this one GPU", "skipped": f"needs {need / 1e9:.1f} GB, {free_b / 1e9:.1f} GB free"})
+            except Exception as e:
+                legs.append({"name": "70b-stack bs=1 on this one GPU", "error": repr(e)})
         qs = [blk["q"] for blk in blocks]   # 32 distinct 4096x4096 layers (268 MB packed: beyond the Infinity Cache)
         y1 = torch.empty(1, 4096, device=dev, dtype=cd)
         y32 = torch.empty(32, 4096, device=dev, dtype=cd)

@@ -44,11 +44,6 @@
 #include "gemv_shared.h"
 #include "w3s.h"
 
-#ifdef GV_LAB_PREFETCH   // lab: what the NEXT launch will stream first (set by the caller before every launch; tools/r5_prefetch_lab.py)
-static const uint8_t* g_lab_pf_base = nullptr;
-static int g_lab_pf_rows = 0, g_lab_pf_row_bytes = 0;
-extern "C" void hqq_lab_set_prefetch(const void* base, int rows, int row_bytes) { g_lab_pf_base = static_cast<const uint8_t*>(base); g_lab_pf_rows = rows; g_lab_pf_row_bytes = row_bytes; }
-#endif
 namespace hqq {
 
 // one 16-byte weight vector (16 k-values of `PER` rows) against the lane's 16 x-values of M rows
@@ -93,7 +88,6 @@ struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the r
 // 8 x 2 grid (o / down of a 7B block: 2048 packed rows), where 8 (x 2 per CU) measured -7 % per launch (fewer workgroups to dispatch and
 // half as many copies of x staged per CU; grouped launches lose 11 % with it: profiles/r03_ab_w8x2.txt)
 #define GV_KERNEL_NAME gemv_f16_kernel
-#define GV_KERNEL_EARLY_B 0
 #define GV_KERNEL_XPASS2 0
 #include "gemv_kernel.inc"
 #undef GV_KERNEL_NAME
@@ -103,235 +97,6 @@ struct GroupConst {   // c1 = s / F, c2 = 1024 + F z  for every slab, from the r
 #include "gemv_kernel.inc"
 #undef GV_KERNEL_NAME
 #undef GV_KERNEL_XPASS2
-#undef GV_KERNEL_EARLY_B
-#define GV_KERNEL_NAME gemv_f16_wide_kernel
-#define GV_KERNEL_EARLY_B 1
-#define GV_KERNEL_XPASS2 0
-#include "gemv_kernel.inc"
-#undef GV_KERNEL_NAME
-#undef GV_KERNEL_EARLY_B
-#undef GV_KERNEL_XPASS2
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The ring variant of the streaming loop (round 3; a LAB SWITCH, off by default: GV_RING_UNITS): units of ONE KiB (one 16-byte load per
-// lane), NF of them in flight.  tools/floor_probe.hip — this kernel's launch structure with the arithmetic taken out — says that over
-// the 7B stack's 128 dependent launches two 2-KiB units in flight stream at 0.50 of 8 TB/s with no arithmetic at all and three 1-KiB
-// units at 0.57: a wave of a 7B launch has only 3-11 KiB to stream, so the granule it requests and consumes in decides how much of
-// its short life is pipelined.  MEASURED on the real kernel (same-box A/B, profiles/r03_ab_ring.txt): it does not carry over — ring of
-// 2 / 3 / 4 units 1.01 / 1.03 / 1.06 ms against 1.00 for the ping-pong loop, a 4096 x 4096 layer 4.9 us against 4.15 — because the
-// real loop's streaming phase is bound by the rebuild's VALU throughput (53 of its 59-68 instructions per KiB), not by how the requests
-// are spaced; the probe's advantage is a property of an idle VALU.  Kept because it is bit-identical (the parity suite ran green on
-// it) and the cheapest place to try the next idea about the request pattern.  The first try — the old loop with GV_U_LOADS = 1 — per
-// unit it paid 2 PER two-byte loads, their hand-round and ~12 address instructions.  Here a unit costs three loads and no address
-// arithmetic at all:
-//   weights   the layer's descriptor + scalar offset of (row, unit) + lane offset 16 lane (a constant)
-//   meta      ONE two-byte load of zero and one of scale per unit: lane l fetches group (l & 15) of slab (l >> 4) % PER — the tensor's
-//             descriptor + scalar offset of (row, unit's first group) + lane offset = slab's row distance + 2 (l & 15); ds_bpermute
-//             hands group (lane >> 2) of slab s to every lane (the engine's scheme)
-//   tails     K % 1024 != 0: in a row's last unit the lanes past K re-read the row's last 16 bytes and the row's last group (two lane-offset
-//             registers per load kind, picked by one select per issue): finite weights against the zeros LDS holds for x past K
-// Same operations in the same order per 16-byte vector as gemv_f16_kernel (SlabExact), same row-end reduction: same bits.
-// fp16, exact weights, group_size 64, one row per wave at a time (no K-split: those shapes keep the ping-pong kernel).
-struct RUnit { u32x4 w; uint32_t z, sc; };
-struct RLayer {   // the layer a wave is streaming: three buffer descriptors over the whole layer (built when the layer changes, not per unit)
-  __amdgpu_buffer_rsrc_t rw, rz, rs;
-  int N, row0, end;
-};
-
-template <int NBITS, int M, bool SUB, int WPG, int NF>
-__global__ __launch_bounds__(WPG * 64) void gemv_ring_kernel(GV_IN_PARAMS, const GvOut o) {
-  const GvIn a = GV_IN_PACK;
-#ifndef GV_LAB_PRELOAD
-  GV_PIN_ARGS;
-#endif
-  constexpr int PER = 8 / NBITS;
-  static_assert(PER == 1 || PER == 2 || PER == 4, "slab index = (lane >> 4) & (PER - 1)");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  u32x4* xs = reinterpret_cast<u32x4*>(smem);   // [M][K/1024 (padded)][2 planes][64 lanes] x 16 B
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = a.K, G = a.G;
-  const int nunits = (K + GV_KSTEP - 1) / GV_KSTEP;
-  const int planes_per_m = nunits * 2 * 64;
-  const int stride = gridDim.x * WPG;
-  const int total = a.total_prow;
-  const int lane_slab = (lane >> 4) & (PER - 1);
-  // lane offsets of a unit's three loads — constants of the launch, except the slab's row distance (per layer).  In a row's LAST unit
-  // (K % 1024 != 0) the lanes past K re-read the row's last 16 bytes / last group instead: finite weights against zeros in x
-  const int klast = K - (nunits - 1) * GV_KSTEP, glast = G - (nunits - 1) * 16;   // bytes / groups of a row's last unit
-  const int w_n = lane * 16, w_l = (lane * 16 < klast ? lane * 16 : klast - 16);
-  const int g_n = (lane & 15) * 2, g_l = ((lane & 15) < glast ? (lane & 15) : glast - 1) * 2;
-  int m_n = g_n, m_l = g_l;   // + slab's row distance in the zero / scale tensors (set_layer)
-
-  auto set_layer = [&](const LayerCtx& c) {
-    const uint32_t rps = static_cast<uint32_t>(c.N) / PER;
-    const int slab_off = lane_slab * static_cast<int>(rps * static_cast<uint32_t>(G) * 2u);
-    m_n = g_n + slab_off;
-    m_l = g_l + slab_off;
-    return RLayer{buffer_rsrc(c.Wq), buffer_rsrc(c.zero), buffer_rsrc(c.scale), c.N, c.row0, c.end};
-  };
-  // one unit = three loads: descriptor of the layer + SCALAR offset of (row, unit) + constant lane offset — no address arithmetic on
-  // the vector side, a dozen scalar instructions (a first version rebuilt three descriptors per unit: ~60 scalar instructions per
-  // KiB, as many issue slots as the rebuild's VALU — it ran 5 % behind the ping-pong loop)
-  auto issue = [&](RUnit& un, const RLayer& c, int prow, int unit, bool live) {
-    const int p = live ? prow - c.row0 : 0;
-    const int u = live ? unit : 0;
-    const uint32_t moff = (static_cast<uint32_t>(p) * static_cast<uint32_t>(G) + static_cast<uint32_t>(u) * 16u) * 2u;   // wave-uniform
-    const uint32_t woff = static_cast<uint32_t>(p) * static_cast<uint32_t>(K) + static_cast<uint32_t>(u) * GV_KSTEP;
-    const bool lastu = u + 1 >= nunits;
-    const int vm = lastu ? m_l : m_n, vw = lastu ? w_l : w_n;
-    // meta first: the consumer needs it before the weight vector (loads return in issue order)
-    un.z = __builtin_amdgcn_raw_buffer_load_b16(c.rz, vm, moff, 0);
-    un.sc = __builtin_amdgcn_raw_buffer_load_b16(c.rs, vm, moff, 0);
-    un.w = __builtin_amdgcn_raw_buffer_load_b128(c.rw, vw, woff, 2 /* nt: streamed once */);
-  };
-  auto advance = [&](int& p, int& u, RLayer& c) {
-    u += 1;
-    if (u >= nunits) {
-      u = 0;
-      p += stride;
-      if (p >= c.end && p < total) c = set_layer(select_layer(a, p));
-    }
-  };
-
-  // ---- prologue as in gemv_f16_kernel: the workgroup's first pass of x loads, this wave's first unit, then x into LDS ----
-  const int chunks_per_m = nunits * 64;
-  auto load_chunk = [&](int m, int j, u32x4& v0, u32x4& v1) {
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.x + static_cast<int64_t>(m) * K), 0, K * 2, 0x00020000);
-    v0 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32, 0, 0);
-    v1 = __builtin_amdgcn_raw_buffer_load_b128(rx, j * 32 + 16, 0, 0);
-  };
-  auto store_chunk = [&](int m, int j, const u32x4& v0, const u32x4& v1) {
-    if (j >= chunks_per_m) return;
-    const int it = j >> 6, ln = j & 63;
-    xs[m * planes_per_m + (it * 2 + 0) * 64 + ln] = permute_x8(v0);
-    xs[m * planes_per_m + (it * 2 + 1) * 64 + ln] = permute_x8(v1);
-  };
-  u32x4 xv0, xv1;
-  load_chunk(0, tid, xv0, xv1);
-  __builtin_amdgcn_sched_barrier(0);
-
-  int cp = blockIdx.x * WPG + wave, cu = 0;   // cursor: the next unit to request
-  const bool live0 = cp < total;
-  cp = live0 ? cp : total - 1;
-#ifdef GV_LAB_PRELOAD
-  LayerCtx lc0{a.Wq[0], a.scale[0], a.zero[0], a.N[0], 0, a.prow_end[0]};
-  if (cp >= a.prow_end[0]) {
-    asm volatile("");
-    lc0 = select_layer(a, cp);
-  }
-#else
-  LayerCtx lc0 = select_layer(a, cp);
-#endif
-  RLayer lc = set_layer(lc0);
-  RUnit ring[NF];
-  int rp[NF], ru[NF];
-  bool rl[NF];
-  rp[0] = cp; ru[0] = cu; rl[0] = live0;
-  issue(ring[0], lc, cp, cu, live0);
-#ifdef GV_LAB_PRELOAD
-  GV_PIN_ARGS;
-#endif
-#ifndef GV_RING_EARLY
-#define GV_RING_EARLY 1   // units requested in front of the x staging (the ping-pong kernel requests one 2-KiB unit there)
-#endif
-#pragma unroll
-  for (int f = 1; f < GV_RING_EARLY && f < NF; ++f) {
-    advance(cp, cu, lc);
-    rl[f] = live0 && cp < total;
-    rp[f] = cp; ru[f] = cu;
-    issue(ring[f], lc, rl[f] ? cp : rp[0], cu, rl[f]);
-  }
-  store_chunk(0, tid, xv0, xv1);
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-    for (int j = tid + (m == 0 ? WPG * 64 : 0); j < chunks_per_m; j += WPG * 64) {
-      load_chunk(m, j, xv0, xv1);
-      store_chunk(m, j, xv0, xv1);
-    }
-  __syncthreads();
-  if (!live0) return;   // (after the barrier: every wave of the workgroup took part in the staging)
-
-  f32x4 acc[M][PER];
-#pragma unroll
-  for (int m = 0; m < M; ++m)
-#pragma unroll
-    for (int s = 0; s < PER; ++s) acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint32_t magic;
-  asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
-  // the fetching lane scales its own (z, s) once for the three-op rebuild: J by the slab it fetched for
-  half2_t f_lane = {static_cast<half_t>(1.0f), static_cast<half_t>(1.0f)};
-  if constexpr (SUB) {
-    const int J = 9 - NBITS * (PER - 1 - lane_slab);
-    f_lane = half2_t{static_cast<half_t>(1.0f / static_cast<float>(1 << J)), static_cast<half_t>(static_cast<float>(1 << J))};
-  }
-  // hand-round sources: slab s, group (lane >> 2) of the unit (in a row's last unit the fetching lanes past the row's last group hold
-  // that group's constants: see issue())
-  int idx_n[PER];
-#pragma unroll
-  for (int s = 0; s < PER; ++s) idx_n[s] = (s * 16 + (lane >> 2)) << 2;
-
-  auto finish_row = [&](int prow) {
-    const OutCtx oc = select_out(a, o, prow);
-    const int p = prow - oc.row0;
-    const int rows_per_slab = oc.N / PER;
-    float mine = 0.f;
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int s = 0; s < PER; ++s) {
-        const float v = diag_sum(acc[m][s]);
-        acc[m][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mine = (lane == m * PER + s) ? v : mine;
-      }
-    if (lane < M * PER) {
-      const int m = lane / PER, s = lane - m * PER;
-      const int n = p + s * rows_per_slab;
-      half_t ov = static_cast<half_t>(mine);
-      if (oc.bias) ov = ov + oc.bias[n];   // `out += bias` on the rounded matmul result (quantize.py:896-897)
-      oc.y[static_cast<int64_t>(m) * oc.N + n] = ov;
-    }
-  };
-  auto consume = [&](const RUnit& un, int prow, int unit) {
-    uint32_t mine = un.z | (un.sc << 16);
-    if constexpr (SUB) mine = __builtin_bit_cast(uint32_t, as_h2(mine) * f_lane);
-    const bool lastu = unit + 1 >= nunits;   // wave-uniform
-    uint32_t zs[PER];
-#pragma unroll
-    for (int s = 0; s < PER; ++s) zs[s] = __builtin_amdgcn_ds_bpermute(idx_n[s], mine);
-    h8_t b0[M], b1[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      b0[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (unit * 2 + 0) * 64 + lane]);
-      b1[m] = __builtin_bit_cast(h8_t, xs[m * planes_per_m + (unit * 2 + 1) * 64 + lane]);
-    }
-    SlabExact<NBITS, M, 0, PER, SUB>::run(un.w, zs, b0, b1, acc, magic);
-    if (lastu) finish_row(prow);
-  };
-
-  // ---- the other NF - 1 units go out behind the barrier; then: consume the oldest, request the next into its registers.  One loop
-  //      shape, one exit at the bottom; a unit past the wave's last one is still requested (the layer's first KiB, cached) and not
-  //      consumed, so that every wait is an exact count ----
-#pragma unroll
-  for (int f = (GV_RING_EARLY < NF ? (GV_RING_EARLY > 1 ? GV_RING_EARLY : 1) : NF); f < NF; ++f) {
-    advance(cp, cu, lc);
-    rl[f] = cp < total;
-    rp[f] = cp; ru[f] = cu;
-    issue(ring[f], lc, rl[f] ? cp : rp[0], cu, rl[f]);
-  }
-  bool more;
-  do {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      if (rl[f]) consume(ring[f], rp[f], ru[f]);
-      advance(cp, cu, lc);
-      rl[f] = cp < total;
-      rp[f] = cp; ru[f] = cu;
-      issue(ring[f], lc, rl[f] ? cp : total - 1, cu, rl[f]);
-    }
-    more = rl[0];
-  } while (more);
-}
 
 static int g_num_cus = 0;
 static int num_cus() {
@@ -343,55 +108,9 @@ static int num_cus() {
   return g_num_cus;
 }
 
-template <int NBITS, int M, bool SUB, int WPG>
-static int launch_gemv_ring(const GvArgs& args, hipStream_t st) {
-  constexpr int NF = GV_RING_UNITS > 0 ? GV_RING_UNITS : 3;
-  constexpr int WG_PER_CU = GV_WG_PER_CU * GV_WAVES / WPG;
-  GvArgs a = args;
-  const int nunits = (a.K + GV_KSTEP - 1) / GV_KSTEP;
-  const size_t lds = (static_cast<size_t>(M) * nunits * GV_KSTEP * 2 + 15) & ~static_cast<size_t>(15);
-  auto kern = gemv_ring_kernel<NBITS, M, SUB, WPG, NF>;
-  int per_cu = static_cast<int>(160 * 1024 / (lds + 256));
-  per_cu = per_cu > WG_PER_CU ? WG_PER_CU : (per_cu < 1 ? 1 : per_cu);
-  {
-    static int by_regs = 0;   // per instantiation: registers bound the residency too
-    if (by_regs == 0) {
-      hipFuncAttributes fa;
-      by_regs = WG_PER_CU;
-      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)) == hipSuccess && fa.numRegs > 0) {
-        const int regs = (fa.numRegs + 7) & ~7;
-        by_regs = (512 / regs) * 4 / WPG;
-        by_regs = by_regs < 1 ? 1 : by_regs;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-    per_cu = per_cu > by_regs ? by_regs : per_cu;
-  }
-  const int tiles = (a.total_prow + WPG - 1) / WPG, cap = num_cus() * per_cu;
-  const int grid = tiles < cap ? tiles : cap;
-  if (lds > 64 * 1024) {
-    static LdsRaised raised;
-    if (const int rc = raise_lds_limit(raised, reinterpret_cast<const void*>(kern), GV_LDS_MAX, "hqq_hip_gemv")) return rc;
-  }
-  GvIn in;
-  GvOut out;
-  for (int i = 0; i < GV_MAXL; ++i) {
-    in.Wq[i] = a.Wq[i]; in.scale[i] = a.scale[i]; in.zero[i] = a.zero[i]; in.N[i] = a.N[i]; in.prow_end[i] = a.prow_end[i];
-    out.bias[i] = a.bias[i]; out.y[i] = a.y[i];
-  }
-  in.x = a.x; in.K = a.K; in.gs = a.gs; in.G = a.G; in.total_prow = a.total_prow; in.red_off = 0; in.ksplit = 0;
-#ifdef GV_LAB_TS
-  in.ts = nullptr;
-#endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out);
-  return check_launch("hqq_hip_gemv");
-}
-
 template <int NBITS, int M, bool GS64, bool EXACT, bool BF16 = false, bool SUB = false, int WPG = GV_WAVES>
 static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   constexpr int WG_PER_CU = GV_WG_PER_CU * GV_WAVES / WPG;   // the same 16 waves per CU
-  constexpr bool RING = GV_RING_UNITS > 0 && M == 1 && GS64 && EXACT && !BF16 && (NBITS == 8 || NBITS == 4 || NBITS == 2);
   if constexpr (WPG == GV_WAVES && M == 1 && GS64 && EXACT && !BF16 && (NBITS == 8 || NBITS == 4 || NBITS == 2)) {
     // a single layer with at most one packed row per wave of the wide grid, whose rows span at least one unit per wave: 8 waves x 2 per CU
     if (args.prow_end[0] == args.total_prow && args.total_prow <= num_cus() * 8 && args.total_prow * 2 > num_cus() * 8 && args.K >= GV_UNIT)
@@ -403,17 +122,8 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
   const int nunits = (nsteps + GV_U - 1) / GV_U;
   const size_t xs_bytes = static_cast<size_t>(M) * nsteps * (GV_KSTEP * 2 + 64 * 4);   // x planes + per-chunk sums
   a.red_off = static_cast<int>((xs_bytes + 15) & ~static_cast<size_t>(15));
-  const size_t lds = a.red_off + sizeof(float) * WPG * M * PER;                  // + K-split reduction buffer
-  // few rows x long K share rows between the waves of a workgroup (the ping-pong kernel's K-split); everything else the ring serves
-  if constexpr (RING) {
-    if (!(nunits >= WPG && static_cast<int64_t>(a.total_prow) * 4 <= static_cast<int64_t>(num_cus()) * WG_PER_CU * WPG))
-      return launch_gemv_ring<NBITS, M, SUB, WPG>(args, st);
-  }
-#ifndef GV_WIDE_EARLY_B
-#define GV_WIDE_EARLY_B 0   // lab switch: measured +12 % on a 4096 x 4096 layer, +4 % on 4096 x 11008 (the burst delays the x loads and the barrier, as in grouped launches)
-#endif
+  const size_t lds = a.red_off + sizeof(float) * WPG * M * PER;             // + K-split reduction buffer
   auto kern = gemv_f16_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>;
-  if constexpr (WPG == 8 && GV_WIDE_EARLY_B) kern = gemv_f16_wide_kernel<NBITS, M, GS64, EXACT, BF16, SUB, WPG>;
   // a row of x longer than one pass of the workgroup's threads (the 11008-wide down projection): the variant that requests the first two
   // passes together (4096 x 11008: 8.3 -> 8.0 us; compiled as its own kernel so that the others keep their code, gemv_kernel.inc)
   int variant = 0;   // which compilation of the kernel text this launch uses (per-kernel caches below)
@@ -457,14 +167,7 @@ static int launch_gemv_f16(const GvArgs& args, hipStream_t st) {
     out.bias[i] = a.bias[i]; out.y[i] = a.y[i];
   }
   in.x = a.x; in.K = a.K; in.gs = a.gs; in.G = a.G; in.total_prow = a.total_prow; in.red_off = a.red_off; in.ksplit = a.ksplit;
-#ifdef GV_LAB_TS
-  in.ts = a.ts;
-#endif
-#ifdef GV_LAB_PREFETCH
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, g_lab_pf_base, g_lab_pf_rows, g_lab_pf_row_bytes);
-#else
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out);
-#endif
   return check_launch("hqq_hip_gemv");
 }
 
@@ -528,23 +231,6 @@ size_t skinny_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t
 int skinny_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
                const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, void* ws, size_t ws_bytes,
                hipStream_t st);
-#ifdef HQQ_LAB_KWAVE   // lab (tools/lab_kwave/: 5..64 rows without a K split across workgroups — built, bit-exact, measured slower)
-bool kwave_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const int64_t* N, int n_layers);
-int kwave_run(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero,
-              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, uint32_t opts, hipStream_t st);
-#define HQQ_OPT_BATCH_SPLITK 2048u
-#define HQQ_OPT_ALL_GEMV (HQQ_OPT_ALL | HQQ_OPT_BATCH_SPLITK)
-static bool kw_serves(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
-  if (!N || (opts & HQQ_OPT_BATCH_SPLITK) || (dtype != HQQ_F16 && dtype != HQQ_BF16) || M < 5) return false;
-  if (nbits == 3 && !(opts & HQQ_OPT_W3S)) return false;
-  return kwave_covers(nbits, M, K, group_size, N, n_layers);
-}
-#else
-#define HQQ_OPT_ALL_GEMV HQQ_OPT_ALL
-static bool kw_serves(int, int, const int64_t*, int64_t, int64_t, int64_t, int, uint32_t) { return false; }
-static int kwave_run(int, int, const void*, const void* const*, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
-                     int64_t, int, uint32_t, hipStream_t) { return HQQ_ERR_UNSUPPORTED; }
-#endif
 int gemv_w3s_run(int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
                  void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, hipStream_t st);
 size_t gemv3_workspace_bytes(int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, uint32_t opts);
@@ -595,22 +281,18 @@ __global__ __launch_bounds__(256) void meta_check3_kernel(const half_t* __restri
 }  // namespace hqq
 
 using namespace hqq;
-#ifdef GV_LAB_TS
-extern unsigned long long* g_lab_ts;
-#endif
 
 extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale,
                                     const void* const* zero, const void* const* bias, void* const* y, const int64_t* N,
                                     int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                                     void* stream) {
   clear_stale_error();
-  if (opts & ~HQQ_OPT_ALL_GEMV) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL_GEMV); return HQQ_ERR_SHAPE; }
+  if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemv: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
   if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemv_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
   // 17..64 activation rows: only where the skinny-GEMM kernel (skinny.hip) applies
   if ((opts & HQQ_OPT_W3S) && nbits != 3) { set_error("hqq_hip_gemv: HQQ_OPT_W3S is a 3-bit layout (nbits=%d)", nbits); return HQQ_ERR_SHAPE; }
   const bool w3s = nbits == 3 && (opts & HQQ_OPT_W3S);   // the 3-bit stream layout runs through the 4-bit container's kernels (w3s.h)
-  const bool kw_ok = kw_serves(nbits, n_layers, N, M, K, group_size, dtype, opts);   // (lab builds only)
-  const bool skinny_ok = kw_ok || (N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(w3s ? 4 : nbits, M, K, group_size, N, n_layers));
+  const bool skinny_ok = (N && (dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(w3s ? 4 : nbits, M, K, group_size, N, n_layers));
   if (M < 1 || M > (skinny_ok ? HQQ_GEMV_MAX_M_SKINNY : HQQ_GEMV_MAX_M)) {
     set_error("hqq_hip_gemv: M=%lld outside [1,%d] (up to %d for fp16, 8-/4-/2-bit, group_size 64, K %% 256 == 0)", (long long)M, HQQ_GEMV_MAX_M, HQQ_GEMV_MAX_M_SKINNY);
     return HQQ_ERR_SHAPE;
@@ -628,7 +310,6 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemv: null layer pointer"); return HQQ_ERR_SHAPE; }
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
-    if (kw_ok) return kwave_run(3, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, as_stream(stream));
     return skinny_run(3, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
   }
   if (nbits == 3) {   // int32 containers, ten slabs: its own kernel (gemv3.hip), fp16, exact weights
@@ -672,7 +353,6 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
       if (!aligned16(Wq[i])) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
     }
     if (!aligned16(x)) { set_error("hqq_hip_gemv: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
-    if (kw_ok) return kwave_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, as_stream(stream));
     if (skinny_ok) return skinny_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, dtype, opts, workspace, workspace_bytes, as_stream(stream));
     return gemv_mfma_run(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, as_stream(stream));
   }
@@ -706,9 +386,6 @@ extern "C" int hqq_hip_gemv_grouped(int nbits, int n_layers, const void* x, cons
   a.gs = static_cast<int>(group_size);
   a.G = static_cast<int>(K / group_size);
   a.total_prow = static_cast<int>(total);
-#ifdef GV_LAB_TS
-  a.ts = g_lab_ts;
-#endif
   hipStream_t st = as_stream(stream);
   // x rows beyond the LDS budget of one launch are served by further launches over row blocks of x / y
   for (int64_t m0 = 0; m0 < M; m0 += m_max) {
@@ -731,7 +408,6 @@ extern "C" int hqq_hip_gemv(int nbits, const void* x, const void* Wq, const void
 
 extern "C" size_t hqq_hip_gemv_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
   if (!N || n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || M < 1 || K <= 0 || group_size <= 0) return 0;
-  if (kw_serves(nbits, n_layers, N, M, K, group_size, dtype, opts)) return 0;   // (lab builds only)
   if (nbits == 3 && (opts & HQQ_OPT_W3S)) {
     if (M <= GV_EXACT_ROWWISE_MAX_M) return 0;
     return ((dtype == HQQ_F16 || dtype == HQQ_BF16) && skinny_covers(4, M, K, group_size, N, n_layers)) ? skinny_workspace_bytes(3, n_layers, N, M, K, opts) : 0;

@@ -33,7 +33,6 @@ namespace hqq {
 template <int NBITS, int M, int S, int PER> struct SlabLoop;
 template <int NBITS, int S, int PER> struct GroupConst;
 
-#define GV_KERNEL_EARLY_B 0
 #define GV_KERNEL_ROPE 0
 // ---- RMSNorm prologue (one / two passes of the workgroup over the row) ----
 #define GV_KERNEL_XPASS2 0
@@ -96,7 +95,6 @@ template <int NBITS, int S, int PER> struct GroupConst;
 #undef GV_KERNEL_SILU
 #undef GV_KERNEL_NORM
 #undef GV_KERNEL_ROPE
-#undef GV_KERNEL_EARLY_B
 
 namespace gb {
 
@@ -170,9 +168,6 @@ static int launch(const GvArgs& args, const Extra& ex, hipStream_t st) {
     out.bias[i] = nullptr; out.y[i] = a.y[i];
   }
   in.x = a.x; in.K = a.K; in.gs = a.gs; in.G = a.G; in.total_prow = a.total_prow; in.red_off = a.red_off; in.ksplit = a.ksplit;
-#ifdef GV_LAB_TS
-  in.ts = nullptr;
-#endif
   if constexpr (KIND == 0) {
     if (two_pass) hipLaunchKernelGGL((gb_norm2_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
     else hipLaunchKernelGGL((gb_norm1_kernel<NB, 1, true, true, BF16, SUB, WPG>), dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out, ex.norm_w, ex.eps);
@@ -277,9 +272,6 @@ extern "C" int hqq_hip_gemv_block(int nbits, int n_layers, const void* x, const 
   a.gs = 64;
   a.G = static_cast<int>(K / 64);
   a.total_prow = static_cast<int>(total);
-#ifdef GV_LAB_TS
-  a.ts = nullptr;
-#endif
   const int kind = resid ? 2 : (silu ? 1 : (rope ? 3 : 0));
   const half_t* nw = static_cast<const half_t*>(norm_weight);
   hipStream_t st = as_stream(stream);

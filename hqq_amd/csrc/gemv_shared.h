@@ -1,5 +1,4 @@
-// gemv_shared.h — what the decode launch kernels (gemv.hip: one launch per layer group; gemv_chain.hip: the same launch, overlapped with
-// its predecessor) have in common: launch constants, the kernel-argument layout, the layer pick, the unit a wave keeps in flight.
+// gemv_shared.h — what the decode launch kernels (gemv.hip: one launch per layer group; gemv_w3s.hip / gemv_block.hip: the same text at 3 bits / with the decoder block's glue folded in) have in common: launch constants, the kernel-argument layout, the layer pick, the unit a wave keeps in flight.
 #pragma once
 #include "decode_common.h"
 
@@ -16,11 +15,12 @@ constexpr int GV_KSTEP = 1024;            // k covered by one wave load instruct
 #ifndef GV_U_LOADS
 #define GV_U_LOADS 2
 #endif
-constexpr int GV_U = GV_U_LOADS;          // load instructions per unit
-constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
-#ifndef GV_RING_UNITS
-#define GV_RING_UNITS 0   // > 0: bs = 1 launches use the ring kernel with this many 1-KiB units in flight (lab switch; 0: the ping-pong kernel everywhere — measured faster, see gemv_ring_kernel)
+#ifndef GV_NF_UNITS
+#define GV_NF_UNITS 2
 #endif
+constexpr int GV_U = GV_U_LOADS;          // load instructions per unit
+constexpr int GV_NF = GV_NF_UNITS;        // units a wave keeps in flight (the streaming loop is a ring of GV_NF register sets)
+constexpr int GV_UNIT = GV_KSTEP * GV_U;  // k per unit
 constexpr int GV_MAXL = HQQ_GEMV_MAX_GROUP;
 constexpr int GV_LDS_MAX = 144 * 1024;    // x staging budget per workgroup
 constexpr int GV_EXACT_ROWWISE_MAX_M = 4;  // EXACT mode: 2*per MFMAs per x row and KiB; beyond this the tile kernel (gemv_mfma.hip) takes over
@@ -40,9 +40,6 @@ struct GvArgs {
   int K, gs, G /* K / gs */, total_prow;
   int red_off;  // byte offset of the K-split reduction buffer in LDS
   int ksplit;   // 1: the workgroup's waves share ONE packed row (units interleaved), partial sums meet in LDS — for few-row / long-K layers
-#ifdef GV_LAB_TS
-  unsigned long long* ts;   // lab only: per-wave timestamps
-#endif
 };
 
 // What the kernel receives.  GvIn — everything the streaming loop reads — travels as plain scalar kernel parameters (GV_IN_PARAMS
@@ -59,48 +56,25 @@ struct GvIn {
   int prow_end[GV_MAXL];
   const half_t* x;
   int K, gs, G, total_prow, red_off, ksplit;
-#ifdef GV_LAB_TS
-  unsigned long long* ts;
-#endif
 };
 struct GvOut {
   const half_t* bias[GV_MAXL];
   half_t* y[GV_MAXL];
 };
 static_assert(GV_MAXL == 4, "the scalar parameter list below spells four layers out");
-#ifdef GV_LAB_TS
-#define GV_IN_TS_PARAM , unsigned long long* ts_
-#define GV_IN_TS_PACK , ts_
-#define GV_IN_TS_ARG(in) , (in).ts
-#else
-#define GV_IN_TS_PARAM
-#define GV_IN_TS_PACK
-#define GV_IN_TS_ARG(in)
-#endif
-#ifdef GV_LAB_PRELOAD
-// lab (tools/gemv_lab.hip, built with -mllvm -amdgpu-kernarg-preload-count=16): what a wave of layer 0 needs for its x loads and its first
-// unit's requests leads the parameter list — 14 dwords, as many as the hardware preloads into SGPRs at wave launch — so that those
-// requests do not wait for the scalar loads of the rest
+// what a wave of layer 0 needs for its x loads and its first unit's requests leads the parameter list — 14 dwords, as many as the hardware
+// preloads into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, Makefile) — so that those requests do not wait for the scalar
+// loads of the rest (round 3: -3.9 % per token on the 7B stack)
 #define GV_IN_PARAMS                                                                                                                    \
   const half_t *x_, int K_, int G_, int total_, int pe0, int N0, int ksplit_, const uint8_t *Wq0, const half_t *sc0, const half_t *ze0, \
       int gs_, int red_off_, const uint8_t *Wq1, const uint8_t *Wq2, const uint8_t *Wq3, const half_t *sc1, const half_t *sc2,          \
-      const half_t *sc3, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N1, int N2, int N3, int pe1, int pe2, int pe3 GV_IN_TS_PARAM
+      const half_t *sc3, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N1, int N2, int N3, int pe1, int pe2, int pe3
 #define GV_IN_ARGS(in)                                                                                                                       \
   (in).x, (in).K, (in).G, (in).total_prow, (in).prow_end[0], (in).N[0], (in).ksplit, (in).Wq[0], (in).scale[0], (in).zero[0], (in).gs,        \
       (in).red_off, (in).Wq[1], (in).Wq[2], (in).Wq[3], (in).scale[1], (in).scale[2], (in).scale[3], (in).zero[1], (in).zero[2], (in).zero[3], \
-      (in).N[1], (in).N[2], (in).N[3], (in).prow_end[1], (in).prow_end[2], (in).prow_end[3] GV_IN_TS_ARG(in)
-#else
-#define GV_IN_PARAMS                                                                                                                       \
-  const uint8_t *Wq0, const uint8_t *Wq1, const uint8_t *Wq2, const uint8_t *Wq3, const half_t *sc0, const half_t *sc1, const half_t *sc2, \
-      const half_t *sc3, const half_t *ze0, const half_t *ze1, const half_t *ze2, const half_t *ze3, int N0, int N1, int N2, int N3,       \
-      int pe0, int pe1, int pe2, int pe3, const half_t *x_, int K_, int gs_, int G_, int total_, int red_off_, int ksplit_ GV_IN_TS_PARAM
-#define GV_IN_ARGS(in)                                                                                                                       \
-  (in).Wq[0], (in).Wq[1], (in).Wq[2], (in).Wq[3], (in).scale[0], (in).scale[1], (in).scale[2], (in).scale[3], (in).zero[0], (in).zero[1],    \
-      (in).zero[2], (in).zero[3], (in).N[0], (in).N[1], (in).N[2], (in).N[3], (in).prow_end[0], (in).prow_end[1], (in).prow_end[2],           \
-      (in).prow_end[3], (in).x, (in).K, (in).gs, (in).G, (in).total_prow, (in).red_off, (in).ksplit GV_IN_TS_ARG(in)
-#endif
+      (in).N[1], (in).N[2], (in).N[3], (in).prow_end[1], (in).prow_end[2], (in).prow_end[3]
 #define GV_IN_PACK \
-  GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ GV_IN_TS_PACK }
+  GvIn { {Wq0, Wq1, Wq2, Wq3}, {sc0, sc1, sc2, sc3}, {ze0, ze1, ze2, ze3}, {N0, N1, N2, N3}, {pe0, pe1, pe2, pe3}, x_, K_, gs_, G_, total_, red_off_, ksplit_ }
 
 // gemv_block.hip's rotary epilogue (kernel parameter, read when a row ends): cos / sin [head_dim] of the position, the position itself in device memory
 struct GbRope {
@@ -144,13 +118,20 @@ __device__ __forceinline__ OutCtx select_out(const GvIn& a, const GvOut& o, int 
 #pragma unroll
   for (int i = 1; i < GV_MAXL; ++i) {
     const bool in = prow >= a.prow_end[i - 1];
-    li += in ? 1 : 0;
+    li = pick(in, i, li);   // (scalar selects: a sum of the comparisons was computed on the vector side and read back with v_readfirstlane)
     row0 = pick(in, a.prow_end[i - 1], row0);
     N = pick(in, a.N[i], N);
   }
   return OutCtx{o.bias[li], o.y[li], N, row0};
 }
 
+// (zero, scale) of a group as fetched — two 2-byte loads — as ONE dword z | sc << 16.  Written as the build of a two-element 16-bit vector:
+// the compiler packs that with one v_perm_b32 and does not mask the registers' upper halves first (as it does for `z | sc << 16` on
+// zero-extended values: v_and + v_lshl_or, or v_lshlrev + an SDWA or).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_zs(uint32_t z, uint32_t sc) {
+  return __builtin_bit_cast(uint32_t, u16x2{static_cast<uint16_t>(z), static_cast<uint16_t>(sc)});
+}
 
 // everything a wave has in flight for one unit: GV_U x 16 bytes of packed weights per lane + the unit's meta
 template <int PER, bool GS64>

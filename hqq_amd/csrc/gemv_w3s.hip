@@ -22,7 +22,6 @@ template <int NBITS, int M, int S, int PER> struct SlabExactBF16;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 #define GV_KERNEL_NAME gemv_w3s_kernel
-#define GV_KERNEL_EARLY_B 0
 #define GV_KERNEL_XPASS2 0
 #include "gemv_kernel.inc"
 #undef GV_KERNEL_NAME
@@ -32,7 +31,6 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #include "gemv_kernel.inc"
 #undef GV_KERNEL_NAME
 #undef GV_KERNEL_XPASS2
-#undef GV_KERNEL_EARLY_B
 
 static int w3s_num_cus() {
   static int n_cus = 0;
@@ -97,9 +95,6 @@ static int launch_w3s(const GvArgs& args, hipStream_t st) {
     out.bias[i] = a.bias[i]; out.y[i] = a.y[i];
   }
   in.x = a.x; in.K = a.K; in.gs = a.gs; in.G = a.G; in.total_prow = a.total_prow; in.red_off = a.red_off; in.ksplit = a.ksplit;
-#ifdef GV_LAB_TS
-  in.ts = nullptr;
-#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WPG * 64), lds, st, GV_IN_ARGS(in), out);
   return check_launch("hqq_hip_gemv");
 }
@@ -154,9 +149,6 @@ int gemv_w3s_run(int n_layers, const void* x, const void* const* Wq, const void*
   a.gs = 64;
   a.G = static_cast<int>(K / 64);
   a.total_prow = static_cast<int>(total);
-#ifdef GV_LAB_TS
-  a.ts = nullptr;
-#endif
   const bool sub = (opts & HQQ_OPT_META_SCALABLE) && dtype == HQQ_F16;
   for (int64_t m0 = 0; m0 < M; m0 += m_max) {
     const int mm = static_cast<int>(M - m0 < m_max ? M - m0 : m_max);

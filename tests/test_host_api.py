@@ -249,3 +249,28 @@ def test_fused_decode_step_is_allow_listed_by_model_type():
         assert not llama_fused.arch_supported(transformers.LlamaForCausalLM(transformers.LlamaConfig(**kw, **bad)).half())
     llama.model.layers[0].self_attn.q_norm = torch.nn.Identity()
     assert not llama_fused.arch_supported(llama)
+
+
+@pytest.mark.parametrize("nbits", [4, 2])
+def test_bench_cpu_baseline_restatement_is_the_references_forward(nbits):
+    """bench.py's `cpu_baseline` leg TIMES a torch-eager restatement of HQQBackend.PYTORCH's forward (nothing pinned it).
+    Here it runs on the packed bytes / scale / zero the imported reference wrote for BASELINE.json configs[0] (tests/golden/cfg1_1024_*): the dequantised
+    weight must hash to the reference's, and x @ W.t() must equal the reference's y (its own CPU matmul; fp16 accumulation order is the library's)."""
+    import hashlib
+    import importlib.util
+    import os
+    import numpy as np
+    from conftest import load_golden
+    g = load_golden(f"cfg1_1024_{nbits}b")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    N = K = 1024
+    Wq = torch.from_numpy(g["Wq_packed"])
+    s, z = torch.from_numpy(g["scale_f16"]).reshape(-1, 1), torch.from_numpy(g["zero_f16"]).reshape(-1, 1)
+    eye = torch.eye(K, dtype=torch.float16)
+    Wd = bench.reference_forward_cpu(Wq, s, z, eye, nbits, N, K).t().contiguous()   # one-hot rows pick the dequantised weight out exactly
+    assert hashlib.sha256(Wd.numpy().tobytes()).hexdigest().encode() == g["Wdeq_sha256_f16"].tobytes()
+    x = torch.from_numpy(g["x_f32"]).half()
+    y = bench.reference_forward_cpu(Wq, s, z, x, nbits, N, K)
+    torch.testing.assert_close(y.float(), torch.from_numpy(g["y_f16"]).float().reshape(y.shape), rtol=2e-3, atol=2e-3)
