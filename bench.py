@@ -1052,39 +1052,61 @@ def main():
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
         # one rank's share of the 8-way column-sharded 70B stack (BASELINE.json configs[4]) on THIS GPU alone: the compute side of the scaling
-        # curve DESIGN.md section 6 expects, as a driver-run number.  No exchange, no second GPU: NOT a multi-GPU measurement.
+        # curve DESIGN.md section 6 expects, as a driver-run number.  No exchange, no second GPU: NOT a multi-GPU measurement.  Two plans
+        # (hqq_amd.shard.plan_exchange_groups): every exchange group sharded, and the adaptive plan that REPLICATES groups too small to shard.
         if nbits == 4 and os.environ.get("HQQ_BENCH_SHARD8", "1") != "0":
             try:
+                from hqq_amd import shard as shard_mod
                 torch.cuda.empty_cache()
-                P8, nb70 = 8, N_BLOCKS_70B
-                sblocks = [{name: make_layer(ops, name, N_ // P8, K_, 4, dev, seed=50000 + 16 * b + i, random_codes=True, cd=cd)
-                            for i, (name, N_, K_) in enumerate(LLAMA2_70B_BLOCK)} for b in range(nb70)]
-                full_bytes = {m_: nb70 * sum(gemv_bytes(N_, K_, 4, m_) for _, N_, K_ in LLAMA2_70B_BLOCK) for m_ in (1, 32)}
-                shard_bytes = {m_: nb70 * sum(gemv_bytes(N_ // P8, K_, 4, m_) for _, N_, K_ in LLAMA2_70B_BLOCK) for m_ in (1, 32)}
-                res8 = {}
-                for m_ in (1, 32):
-                    xs8 = {K_: torch.randn(m_, K_, device=dev, generator=gx).to(cd) for K_ in sorted({K_ for _, _, K_ in LLAMA2_70B_BLOCK})}
-                    o8 = {grp: [torch.empty(m_, sblocks[0][n].N, device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+                P8 = 8
 
-                    def step8(xs8=xs8, o8=o8):
-                        for blk in sblocks:
+                def rank_compute(BLK, nb_, plan, m_, seed0):
+                    """one rank's launches of a block list under `plan` (per exchange group: sharded -> N / 8 columns, replicated-small -> the whole layer)"""
+                    whole = {n: pl == "replicated-small" for grp, pl in zip(EXCHANGE_GROUPS, plan) for n in grp}
+                    sb = [{name: make_layer(ops, name, N_ if whole[name] else N_ // P8, K_, 4, dev, seed=seed0 + 16 * b_ + i, random_codes=True, cd=cd)
+                           for i, (name, N_, K_) in enumerate(BLK)} for b_ in range(nb_)]
+                    xs8 = {K_: torch.randn(m_, K_, device=dev, generator=gx).to(cd) for K_ in sorted({K_ for _, _, K_ in BLK})}
+                    o8 = {grp: [torch.empty(m_, sb[0][n].N, device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+
+                    def step8():
+                        for blk in sb:
                             for grp in EXCHANGE_GROUPS:
                                 Ls = [blk[n] for n in grp]
                                 ops.gemv_grouped(xs8[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, 4, outs=o8[grp], opts=group_opts(Ls))
-                    r8, g8 = _graphed(step8, use_graph, rank)
+                    r8, _ = _graphed(step8, use_graph, rank)
                     w8, d8 = _timed(r8, max(5, a.steps // 2), 3)
-                    res8[f"bs={m_}"] = {"ms_per_step": round(w8 * 1e3, 4), "launches_per_step": nb70 * len(EXCHANGE_GROUPS), "avg_launch_us": round(d8 / (nb70 * len(EXCHANGE_GROUPS)) * 1e6, 3),
-                                        "shard_GB_s": round(shard_bytes[m_] / w8 / 1e9, 1), "roofline_frac_of_this_gpu": round(shard_bytes[m_] / d8 / 1e9 / HBM_PEAK_GBS, 4),
-                                        "if_eight_ranks_computed_like_this_and_exchanged_for_free": {
-                                            "tok_s": round(m_ / w8, 1), "whole_stack_GB_s": round(full_bytes[m_] / w8 / 1e9, 1),
-                                            "frac_of_8_gpu_roofline": round(full_bytes[m_] / w8 / 1e9 / (P8 * HBM_PEAK_GBS), 4)}}
-                    del r8
-                out["shard_of_8"] = {"what": "ONE rank's compute of the Llama-2-70B linear stack column-sharded 8 ways (hqq_amd/shard.py: N / 8 output columns of every layer, 80 blocks, int4 gs=64, "
-                                             "random codes), timed on this single GPU: one rank's compute, NO exchange, nothing measured on more than one GPU", **res8,
-                                     "note": "the per-GPU launches of the 8-way shard (q|k|v 10.9 MB, o 4.7, gate|up 33, down 16.5 MB per launch) are smaller than the 7B stack's: every launch pays the same "
-                                             "~4 us of fixed cost on fewer bytes, so the bs = 1 fraction of the node's roofline can only fall with the rank count (DESIGN.md section 6); the exchange comes on top"}
-                del sblocks
-                torch.cuda.empty_cache()
+                    rank_bytes = nb_ * sum(gemv_bytes(N_ if whole[name] else N_ // P8, K_, 4, m_) for name, N_, K_ in BLK)
+                    del r8, sb
+                    torch.cuda.empty_cache()
+                    return w8, d8, rank_bytes
+
+                res8 = {}
+                for tag, BLK, nb_ in (("llama2-70b", LLAMA2_70B_BLOCK, N_BLOCKS_70B), ("llama2-7b", LLAMA2_7B_BLOCK, N_BLOCKS_7B)):
+                    gb = [sum(wq_bytes(N_, K_, 4) for name, N_, K_ in BLK if name in grp) for grp in EXCHANGE_GROUPS]
+                    plans = {"sharded": ["sharded"] * len(EXCHANGE_GROUPS), "adaptive": shard_mod.plan_exchange_groups(gb, P8)}
+                    rows = []
+                    for m_ in (1, 32):
+                        full_bytes = nb_ * sum(gemv_bytes(N_, K_, 4, m_) for _, N_, K_ in BLK)
+                        for pname, plan in plans.items():
+                            if pname == "adaptive" and plan == plans["sharded"]:
+                                rows.append({"bs": m_, "plan": "adaptive", "same_as": "sharded"})
+                                continue
+                            w8, d8, rb = rank_compute(BLK, nb_, plan, m_, 50000)
+                            n_l = nb_ * len(EXCHANGE_GROUPS)
+                            rows.append({"bs": m_, "plan": pname, "groups": dict(zip(["|".join(g_) for g_ in EXCHANGE_GROUPS], plan)),
+                                         "exchange_points_per_block": sum(1 for pl in plan if pl == "sharded"),
+                                         "ms_per_step": round(w8 * 1e3, 4), "launches_per_step": n_l, "avg_launch_us": round(d8 / n_l * 1e6, 3),
+                                         "rank_GB_s": round(rb / w8 / 1e9, 1), "roofline_frac_of_this_gpu": round(rb / d8 / 1e9 / HBM_PEAK_GBS, 4),
+                                         "if_eight_ranks_computed_like_this_and_exchanged_for_free": {
+                                             "tok_s": round(m_ / w8, 1), "frac_of_8_gpu_roofline": round(full_bytes / w8 / 1e9 / (P8 * HBM_PEAK_GBS), 4)}})
+                    res8[tag] = rows
+                out["shard_of_8"] = {"what": "ONE rank's compute of a linear stack column-sharded 8 ways (hqq_amd/shard.py: N / 8 output columns of every sharded layer; int4 gs=64, random codes), "
+                                             "timed on this single GPU: one rank's compute, NO exchange, nothing measured on more than one GPU",
+                                     "replicate_below_bytes": shard_mod.replicate_below_bytes(P8), "stacks": res8,
+                                     "note": "plan 'sharded': every exchange group (q|k|v, o, gate|up, down) column-sharded, 4 exchange points per block.  plan 'adaptive' "
+                                             "(hqq_amd.shard.plan_exchange_groups): a group whose packed bytes are below replicate_below_bytes is held and computed WHOLE by every rank — "
+                                             "more bytes per launch, one exchange point fewer.  The threshold comes from the single-GPU launch model t = 3.8 us + bytes / 7.7 TB/s and an "
+                                             "ASSUMED 4 us per exchange point; the exchange has never run over xGMI (DESIGN.md section 6)"}
             except Exception as e:
                 out["shard_of_8"] = {"error": repr(e)}
         out["legs"] = legs

@@ -232,9 +232,6 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : 1) void gemm_f16_kernel(
 // and 64 MFMAs per K-step — so the two pipes overlap inside each wave without a producer/consumer hand-off.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int RT_WAVES = 8, RT_THREADS = 64 * RT_WAVES;   // token-tile height BM: 256 at 4 bits, 128 at 2 bits (accumulator registers)
-#ifdef GEMM_LAB_TS
-__device__ unsigned long long* g_ws_ts_dev = nullptr;   // lab only
-#endif
 
 template <int NBITS, int S, int PER>
 struct RtSlab {   // A fragments (two k-octets) of slab S from the lane's 16 packed bytes: exact, two fp16 roundings
@@ -329,23 +326,12 @@ __global__ __launch_bounds__(RT_THREADS, 2) void gemm_rt_f16_kernel(
   if (nk > 1) load_x(1);
   __syncthreads();
 
-#ifdef GEMM_LAB_TS
-  unsigned long long t_w = 0, t_d = 0, t_m = 0, t_b = 0;
-#define RT_STAMP(v) { const unsigned long long n_ = __builtin_readcyclecounter(); v += n_ - t_last; t_last = n_; }
-#else
-#define RT_STAMP(v)
-#endif
   auto step = [&](WStage& cur, int kt) {
-#ifdef GEMM_LAB_TS
-    unsigned long long t_last = __builtin_readcyclecounter();
-#endif
     const uint8_t* ldsX = lds + (kt & 1) * XSTAGE;
     if (kt + 1 < nk) write_x(lds + ((kt + 1) & 1) * XSTAGE);       // registers hold x of step kt+1
-    RT_STAMP(t_w)
     h8_t a0[PER], a1[PER];
     RtSlab<NBITS, 0, PER>::run(cur.w, cur.z, cur.s, a0, a1);
     if (kt + 2 < nk) { load_w(cur, kt + 2); load_x(kt + 2); }       // two steps ahead, in flight across the barrier
-    RT_STAMP(t_d)
     // four token tiles at a time: 4*PER independent MFMAs between two MFMAs on the same accumulator (a dependent pair issued
     // back to back stalls for the full MFMA latency)
 #pragma unroll
@@ -365,9 +351,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void gemm_rt_f16_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[s][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[s], b1[j], acc[s][jh + j], 0, 0, 0);
     }
-    RT_STAMP(t_m)
     __syncthreads();   // x stage (kt+1)&1 filled, stage kt&1 drained
-    RT_STAMP(t_b)
   };
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
@@ -375,9 +359,6 @@ __global__ __launch_bounds__(RT_THREADS, 2) void gemm_rt_f16_kernel(
     step(wb, kt + 1);
   }
   if (kt < nk) step(wa, kt);
-#ifdef GEMM_LAB_TS
-  if (lane == 0 && g_ws_ts_dev && blockIdx.x < 64) { unsigned long long* o = g_ws_ts_dev + (blockIdx.x * 8 + wave) * 5; o[0] = t_w; o[1] = t_d; o[2] = t_m; o[3] = t_b; o[4] = nk; }
-#endif
 
   // ---- epilogue: D layout — lane holds packed rows 4c + i (i = 0..3) of the wave's 16, token r of token tile j ----
   const int p_base = nt * PROWS + wave * 16 + c * 4;

@@ -106,9 +106,6 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
   auto stage = [&](int u, int kt) {   // unit u of K tile kt (kt < nk) into buffer kt & 1
     uint8_t* base = lds + (kt & 1) * BUF;
     const bool is_x = (u == 0 || u == 3);
-#ifdef GD_LAB_SKIP_DMA   // lab (wrong results): 1 = no W pieces after the prologue, 2 = no pieces at all — what the memory path costs the loop
-    if (kt >= 2 && (GD_LAB_SKIP_DMA == 2 || !is_x)) return;
-#endif
 #pragma unroll
     for (int p = 0; p < 2; ++p)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(is_x ? rx : rw, (lds_t)(base + dst[u][p]), 16, voff[p], soff[u][p] + kt * (BK * 2), 0, 0);
@@ -121,9 +118,6 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
   const int xrd = (wm * 128 + r) * 128, wrd = XBYTES + (wn * 64 + r) * 128;   // swz(row) = swz(r): tile bases are multiples of 16 rows
   const int ch0 = ((2 * c) ^ swz(r)) << 4, ch1 = ((2 * c + 1) ^ swz(r)) << 4;
   auto read_x = [&](int s, int kt) {
-#ifdef GD_LAB_SKIP_READS   // lab (wrong results): no fragment reads after the first tile
-    if (kt >= 1) return;
-#endif
     const uint8_t* base = lds + (kt & 1) * BUF + xrd;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -132,9 +126,6 @@ __global__ __launch_bounds__(NT, 2) void dense_gemm_kernel(const Args a) {
     }
   };
   auto read_w = [&](int s, int kt) {
-#ifdef GD_LAB_SKIP_READS
-    if (kt >= 1) return;
-#endif
     const uint8_t* base = lds + (kt & 1) * BUF + wrd;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

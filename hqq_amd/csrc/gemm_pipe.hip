@@ -342,13 +342,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
 #pragma unroll
     for (int j = 0; j < HT; ++j) {
       const int row = (part * HT + j) * 16 + r;
-#ifdef GP_LAB_NODSR   // lab switches (tools/r2_lab_pipe.sh): one part of a step compiled out — timing only, wrong results
-      f0[j] = u32x4{0x3C003C00u + static_cast<uint32_t>(row), 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}; f1[j] = f0[j];
-      (void)xs;
-#else
       f0[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c) ^ gd_swz(row)) << 4));
       f1[j] = *reinterpret_cast<const u32x4*>(xs + row * 128 + (((2 * c + 1) ^ gd_swz(row)) << 4));
-#endif
     }
   };
   auto mfma = [&](const u32x4& A, const u32x4& B, f32x4 C) {
@@ -356,14 +351,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, A), __builtin_bit_cast(h8_t, B), C, 0, 0, 0);
   };
   auto mma = [&](int part, const u32x4 (&ca0)[PER], const u32x4 (&ca1)[PER], const u32x4 (&f0)[HT], const u32x4 (&f1)[HT]) {
-#ifdef GP_LAB_NOMFMA
-#pragma unroll
-    for (int j = 0; j < HT; ++j) { acc[0][part * HT + j][0] += __uint_as_float(ca0[0][0] ^ f0[j][0]); acc[PER - 1][part * HT + j][1] += __uint_as_float(ca1[PER - 1][1] ^ f1[j][1]); }
-    return;
-#endif
-#ifdef GP_LAB_PRIO   // lab: priority flips around every MFMA cluster (the guide's T5)
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int s = 0; s < PER; ++s)
 #pragma unroll
@@ -372,14 +359,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     for (int s = 0; s < PER; ++s)
 #pragma unroll
       for (int j = 0; j < HT; ++j) acc[s][part * HT + j] = mfma(ca1[s], f1[j], acc[s][part * HT + j]);
-#ifdef GP_LAB_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
   read_b(0, 0, bA0, bA1);
-#ifdef GP_LAB_PRIOS   // lab: static priority for the younger half of an 8-wave workgroup
-  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   // DMA instructions issued after the ones the next step needs: the groups of the PX - 2 iterations in between
   auto iter = [&](int i, auto parity, u32x4 (&ca0)[PER], u32x4 (&ca1)[PER], u32x4 (&na0)[PER], u32x4 (&na1)[PER]) {
     constexpr int par = decltype(parity)::value;   // i & 1
@@ -392,14 +373,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     }
     // (lgkmcnt(0): this wave's fragment reads have left the LDS before another wave's DMA may overwrite the stage)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_OUT) : "memory");
-#ifndef GP_LAB_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     constexpr bool SPREAD = NW == 8;   // measured: +5 % with two waves per SIMD, -3..9 % with one (there the earlier issue matters more)
     auto issue_all = [&]() {
-#ifdef GP_LAB_NODMA
-      return;
-#endif
       issue_w(i + GD_PW);
       if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
       issue_x(i + GD_PX);
@@ -410,9 +386,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     const u32x4 raw = read_w(i + 1);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SPREAD) issue_all();   // the DMA issue (60-185 cycles a piece in a burst) goes UNDER the last part's MFMAs, like the rebuild's VALU work
-#ifndef GP_LAB_NOVALU
     rebuild(raw, i + 1, na0, na1);
-#endif
     mma(NQ - 1, ca0, ca1, bB0, bB1);
     if constexpr (SPREAD) {
       constexpr int NMF = PER * HT * 2, NDMA = 1 + XP + MD::NI;
@@ -424,76 +398,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
       }
     }
   };
-  // Lab: staggered half (8 waves x 256 tokens; waves 4-7 = the second wave of each SIMD): the same work between the same barriers in another
-  // order, so that the part heavy in VALU / LDS / DMA issue (the rebuild) never coincides on a SIMD — one wave's pure-MFMA parts run beside
-  // the other's rebuild.  In lockstep the two waves contend for the matrix pipe in the MFMA parts and leave it idle in the rebuild part:
-  // time ~ MFMA + the rest (tools/r3_lab_pipe8k.sh: 273 us with, 181 us without the MFMAs, ~110 us of MFMA work alone).
-  //   first half   | b_i | DMA, reads(i+1, 0), REBUILD(i+1) + P3(i) | P0(i+1) | P1(i+1) | P2(i+1)            | b_i+1 |
-  //   second half  | b_i | DMA + P1(i)                              | P2(i)   | reads(i+1, 0), REBUILD(i+1) + P3(i) | P0(i+1) | b_i+1 |
-  // Hazards: what a wave reads after b_i (x, weights, constants of step i + 1) landed before b_i for both halves; what the DMA issued
-  // after b_i overwrites (x stage of step i - 1, weights of step i - 1) was last read before b_i by both (the second half reads x(i - 1)
-  // up to P3(i - 1), in front of b_i).
-  // Measured (profiles/r03_pipe8k_ablation.txt): 5 % SLOWER than lockstep (291 vs 278 us at 4096 x 4096 x 8192 rows, bit-identical) — the
-  // matrix pipe is not what the two waves of a SIMD contend for.  Kept as a lab switch.
-#ifdef GP_LAB_STAGGER
-  constexpr bool STAGGER = NW == 8 && NQ == 4 && GD_PX == 2;
-#else
-  constexpr bool STAGGER = false;
-#endif
-  auto iter_b = [&](int i, auto parity, u32x4 (&ca0)[PER], u32x4 (&ca1)[PER], u32x4 (&na0)[PER], u32x4 (&na1)[PER]) {
-    constexpr int par = decltype(parity)::value;
-    constexpr int NMF = PER * HT * 2, NDMA = 1 + XP + MD::NI;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_b(i, 2, bA0, bA1);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_w(i + GD_PW);
-    if constexpr (((par + GD_PW) & 1) == 0) issue_m(i + GD_PW);
-    issue_x(i + GD_PX);
-    mma(1, ca0, ca1, bB0, bB1);
-#pragma unroll
-    for (int t = 0; t < NMF; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (t * NDMA / NMF != (t + 1) * NDMA / NMF) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(i, 3, bB0, bB1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(2, ca0, ca1, bA0, bA1);
-    __builtin_amdgcn_sched_barrier(0);
-    read_b(i + 1, 0, bA0, bA1);
-    if constexpr (par == 1) fetch_meta(i + 1);
-    const u32x4 raw = read_w(i + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    rebuild(raw, i + 1, na0, na1);
-    mma(3, ca0, ca1, bB0, bB1);
-#pragma unroll
-    for (int t = 0; t < NMF; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, (100 + NMF - 1) / NMF, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < nsteps) {
-      read_b(i + 1, 1, bB0, bB1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0, na0, na1, bA0, bA1);
-    }
-  };
-  if (STAGGER && wave >= 4) {
-    if constexpr (STAGGER) {
-      read_b(0, 1, bB0, bB1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0, a0[0], a1[0], bA0, bA1);
-      for (int i = 0; i < nsteps; i += 2) {
-        iter_b(i, std::integral_constant<int, 0>{}, a0[0], a1[0], a0[1], a1[1]);
-        if (i + 1 < nsteps) iter_b(i + 1, std::integral_constant<int, 1>{}, a0[1], a1[1], a0[0], a1[0]);
-      }
-    }
-  } else {
-    for (int i = 0; i < nsteps; i += 2) {
-      iter(i, std::integral_constant<int, 0>{}, a0[0], a1[0], a0[1], a1[1]);
-      if (i + 1 < nsteps) iter(i + 1, std::integral_constant<int, 1>{}, a0[1], a1[1], a0[0], a1[0]);
-    }
+  // (A staggered order for the second wave of each SIMD — its pure-MFMA parts beside the other's rebuild — was built and measured 5 % SLOWER than
+  //  lockstep, bit-identical: profiles/r03_pipe8k_ablation.txt.  The matrix pipe is not what the two waves of a SIMD contend for.)
+  for (int i = 0; i < nsteps; i += 2) {
+    iter(i, std::integral_constant<int, 0>{}, a0[0], a1[0], a0[1], a1[1]);
+    if (i + 1 < nsteps) iter(i + 1, std::integral_constant<int, 1>{}, a0[1], a1[1], a0[0], a1[0]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the clamped DMAs past the last step: nothing may land in LDS after the workgroup is gone)
 

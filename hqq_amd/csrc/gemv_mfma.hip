@@ -140,8 +140,10 @@ struct GmUnit {
   uint16_t sc[GS64 ? PER : GM_UB * PER];
 };
 
+// (a workgroup is KS <= min(32 / PER, 16) waves — gm_launch — so the 2- and 1-bit instantiations, whose four / eight slabs of accumulators do not fit
+//  the 128 registers a 1024-thread bound leaves, declare what they are launched with: no scratch; until round 6 they spilled 22 / 239 registers)
 template <int NBITS, bool GS64>
-__global__ __launch_bounds__(1024) void gemv_mfma_f16_kernel(const GmArgs a) {
+__global__ __launch_bounds__(NBITS == 2 ? 512 : (NBITS == 1 ? 256 : 1024)) void gemv_mfma_f16_kernel(const GmArgs a) {
   constexpr int PER = 8 / NBITS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 

@@ -42,11 +42,7 @@ __device__ __forceinline__ float sgnf(float e) { return static_cast<float>((e > 
 
 // |e|^(p-1) evaluated in double and rounded once to float (ATen's Sleef powf is <= 1 ulp; this matched it on every fixture)
 __device__ __forceinline__ float pow_lp(float a, double pexp) {
-#ifdef SOLVE_LAB_NOPOW
-  return a * static_cast<float>(pexp);   // lab: timing without the transcendental (wrong numerics)
-#else
   return static_cast<float>(pow(static_cast<double>(a), pexp));   // a = 0 -> +inf
-#endif
 }
 
 

@@ -46,9 +46,6 @@
 #include "w3s.h"
 #include <stdlib.h>
 
-#ifdef SK_LAB_TS
-extern unsigned long long* g_sk_lab_ts;
-#endif
 // This file is compiled twice (Makefile): the WIDE tile — 64-packed-row panels, four row groups x two block halves — and, with -DSK_NARROW,
 // the NARROW one — 32-row panels, two row groups x four blocks — for 4- / 2-bit launches of at most 2048 packed rows (one 4096-row int4 layer: o, down),
 // where the wide tile has 32 panels and must cut K eight ways to fill the chip.  Measured (profiles/r03_skinny_tiles_ks.txt, us per launch,
@@ -112,9 +109,6 @@ struct SkArgs {
   float* part;              // [KS][panel][row group][PER][MT][4][64 lanes] fp32 partial tiles in accumulator order (KS > 1 only)
   int* cnt;                 // [panel][row group] arrival counters of the K splits, zero between launches (KS > 1 only)
   int M, K, G, total_panels, KS, cps, n_total;
-#ifdef SK_LAB_TS
-  unsigned long long* ts;   // lab only: per-wave timestamps
-#endif
 };
 
 struct SkLayer {   // workgroup-uniform -> SGPRs
@@ -311,16 +305,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   uint32_t* mz = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(2) * XS_BUF * sizeof(u32x4));   // [64 rows][PER][mstride] (zero | scale << 16)
   constexpr int XP = (MT * 8 + SK_WAVES - 1) / SK_WAVES;   // 16-byte pieces of x per thread and chunk (8 MT fragments of 64 lanes / waves)
 
-#ifdef SK_LAB_TS
-  unsigned long long t_[8] = {};
-  int tsn = 0;
-#define SK_TS() do { if (tsn < 8) t_[tsn++] = __builtin_amdgcn_s_memrealtime(); } while (0)   /* 100 MHz, one clock for the whole device */
-#define SK_TS_FLUSH() do { t_[7] = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && a.ts) { const int w_ = ((blockIdx.z * gridDim.y + blockIdx.y) * 8 + blockIdx.x) * SK_WAVES + (threadIdx.x >> 6); for (int q = 0; q < 8; ++q) a.ts[w_ * 8 + q] = t_[q]; } } while (0)
-#else
-#define SK_TS()
-#define SK_TS_FLUSH()
-#endif
-  SK_TS();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, c = lane >> 4;
@@ -362,7 +346,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     pl = pl < rows_per_slab ? pl : rows_per_slab - 1;
     wline[u] = ly.Wq + static_cast<int64_t>(pl) * K + ((lane >> 3) & 1) * 64 + c * 16;
   }
-  SK_TS();   // 1: kernel arguments read, layer selected
 
   // x: the 256 threads fill the chunk's 8 MT fragments in LDS order — piece q = tid + 256 i is lane (q & 63) of fragment
   // f = q >> 6 = (m-tile t, block j, half h), i.e. the k-octet 64 j + 16 c + 8 h of activation row 16 t + r.  Rows >= M repeat
@@ -382,11 +365,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       f = f < 8 * MT ? f : 8 * MT - 1;   // (8 MT not a multiple of the wave count: the spare pieces repeat the last fragment)
       const int t = f >> 3, j = (f & 7) >> 1, h = f & 1;
       const int m = 16 * t + r;
-#ifdef SK_LAB_NOX      // lab: no x loads
-      xr[set][i] = u32x4{0x3C003C00u + static_cast<uint32_t>(m + chunk + j + h), 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-#else
       xr[set][i] = *reinterpret_cast<const u32x4*>(a.x + static_cast<int64_t>(m < M ? m : 0) * K + chunk * SK_KC + 64 * j + 16 * c + 8 * h);
-#endif
     }
   };
   auto xstore = [&](int buf, int set) {
@@ -447,18 +426,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         b0[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 0) * 64 + lane]);
         b1[t] = __builtin_bit_cast(frag_t, xs[buf * XS_BUF + ((t * SK_BLK + j) * 2 + 1) * 64 + lane]);
       }
-#ifdef SK_LAB_NOARITH   // lab (tools/r5_bs32_probe.sh: the floor of this launch shape): every loaded / staged register is touched, nothing is rebuilt or contracted
-      {
-        float f = __uint_as_float((cur.w[jl].x ^ cur.w[jl].y ^ cur.w[jl].z ^ cur.w[jl].w ^ zs[0] ^ zs[PER - 1]) & 0x3F800000u);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          const u32x4 u0 = __builtin_bit_cast(u32x4, b0[t]), u1 = __builtin_bit_cast(u32x4, b1[t]);
-          f += __uint_as_float((u0.x ^ u0.y ^ u0.z ^ u0.w ^ u1.x ^ u1.y ^ u1.z ^ u1.w) & 0x3F800000u);
-          acc[0][t][0] += f;
-        }
-        continue;
-      }
-#endif
       if constexpr (W3) SkSlabW3s<MT, BF16, SUB>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else if constexpr (BF16) SkSlabBF16<NBITS, MT, 0, PER>::run(cur.w[jl], zs, b0, b1, acc, magic);
       else
@@ -488,20 +455,14 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       int pm = (panel - ly.panel0) * SK_ROWS + row;
       pm = pm < rows_per_slab ? pm : rows_per_slab - 1;
       const half_t* src = (hi ? ly.scale : ly.zero) + static_cast<int64_t>(pm + s * rows_per_slab) * G + (c0 + (cc < c1 - c0 ? cc : 0)) * SK_BLK;
-#ifdef SK_LAB_NOMETA   // lab (tools/r2_lab_skinny.sh): no group-constant loads — timing only, wrong results
-      mv[rd][pass] = u32x2{0x3C003C00u + static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 0u), 0x3C003C00u};
-#else
       mv[rd][pass] = *reinterpret_cast<const u32x2*>(src);
-#endif
     }
-  SK_TS();   // 2: group constants requested
   xload(c0, 0);
   issue(un[0], c0);
   xload(c0 + 1, 1);
 #pragma unroll
   for (int k = 1; k < SK_RING; ++k) issue(un[k], c0 + k);
   __builtin_amdgcn_sched_barrier(0);
-  SK_TS();   // 3: x + both units requested
 #pragma unroll
   for (int rd = 0; rd < NROUND; ++rd)
 #pragma unroll
@@ -524,7 +485,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         dst[6] = static_cast<uint16_t>(v.y >> 16);
       }
     }
-  SK_TS();   // 4: group constants in LDS
   xstore(0, 0);
   __syncthreads();
 
@@ -551,7 +511,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       xstore((k + 1) & 1, (k + 1) & 1);   // x of chunk i + k + 1, requested one half-iteration ago
       __syncthreads();
-      SK_TS();   // 5, 6: a half-iteration done
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -567,7 +526,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         for (int t = 0; t < MT; ++t) red[((((hf - 1) * SK_RG + rg) * PER + s) * MT + t) * 64 + lane] = acc[s][t];
     }
     __syncthreads();
-    if (hf > 0) { SK_TS_FLUSH(); return; }
+    if (hf > 0) return;
 #pragma unroll
     for (int h = 1; h < SK_SPLIT; ++h)
 #pragma unroll
@@ -582,12 +541,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   //      instruction), the LAST split of the row group to arrive — a ticket from an atomic counter, no waiting — adds all KS tiles
   //      in split order and goes on to the store below.  Fixed order, so the bits do not depend on which split finished last;
   //      no second launch (the finishing kernel this replaces cost one graph-node gap + ~1 us per call). ----
-#ifdef SK_LAB_NOFIN    // lab: no partial tiles, no ticket
-  if (a.KS > 1 && ks != 0) { SK_TS_FLUSH(); return; }
-  if (false) {
-#else
   if (a.KS > 1) {
-#endif
     constexpr int TILE = PER * MT * 4 * 64;   // floats per (split, panel, row group)
     const int64_t slot = static_cast<int64_t>(panel) * SK_RG + rg;
     const int64_t kstride = static_cast<int64_t>(a.total_panels) * SK_RG * TILE;
@@ -605,7 +559,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
     int ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(a.cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != a.KS - 1) { SK_TS_FLUSH(); return; }
+    if (ticket != a.KS - 1) return;
     const float* all = a.part + slot * TILE + lane;
 #pragma unroll
     for (int s = 0; s < PER; ++s)
@@ -661,7 +615,6 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
         }
       }
     }
-  SK_TS_FLUSH();   // (lab builds only)
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -711,9 +664,6 @@ static int sk_launch(SkArgs& a, uint32_t opts, void* ws, size_t ws_bytes, hipStr
   sk_choose(a.total_panels, nchunks, static_cast<int>(opts >> 24), ks, cps);
   a.KS = ks;
   a.cps = cps;
-#ifdef SK_LAB_TS
-  a.ts = g_sk_lab_ts;
-#endif
   a.part = nullptr;
   if (ks > 1) {
     if (static_cast<size_t>(a.total_panels) * SK_RG * sizeof(int) > SK_CNT_BYTES) { set_error("hqq_hip_gemv: too many row panels for the split-K counters"); return HQQ_ERR_UNSUPPORTED; }

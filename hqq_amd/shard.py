@@ -82,22 +82,54 @@ def gather_columns(y_loc: Tensor, out_full: Tensor, N: int, nbits: int, group=No
     return out_full
 
 
+# ---- which exchange points are worth sharding (round 6) ------------------------------------------------------------------------------------
+# One rank's launch costs t ~ T0 + bytes / B with T0 ~ 3.8 us and B ~ 7.7 TB/s on an MI355X (profiles/r06_per_launch.txt): sharding a layer P ways
+# takes bytes (1 - 1 / P) / B off the launch and adds one exchange point (a latency-bound all-gather of a few KiB, or the peer-store kernel: >= ~4 us).
+# Below  bytes (1 - 1 / P) / B  <  exchange cost  the shard LOSES before anything else is counted — `bench.py`'s `shard_of_8` leg measures one rank
+# of the 8-way 70B shard at 0.29 of its GPU's roofline against 0.60-0.63 for the unsharded stack.  So an exchange group (layers consumed together:
+# q|k|v, o, gate|up, down) whose layers are ALL small is REPLICATED: every rank holds and computes it whole, and it has no exchange point.
+# The threshold is on the group's packed bytes; nothing here has been measured over xGMI — the constant comes from the single-GPU launch model and
+# is the first thing `tools/node_first_run.sh` should calibrate.
+EXCHANGE_COST_US = 4.0          # assumed cost of one bs = 1 exchange point (unmeasured over xGMI)
+STREAM_TB_S = 7.7               # marginal streaming rate of a decode launch on one MI355X
+
+
+def replicate_below_bytes(world: int) -> int:
+    """packed bytes of an exchange group below which replicating it beats sharding it `world` ways (launch model above)"""
+    if world <= 1:
+        return 0
+    return int(EXCHANGE_COST_US * 1e-6 * STREAM_TB_S * 1e12 / (1.0 - 1.0 / world))
+
+
+def plan_exchange_groups(group_bytes, world: int, threshold: int | None = None):
+    """group_bytes: packed weight bytes of each exchange group of a block (whole layers, summed over the group) -> one of
+    "sharded" / "replicated-small" per group.  Pure arithmetic: every rank derives the same plan."""
+    thr = replicate_below_bytes(world) if threshold is None else threshold
+    return ["replicated-small" if (world > 1 and b < thr) else "sharded" for b in group_bytes]
+
+
 class ShardedHQQForward:
     """One rank's share of a column-sharded layer.  forward(x) = local fused forward + one all-gather over the process
     group (RCCL on GPUs; any torch.distributed backend works, the CPU tests use gloo with a stand-in local op)."""
 
-    def __init__(self, W_q, scale, zero, bias, N, K, group_size, nbits, group=None, local_forward=None, peer=None):
+    def __init__(self, W_q, scale, zero, bias, N, K, group_size, nbits, group=None, local_forward=None, peer=None, replicate: bool = False):
         """peer: (PeerExchange, point) — at one activation row the outputs are then exchanged by that object's kernel (peer-memory stores,
-        csrc/exchange.hip) instead of a collective; the returned row is the exchange's buffer, valid until the point is used again"""
+        csrc/exchange.hip) instead of a collective; the returned row is the exchange's buffer, valid until the point is used again.
+        replicate: the plan (plan_exchange_groups) found this layer's exchange group too small to shard: the rank keeps the WHOLE layer and
+        forward() is the local forward — no slice, no collective, the same result on every rank."""
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.peer = peer
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.N, self.K, self.gs, self.nbits = N, K, group_size, nbits
-        self.Wq, self.scale, self.zero, self.bias, self.n_loc = shard_packed(W_q, scale, zero, bias, N, K, group_size, nbits, self.rank, self.world)
+        self.replicated = bool(replicate)
+        if self.replicated:
+            self.Wq, self.scale, self.zero, self.bias, self.n_loc = W_q, scale, zero, bias, N
+        else:
+            self.Wq, self.scale, self.zero, self.bias, self.n_loc = shard_packed(W_q, scale, zero, bias, N, K, group_size, nbits, self.rank, self.world)
         self.opts = 0
-        if local_forward is None and nbits == 3 and self.Wq.is_cuda and ops.w3s_covers(self.n_loc, K, group_size):
+        if local_forward is None and nbits == 3 and not self.replicated and self.Wq.is_cuda and ops.w3s_covers(self.n_loc, K, group_size):
             # a 3-bit shard is re-packed anyway (the reference container mixes unrelated rows): keep it in the 3-bit STREAM layout (csrc/w3s.h), which
             # runs through the 4-bit container's kernels — one launch per stage instead of two (0.38 instead of 0.16 of the HBM roofline on the 7B stack)
             self.Wq = ops.w3s_pack(self.Wq, self.n_loc, K)
@@ -136,6 +168,8 @@ class ShardedHQQForward:
         out[c0:c0 + mc] = unpermute(buf.view(self.world, mc, self.n_loc), self.N, self.nbits, self.world)
 
     def forward(self, x: Tensor) -> Tensor:
+        if self.replicated:   # the whole layer on every rank: nothing to exchange
+            return self._local(x).reshape(*x.shape[:-1], self.N)
         rows_in = x.numel() // self.K
         if self.OVERLAP_ROWS and rows_in >= 2 * self.OVERLAP_ROWS and self.world > 1:
             return self._forward_chunked(x.reshape(-1, self.K), self.OVERLAP_ROWS).reshape(*x.shape[:-1], self.N)

@@ -93,6 +93,16 @@ def _worker(rank, world, port, nbits, q):
         ok = ok and tuple(yl.shape) == (23, N) and torch.allclose(yl, xl @ Wfull.t() + bias, atol=1e-5)
         yl3 = sh(xl.reshape(1, 23, K))
         ok = ok and tuple(yl3.shape) == (1, 23, N) and torch.equal(yl3[0], yl)
+        # a layer the plan replicates (exchange group too small to shard): every rank computes it whole, no collective is issued
+        rep = shard.ShardedHQQForward(Wq, scale, zero, bias, N, K, gs, nbits, local_forward=lambda xx: xx @ Wfull.t() + bias, replicate=True)
+        calls = []
+        orig = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
+        try:
+            yr = rep(x)
+        finally:
+            dist.all_gather_into_tensor = orig
+        ok = ok and not calls and rep.n_loc == N and torch.allclose(yr, x @ Wfull.t() + bias, atol=1e-5)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -161,3 +171,18 @@ def test_peer_exchange_host_logic_without_a_gpu():
     grp[0]._last = 1                                 # (as after an enqueued exchange of point 1)
     with pytest.raises(RuntimeError, match="alternate between at least two points"):
         grp[0].run(1, [torch.zeros(1, 256, dtype=torch.bfloat16)])
+
+
+def test_exchange_plan_replicates_small_groups_only():
+    """plan_exchange_groups: pure arithmetic on (packed bytes per exchange group, world) — the same plan on every rank; one rank has nothing to plan;
+    at 8 ranks the 7B block's q|k|v / o / down fall under the launch-model threshold (35 MB) and gate|up does not; of the 70B block only o (33.5 MB, the
+    borderline case: 3.8 us more streaming against one exchange) does"""
+    b7 = [3 * 4096 * 4096 // 2, 4096 * 4096 // 2, 2 * 11008 * 4096 // 2, 4096 * 11008 // 2]
+    b70 = [(8192 + 2 * 1024) * 8192 // 2, 8192 * 8192 // 2, 2 * 28672 * 8192 // 2, 8192 * 28672 // 2]
+    assert shard.plan_exchange_groups(b7, 1) == ["sharded"] * 4
+    assert shard.plan_exchange_groups(b7, 8) == ["replicated-small", "replicated-small", "sharded", "replicated-small"]
+    assert shard.plan_exchange_groups(b70, 8) == ["sharded", "replicated-small", "sharded", "sharded"]
+    assert shard.plan_exchange_groups(b70, 8, threshold=0) == ["sharded"] * 4
+    assert shard.plan_exchange_groups(b70, 8, threshold=1 << 40) == ["replicated-small"] * 4
+    thr2, thr8 = shard.replicate_below_bytes(2), shard.replicate_below_bytes(8)
+    assert thr2 > thr8 > 0 and shard.replicate_below_bytes(1) == 0   # the fewer ranks, the less a shard takes off a launch
