@@ -836,6 +836,20 @@ def main():
                     leg(nm, lambda f=fused: stack128(f), nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * len(BLOCK), kern)
                     legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
                     legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+                # the same rows, the layers as they are, one GROUPED launch per q|k|v / o / gate|up / down (hqq_hip_gemm_grouped, round 6: the route a patched model
+                # takes through backends.hip.group_llama_projections): 4 launches + 4 split-K reduces per block instead of 7 + 7, no second copy of any layer
+                y128g = {grp: [torch.empty(128, dimN[n], device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
+
+                def stack128_grouped():
+                    for blk in blocks:
+                        for grp in EXCHANGE_GROUPS:
+                            Ls = [blk[n] for n in grp]
+                            ops.gemm_grouped(xs128[Ls[0].K], [(L.Wq, L.scale, L.zero, None, L.N) for L in Ls], Ls[0].K, 64, nbits, outs=y128g[grp], opts=group_opts(Ls))
+                leg("7b-stack bs=128, fused dequant-GEMM, q|k|v and gate|up as GROUPED launches (hqq_hip_gemm_grouped: 4 launches + 4 reduces per block, the layers' own tensors)",
+                    stack128_grouped, nblocks * sum(gemv_bytes(N, K, nbits, 128) for _, N, K in BLOCK), 128, nblocks * len(EXCHANGE_GROUPS), "hqq::gemm_pipe_f16_kernel")
+                legs[-1]["tflops"] = round(flops128 / (legs[-1]["ms_per_step"] * 1e-3) / 1e12, 1)
+                legs[-1]["mfma_frac"] = round(legs[-1]["tflops"] / MFMA_PEAK_TFLOPS, 4)
+                del y128g
                 # the same rows with q|k|v and gate|up held as ONE layer each (HQQLinear.merge / ops.merge_layers: the layers' own levels and constants,
                 # stacked and packed again): 4 launches per block instead of 7
                 if nbits == 4 and not (blocks[0]["q"].opts & ops.OPT_W3S):

@@ -42,6 +42,9 @@ SYMBOLS = {
     "hqq_hip_gemv_block": (_i32, [_i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _u32, _u32, _vp, _vp]),
     "hqq_hip_exchange": (_i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u32, _vp]),
     "hqq_hip_gemm": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
+    "hqq_hip_gemm_grouped_covers": (_i32, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
+    "hqq_hip_gemm_grouped_workspace_bytes": (_sz, [_i32, _i32, _vp, _i64, _i64, _i64, _i32, _u32]),
+    "hqq_hip_gemm_grouped": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _u32, _vp, _sz, _vp]),
     "hqq_hip_gemm_dense": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "hqq_hip_forward_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
     "hqq_hip_gemm_workspace_bytes": (_sz, [_i32, _i64, _i64, _i64, _i64, _i32, _u32]),
@@ -57,7 +60,7 @@ SYMBOLS = {
     "hqq_hip_quantize_tensor": (_i32, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -145,12 +145,18 @@ class _GroupedMember(nn.Module):
                 g.x = None   # every sibling served: do not keep the activation alive
             return out
         rows = x.numel() // x.shape[-1]
-        if rows > g.max_rows or x.dtype != torch.float16:
+        if x.dtype != torch.float16:
             return self.layer(x)
         layers = [m.layer for m in g.members]
-        outs = ops.gemv_grouped(x, [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers], self.in_features,
-                                layers[0].group_size, layers[0].nbits,
-                                opts=ops.layer_opts(g.opts))
+        specs = [(L.W_q, L.scale, L.zero, L.bias, L.out_features) for L in layers]
+        if rows <= g.max_rows:
+            outs = ops.gemv_grouped(x, specs, self.in_features, layers[0].group_size, layers[0].nbits, opts=ops.layer_opts(g.opts))
+        elif g.gemm_rows and rows <= g.gemm_rows and ops.gemm_grouped_covers(x.dtype, [L.out_features for L in layers], rows, self.in_features, layers[0].group_size,
+                                                                             layers[0].nbits, ops.layer_opts(g.opts)):
+            # batched decode / speculative verification / short prompts: the group through ONE launch of the pipelined fused GEMM (round 6)
+            outs = ops.gemm_grouped(x, specs, self.in_features, layers[0].group_size, layers[0].nbits, opts=ops.layer_opts(g.opts))
+        else:
+            return self.layer(x)
         g.x, g.version, g.outs = x, ver, list(outs)
         out, g.outs[self._index] = g.outs[self._index], None
         return out
@@ -159,6 +165,7 @@ class _GroupedMember(nn.Module):
 class _GroupState:
     def __init__(self):
         self.members, self.x, self.version, self.outs, self.max_rows, self.opts = [], None, -1, [], 4, 0
+        self.gemm_rows = 0   # > 0: batches up to this many rows take the grouped fused GEMM (hqq_hip_gemm_grouped); beyond, every layer its own route
 
 
 def group_projections(parent: nn.Module, names) -> bool:
@@ -182,6 +189,9 @@ def group_projections(parent: nn.Module, names) -> bool:
     if all(ops.skinny_covers(torch.float16, ops.SKINNY_MAX_M, L.out_features, L.in_features, L.group_size, L.nbits, L.w3s) for L in layers):
         state.max_rows = ops.SKINNY_MAX_M   # decode with a batch: still one weight-streaming launch for the group
     state.opts = (ops.OPT_META_SCALABLE if all(L.opts & ops.OPT_META_SCALABLE for L in layers) else 0) | (ops.OPT_W3S if L0.w3s else 0)
+    # up to the row count where ops.forward itself leaves the fused GEMM for dequantise + dense GEMM (hqq_hip_forward_prefers_fused: 2560)
+    if ops.gemm_grouped_covers(torch.float16, [L.out_features for L in layers], 128, L0.in_features, L0.group_size, L0.nbits, state.opts):
+        state.gemm_rows = ops.FUSED_GEMM_MAX_M
     for i, (n, L) in enumerate(zip(names, layers)):
         m = _GroupedMember(L, state, i)
         state.members.append(m)

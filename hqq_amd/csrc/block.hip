@@ -392,11 +392,18 @@ __global__ __launch_bounds__(1024) void argmax_advance_kernel(const uint16_t* __
   __shared__ float bv[1024];
   __shared__ int bi[1024];
   const int tid = static_cast<int>(threadIdx.x);
+  // torch.argmax's order: a NaN is the maximum (the FIRST NaN wins), otherwise the greatest value, the earliest index on a tie
+  auto better = [](float v, int i, float bvv, int bii) {
+    if (bii == 0x7fffffff) return true;
+    if (v != v) return !(bvv != bvv) || i < bii;
+    if (bvv != bvv) return false;
+    return v > bvv || (v == bvv && i < bii);
+  };
   float best = -INFINITY;
   int idx = 0x7fffffff;
   for (int i = tid; i < n; i += 1024) {
     const float v = E::f(logits[i]);
-    if (v > best || idx == 0x7fffffff) { best = v; idx = i; }   // (strictly greater: the earlier index of a thread's share stays on a tie)
+    if (better(v, i, best, idx)) { best = v; idx = i; }
   }
   bv[tid] = best; bi[tid] = idx;
   __syncthreads();
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(1024) void argmax_advance_kernel(const uint16_t* __
     if (tid < s_) {
       const float v = bv[tid + s_];
       const int j = bi[tid + s_];
-      if (v > bv[tid] || (v == bv[tid] && j < bi[tid])) { bv[tid] = v; bi[tid] = j; }
+      if (j != 0x7fffffff && better(v, j, bv[tid], bi[tid])) { bv[tid] = v; bi[tid] = j; }
     }
     __syncthreads();
   }

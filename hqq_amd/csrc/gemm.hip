@@ -430,6 +430,9 @@ bool skinny_covers(int nbits, int64_t M, int64_t K, int64_t group_size, const in
 void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]);
 int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
                   int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t gemm_pipe_workspace_bytes_grouped(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts);
+int gemm_pipe_run_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
+                          void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // which fused GEMM serves a call: the pipelined kernel (gemm_pipe.hip) wherever it applies — it is ahead of the output-tile kernels
 // below at every M (0.8-1.14 PFLOP/s against 0.5-0.84 from 2048 rows on, 2-4x below 512) —, the output-tile kernels for the group sizes
@@ -508,6 +511,44 @@ int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, co
   const bool big = static_cast<int64_t>((M + 255) / 256) * ((N + GB_N - 1) / GB_N) >= 1536;   // >= 3 full waves of 256-token tiles
   if (nbits == 4) return big ? launch_gemm_f16<4, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_f16<4, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
   return big ? launch_gemm_f16<2, 256>(x, Wq, scale, zero, bias, y, m, n, k, gs, st) : launch_gemm_f16<2, 128>(x, Wq, scale, zero, bias, y, m, n, k, gs, st);
+}
+
+// A group of layers that read the same x (q | k | v, gate | up) through ONE launch of the pipelined fused GEMM (+ one split-K reduce): ABI 8
+static bool group_on_pipe(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  if (!N || n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP || M < 1 || K <= 0 || group_size <= 0) return false;
+  for (int i = 0; i < n_layers; ++i)
+    if (N[i] <= 0 || !use_pipe(nbits, M, N[i], K, group_size, dtype, opts)) return false;
+  return true;
+}
+int hqq_hip_gemm_grouped_covers(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  return group_on_pipe(nbits, n_layers, N, M, K, group_size, dtype, opts) ? 1 : 0;
+}
+size_t hqq_hip_gemm_grouped_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts) {
+  return group_on_pipe(nbits, n_layers, N, M, K, group_size, dtype, opts) ? gemm_pipe_workspace_bytes_grouped(nbits, n_layers, N, M, K, opts) : 0;
+}
+int hqq_hip_gemm_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
+                         void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  clear_stale_error();
+  if (opts & ~HQQ_OPT_ALL) { set_error("hqq_hip_gemm_grouped: unknown option bits 0x%x", opts & ~HQQ_OPT_ALL); return HQQ_ERR_SHAPE; }
+  if (n_layers < 1 || n_layers > HQQ_GEMV_MAX_GROUP) { set_error("hqq_hip_gemm_grouped: n_layers=%d outside [1,%d]", n_layers, HQQ_GEMV_MAX_GROUP); return HQQ_ERR_SHAPE; }
+  if (!x || !Wq || !scale || !zero || !y || !N) { set_error("hqq_hip_gemm_grouped: null argument"); return HQQ_ERR_SHAPE; }
+  if (M < 1 || K <= 0 || group_size <= 0 || K % group_size) { set_error("hqq_hip_gemm_grouped: bad M/K/group_size"); return HQQ_ERR_SHAPE; }
+  if (M > INT32_MAX || K > INT32_MAX) { set_error("hqq_hip_gemm_grouped: size overflow"); return HQQ_ERR_SHAPE; }
+  int64_t ntot = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    if (N[i] <= 0 || N[i] > INT32_MAX || N[i] * (K / group_size) > INT32_MAX) { set_error("hqq_hip_gemm_grouped: bad N / size overflow"); return HQQ_ERR_SHAPE; }
+    if (!Wq[i] || !scale[i] || !zero[i] || !y[i]) { set_error("hqq_hip_gemm_grouped: null layer pointer"); return HQQ_ERR_SHAPE; }
+    if (!aligned16(Wq[i]) || !aligned16(y[i])) { set_error("hqq_hip_gemm_grouped: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    ntot += N[i];
+  }
+  if (!aligned16(x)) { set_error("hqq_hip_gemm_grouped: pointers must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+  if (ntot > INT32_MAX) { set_error("hqq_hip_gemm_grouped: size overflow"); return HQQ_ERR_SHAPE; }
+  if (!group_on_pipe(nbits, n_layers, N, M, K, group_size, dtype, opts)) {
+    set_error("hqq_hip_gemm_grouped: every layer of the group must be served by the pipelined fused GEMM (fp16 / bf16, nbits 8 / 4 / 2 or the 3-bit stream layout, group_size 64, K %% 128 == 0)");
+    return HQQ_ERR_UNSUPPORTED;
+  }
+  return gemm_pipe_run_grouped(nbits, n_layers, x, Wq, scale, zero, bias, y, N, M, K, group_size, dtype, opts, workspace, workspace_bytes, as_stream(stream));
 }
 
 int hqq_hip_forward(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,

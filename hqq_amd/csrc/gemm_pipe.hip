@@ -42,17 +42,35 @@ template <int NW, int BM> struct GdCfg {   // LDS rings: x stages / steps ahead,
   static constexpr int XSTAGE = BM * GD_K * 2;
 };
 
+// A launch serves a GROUP of up to GD_MAXL layers that read the same x (q | k | v, gate | up, or one layer; round 6): their feature tiles form one
+// concatenated tile space — a workgroup looks its layer up once, before anything else — so a decoder block at 65..2560 rows is 4 launches (+ 4 split-K
+// reduces) instead of 7 (+ 7).  Entries past the last layer repeat it.
+constexpr int GD_MAXL = HQQ_GEMV_MAX_GROUP;
 struct GdArgs {
   const half_t* x;
-  const uint8_t* Wq;
-  const half_t* scale;
-  const half_t* zero;
-  const half_t* bias;
-  half_t* y;
+  const uint8_t* Wq[GD_MAXL];
+  const half_t* scale[GD_MAXL];
+  const half_t* zero[GD_MAXL];
+  const half_t* bias[GD_MAXL];
+  half_t* y[GD_MAXL];
+  int N[GD_MAXL];
+  int tile_end[GD_MAXL];   // end (exclusive) of layer i's feature tiles in the group's concatenated tile space
   float* part;     // [KS][split tiles][PER * BM / 16 accumulator quads][threads] x 4 fp32 (KS > 1 only)
-  int M, N, K, G, n_tiles, m_tiles, KS, kps;
+  int M, K, G, n_tiles, m_tiles, KS, kps;
   int full;        // the first `full` tiles run whole (no split); the remaining tiles x KS splits follow (full = 0: every tile is split, or KS = 1)
 };
+struct GdLayer { const uint8_t* Wq; const half_t* scale; const half_t* zero; const half_t* bias; half_t* y; int N, nt; };
+// the layer of feature tile `nt` and the tile's index inside it (wave-uniform: scalar selects over the argument arrays)
+__device__ __forceinline__ GdLayer gd_layer(const GdArgs& a, int nt) {
+  GdLayer L{a.Wq[0], a.scale[0], a.zero[0], a.bias[0], a.y[0], a.N[0], nt};
+#pragma unroll
+  for (int i = 1; i < GD_MAXL; ++i) {
+    const bool in = nt >= a.tile_end[i - 1];   // (entries past the last layer repeat its tile_end: never true for a valid tile)
+    L.Wq = pick(in, a.Wq[i], L.Wq); L.scale = pick(in, a.scale[i], L.scale); L.zero = pick(in, a.zero[i], L.zero); L.bias = pick(in, a.bias[i], L.bias);
+    L.y = pick(in, a.y[i], L.y); L.N = pick(in, a.N[i], L.N); L.nt = pick(in, nt - a.tile_end[i - 1], L.nt);
+  }
+  return L;
+}
 
 // chunk position (16 B units) inside a 128-byte row of the x stage: chunk ^ gd_swz(row).  Found by search over the GF(2)-linear maps
 // row -> 3 bits: with it the four 16-lane groups of a ds_read_b128 whose lane (r, c) reads chunk 2 c + h of row 16 j + r touch 16
@@ -215,8 +233,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     tile = whole ? L : a.full + L % split_tiles;
     ks = whole ? 0 : L / split_tiles;
   }
-  const int nt = tile % a.n_tiles, mt = tile / a.n_tiles;
-  const int N = a.N, K = a.K, M = a.M, G = a.G;
+  const int mt = tile / a.n_tiles;
+  const GdLayer L = gd_layer(a, tile % a.n_tiles);
+  const int nt = L.nt;
+  const int N = L.N, K = a.K, M = a.M, G = a.G;
   const int rows_per_slab = N / PER;
   const int p0 = nt * GD_PROWS + wave * 16, m0 = mt * GD_BM;
   const int nk = K / GD_K;
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
   //      M read row 0: their accumulator columns are never stored, and a column depends on its own x row only) ----
   const bool w_active = (p0 + r) < rows_per_slab;
   const int wrow = w_active ? p0 + r : rows_per_slab - 1;
-  const uint8_t* wsrc = a.Wq + static_cast<int64_t>(wrow) * (K / 16 * LB) + c * LB + static_cast<int64_t>(kt0) * (4 * LB);
+  const uint8_t* wsrc = L.Wq + static_cast<int64_t>(wrow) * (K / 16 * LB) + c * LB + static_cast<int64_t>(kt0) * (4 * LB);
   const half_t* xsrc[XP];
 #pragma unroll
   for (int q = 0; q < XP; ++q) {   // piece XP w + q fills rows 8 (XP w + q) .. + 7 of the stage: lane -> (row, position)
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
   for (int t = 0; t < MD::NI; ++t) {   // element e = 64 t + lane: row e & 15, slab (e >> 4) % PER, zero | scale (e >> 4) / PER
     const int e = 64 * t + lane, er = e & 15, es = (e >> 4) % PER, which = ((e >> 4) / PER) & 1;
     const int prow = (p0 + er) < rows_per_slab ? p0 + er : rows_per_slab - 1;
-    msrc[t] = (which ? a.scale : a.zero) + (static_cast<int64_t>(es) * rows_per_slab + prow) * G + kt0;
+    msrc[t] = (which ? L.scale : L.zero) + (static_cast<int64_t>(es) * rows_per_slab + prow) * G + kt0;
   }
   const uint16_t smask = w_active ? 0xFFFFu : 0u;   // rows past the end of the slab: scale 0 -> exact zero weights
 
@@ -427,8 +447,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
       if (m >= M) continue;
       uint16_t o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(acc[s][j][i], (a.bias && pb + i < rows_per_slab) ? a.bias : nullptr, n + i);
-      uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + static_cast<int64_t>(m) * N + n;
+      for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(acc[s][j][i], (L.bias && pb + i < rows_per_slab) ? L.bias : nullptr, n + i);
+      uint16_t* dst = reinterpret_cast<uint16_t*>(L.y) + static_cast<int64_t>(m) * N + n;
       if (pb + 3 < rows_per_slab) {
         *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
       } else {
@@ -450,7 +470,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
   const int r = lane & 15, c = lane >> 4;
   const int sj = blockIdx.x % (PER * GD_MT), stile = blockIdx.x / (PER * GD_MT), tile = a.full + stile;   // (the split tiles only)
   const int s = sj / GD_MT, j = sj % GD_MT;
-  const int nt = tile % a.n_tiles, mt = tile / a.n_tiles;
+  const int mt = tile / a.n_tiles;
+  const GdLayer L = gd_layer(a, tile % a.n_tiles);
+  const int nt = L.nt;
   const int64_t tiles = static_cast<int64_t>(a.n_tiles) * a.m_tiles - a.full;
   const f32x4* src = reinterpret_cast<const f32x4*>(a.part) + (static_cast<int64_t>(stile) * (PER * GD_MT) + sj) * GD_T + tid;
   const int64_t kstride = tiles * (PER * GD_MT * GD_T);
@@ -463,15 +485,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
     for (int kk = 0; kk < 4; ++kk)
       if (k0 + kk < a.KS) { sum[0] += t[kk][0]; sum[1] += t[kk][1]; sum[2] += t[kk][2]; sum[3] += t[kk][3]; }
   }
-  const int rows_per_slab = a.N / PER;
+  const int rows_per_slab = L.N / PER;
   const int pb = nt * GD_PROWS + wave * 16 + 4 * c;
   const int m = mt * GD_BM + 16 * j + r;
   if (pb >= rows_per_slab || m >= a.M) return;
   const int n = s * rows_per_slab + pb;
   uint16_t o[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(sum[i], (a.bias && pb + i < rows_per_slab) ? a.bias : nullptr, n + i);
-  uint16_t* dst = reinterpret_cast<uint16_t*>(a.y) + static_cast<int64_t>(m) * a.N + n;
+  for (int i = 0; i < 4; ++i) o[i] = gd_out<BF>(sum[i], (L.bias && pb + i < rows_per_slab) ? L.bias : nullptr, n + i);
+  uint16_t* dst = reinterpret_cast<uint16_t*>(L.y) + static_cast<int64_t>(m) * L.N + n;
   if (pb + 3 < rows_per_slab) {
     *reinterpret_cast<u32x2*>(dst) = *reinterpret_cast<u32x2*>(o);
   } else {
@@ -484,15 +506,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_pipe_reduce_kernel(const GdArgs 
 // ---- host side --------------------------------------------------------------------------------------------------------------------
 struct GpPlan { int NW, BM, n_tiles, m_tiles, KS, kps, full; };   // full: tiles that run whole before the split ones (0 unless the plan is a hybrid)
 
-static GpPlan gp_make(int nbits, int64_t M, int64_t N, int64_t K, int nw, int bm, int ks) {
+// the layers of a launch (one layer: nl = 1).  A plan looks at the group as ONE layer of sum(N) features whose feature tiles never straddle two layers.
+struct GpGroup { int nl; int64_t N[GD_MAXL]; int64_t Ntot; };
+static GpGroup gp_group(const int64_t* N, int nl) {
+  GpGroup g;
+  g.nl = nl; g.Ntot = 0;
+  for (int i = 0; i < GD_MAXL; ++i) { g.N[i] = N[i < nl ? i : nl - 1]; if (i < nl) g.Ntot += N[i]; }
+  return g;
+}
+static int gp_feature_tiles(const GpGroup& g, int nbits, int nw) {
+  int64_t t = 0;
+  for (int i = 0; i < g.nl; ++i) t += (g.N[i] / gd_per(nbits) + 16 * nw - 1) / (16 * nw);
+  return static_cast<int>(t);
+}
+
+static GpPlan gp_make(int nbits, int64_t M, const GpGroup& g, int64_t K, int nw, int bm, int ks) {
   GpPlan p;
-  const int64_t rows_per_slab = N / gd_per(nbits);
   const int nk = static_cast<int>(K / GD_K);
   p.NW = nw;
   p.BM = bm;
   p.full = 0;
   p.m_tiles = static_cast<int>((M + bm - 1) / bm);
-  p.n_tiles = static_cast<int>((rows_per_slab + 16 * nw - 1) / (16 * nw));
+  p.n_tiles = gp_feature_tiles(g, nbits, nw);
   if (ks > GD_MAX_KS) ks = GD_MAX_KS;
   if (ks < 1) ks = 1;
   p.kps = (nk + ks - 1) / ks;
@@ -526,7 +561,8 @@ static double gp_cost(const GpPlan& p, int64_t M, int64_t N, int nk) {
 
 // Shapes only (never the data): the split depends on (M, N, K), so a row of y can differ in the last bit between batch sizes that
 // choose different splits — as with any split-K GEMM — but is reproducible run to run.
-static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
+static GpPlan gp_plan(int nbits, int64_t M, const GpGroup& grp, int64_t K, uint32_t opts) {
+  const int64_t N = grp.Ntot;
   const int nk = static_cast<int>(K / GD_K);
   const int forced_ks = static_cast<int>(opts >> 24);
   const int forced_nw = (opts & HQQ_OPT_GEMM_WIDE) ? 8 : (opts & HQQ_OPT_GEMM_NARROW) ? 4 : 0;
@@ -534,25 +570,25 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
   static const int KSS[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
   static const int SHAPES[3][2] = {{4, 128}, {8, 128}, {8, 256}};
   if (nbits == 2) {   // the 4-wave tile only (see GD_2BIT_ONE_WAVE_PER_SIMD): the split is still chosen by the model (or forced)
-    GpPlan b2 = gp_make(2, M, N, K, 4, 128, forced_ks ? forced_ks : 1);
+    GpPlan b2 = gp_make(2, M, grp, K, 4, 128, forced_ks ? forced_ks : 1);
     double c2 = gp_cost(b2, M, N, nk);
     for (int ks : KSS) {
       if (forced_ks) break;
-      GpPlan p = gp_make(2, M, N, K, 4, 128, ks);
+      GpPlan p = gp_make(2, M, grp, K, 4, 128, ks);
       if (p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
       const double c = gp_cost(p, M, N, nk);
       if (c < c2) { b2 = p; c2 = c; }
     }
     return b2;
   }
-  GpPlan best = gp_make(nbits, M, N, K, both ? 8 : (forced_nw ? forced_nw : 4), both && nbits != 2 ? 256 : 128, forced_ks ? forced_ks : 1);
+  GpPlan best = gp_make(nbits, M, grp, K, both ? 8 : (forced_nw ? forced_nw : 4), both && nbits != 2 ? 256 : 128, forced_ks ? forced_ks : 1);
   double best_cost = gp_cost(best, M, N, nk);
   for (const auto& sh : SHAPES) {
     if (both ? sh[1] != 256 : (forced_nw && (sh[0] != forced_nw || sh[1] != 128))) continue;
     if (sh[1] == 256 && nbits == 2) continue;   // four slabs x 16 token tiles of accumulators do not fit the register file
     for (int ks : KSS) {
       if (forced_ks && ks != 1) continue;
-      GpPlan p = gp_make(nbits, M, N, K, sh[0], sh[1], forced_ks ? forced_ks : ks);
+      GpPlan p = gp_make(nbits, M, grp, K, sh[0], sh[1], forced_ks ? forced_ks : ks);
       // at least sixteen steps (1024 k) per split: below that the prologue and the parked tile cost more than the split saves
       if (!forced_ks && p.KS > 1 && (p.kps < 16 || nk / p.KS < 16)) continue;
       const double c = gp_cost(p, M, N, nk);
@@ -569,8 +605,8 @@ static GpPlan gp_plan(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts)
   return best;
 }
 
-size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) {
-  const GpPlan p = gp_plan(nbits, M, N, K, opts);
+size_t gemm_pipe_workspace_bytes_grouped(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, uint32_t opts) {
+  const GpPlan p = gp_plan(nbits, M, gp_group(N, n_layers), K, opts);
   if (p.KS <= 1) return 0;
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full;
   return WS_COUNTER_BYTES + static_cast<size_t>(p.KS) * tiles * p.BM * (16 * p.NW) * gd_per(nbits) * sizeof(float);   // (the head stays zero: the decode kernels' arrival counters)
@@ -583,13 +619,15 @@ size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uin
 // Against the other prefill route, hqq_hip_dequantize + hqq_hip_gemm_dense (rebuild the weights once, stream them as fp16): this kernel rebuilds
 // every weight once per 256-token tile and is ahead while that is a few times — to ~2000 tokens on the 7B shapes, level at 3072, behind from
 // 4096 (profiles/r04_prefill_routes_int4.txt; the dense kernel's 256 x 256 tiles also leave CUs idle below ~2000 tokens)
+size_t gemm_pipe_workspace_bytes(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts) { return gemm_pipe_workspace_bytes_grouped(nbits, 1, &N, M, K, opts); }
+
 bool gemm_pipe_wins(int nbits, int64_t M, int64_t N, int64_t K) {
   (void)nbits; (void)N; (void)K;
   return M <= 2560;
 }
 
 void gemm_pipe_describe(int nbits, int64_t M, int64_t N, int64_t K, uint32_t opts, int out[8]) {
-  const GpPlan p = gp_plan(nbits, M, N, K, opts);
+  const GpPlan p = gp_plan(nbits, M, gp_group(&N, 1), K, opts);
   out[0] = p.NW; out[1] = p.BM; out[2] = p.n_tiles; out[3] = p.m_tiles; out[4] = p.KS; out[5] = p.kps; out[6] = p.full;
   out[7] = static_cast<int>(p.full + (static_cast<int64_t>(p.n_tiles) * p.m_tiles - p.full) * p.KS);
 }
@@ -625,23 +663,31 @@ static int gp_launch(const GdArgs& a, int64_t blocks, hipStream_t st) {
   return check_launch("hqq_hip_gemm(split-K reduce)");
 }
 
-int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
-                  int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  const GpPlan p = gp_plan(nbits, M, N, K, opts);
+int gemm_pipe_run_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
+                          void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const GpGroup grp = gp_group(N, n_layers);
+  const GpPlan p = gp_plan(nbits, M, grp, K, opts);
   const int64_t tiles = static_cast<int64_t>(p.n_tiles) * p.m_tiles;
   const int64_t blocks = p.full + (tiles - p.full) * p.KS;
   if (blocks * (gd_per(nbits) * (p.BM / 16)) > INT32_MAX) { set_error("hqq_hip_gemm: grid too large"); return HQQ_ERR_SHAPE; }
   GdArgs a;
-  a.x = static_cast<const half_t*>(x); a.Wq = static_cast<const uint8_t*>(Wq); a.scale = static_cast<const half_t*>(scale);
-  a.zero = static_cast<const half_t*>(zero); a.bias = static_cast<const half_t*>(bias); a.y = static_cast<half_t*>(y);
+  a.x = static_cast<const half_t*>(x);
+  int64_t t_end = 0;
+  for (int i = 0; i < GD_MAXL; ++i) {
+    const int j = i < n_layers ? i : n_layers - 1;
+    if (!aligned16(scale[j]) || !aligned16(zero[j])) { set_error("hqq_hip_gemm: scale / zero must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
+    a.Wq[i] = static_cast<const uint8_t*>(Wq[j]); a.scale[i] = static_cast<const half_t*>(scale[j]); a.zero[i] = static_cast<const half_t*>(zero[j]);
+    a.bias[i] = bias ? static_cast<const half_t*>(bias[j]) : nullptr; a.y[i] = static_cast<half_t*>(y[j]); a.N[i] = static_cast<int>(N[j]);
+    if (i < n_layers) t_end += (N[i] / gd_per(nbits) + 16 * p.NW - 1) / (16 * p.NW);
+    a.tile_end[i] = static_cast<int>(t_end);
+  }
   a.part = nullptr;
-  a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K); a.G = static_cast<int>(K / gs);
+  a.M = static_cast<int>(M); a.K = static_cast<int>(K); a.G = static_cast<int>(K / gs);
   a.n_tiles = p.n_tiles; a.m_tiles = p.m_tiles; a.KS = p.KS; a.kps = p.kps; a.full = p.full;
-  if (!aligned16(scale) || !aligned16(zero)) { set_error("hqq_hip_gemm: scale / zero must be 16-byte aligned"); return HQQ_ERR_ALIGN; }
   if (p.KS > 1) {
-    const size_t need = gemm_pipe_workspace_bytes(nbits, M, N, K, opts);
+    const size_t need = gemm_pipe_workspace_bytes_grouped(nbits, n_layers, N, M, K, opts);
     if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
-      set_error("hqq_hip_gemm: workspace %zu < %zu bytes (hqq_hip_forward_workspace_bytes)", workspace_bytes, need);
+      set_error("hqq_hip_gemm: workspace %zu < %zu bytes (hqq_hip_forward_workspace_bytes / hqq_hip_gemm_grouped_workspace_bytes)", workspace_bytes, need);
       return HQQ_ERR_WORKSPACE;
     }
     a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTER_BYTES);
@@ -655,6 +701,11 @@ int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, c
   return GP_GO(2);
 #undef GP_GO3
 #undef GP_GO
+}
+
+int gemm_pipe_run(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias, void* y,
+                  int64_t M, int64_t N, int64_t K, int64_t gs, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  return gemm_pipe_run_grouped(nbits, 1, x, &Wq, &scale, &zero, bias ? &bias : nullptr, &y, &N, M, K, gs, dtype, opts, workspace, workspace_bytes, st);
 }
 
 }  // namespace hqq

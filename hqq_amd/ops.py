@@ -327,6 +327,56 @@ def gemv_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=No
     return [o.reshape(*x.shape[:-1], L[4]) for o, L in zip(outs, layers)]
 
 
+FUSED_GEMM_MAX_M = 2560   # gemm_pipe_wins (csrc/gemm_pipe.hip): beyond, dequantise + the dense GEMM is the faster route
+
+
+def gemm_grouped_covers(dtype, layers_N, M: int, K: int, group_size, nbits: int, opts=None) -> bool:
+    """True when hqq_hip_gemm_grouped serves this group: every layer on the pipelined fused GEMM (fp16 / bf16, 8 / 4 / 2 bit or the 3-bit stream layout, group_size 64, K % 128 == 0)"""
+    import ctypes
+    n = len(layers_N)
+    if dtype not in _DT or not 1 <= n <= GEMV_MAX_GROUP or M < 1 or not group_size:
+        return False
+    return bool(_C.lib().hqq_hip_gemm_grouped_covers(int(nbits), n, (ctypes.c_int64 * n)(*[int(v) for v in layers_N]), int(M), int(K), int(group_size), _dt(dtype), _opts(opts)))
+
+
+def gemm_grouped(x: Tensor, layers, K: int, group_size: int, nbits: int, outs=None, opts=None):
+    """Horizontal fusion beyond the decode rows: ONE launch of the pipelined fused GEMM (+ one split-K reduce) for up to GEMV_MAX_GROUP layers that consume
+    the same x (q / k / v, gate / up) — a decoder block at 65..2560 rows is 4 launches instead of 7.  layers: sequence of (W_q, scale, zero, bias_or_None, N).
+    Returns the list of outputs [*, N_i].  The K split is chosen for the group's total width: a row can differ in the last bit from the layer launched alone."""
+    import ctypes
+    n = len(layers)
+    if not 1 <= n <= GEMV_MAX_GROUP:
+        raise ValueError(f"hqq_amd: a GEMM group holds 1..{GEMV_MAX_GROUP} layers, got {n}")
+    if x.shape[-1] != K:
+        raise ValueError(f"hqq_amd: x has {x.shape[-1]} features, layers expect {K}")
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    for (W_q, s, z, b, N) in layers:
+        _dev(x, W_q, s, z, b)
+        if x.dtype != s.dtype or z.dtype != s.dtype or (b is not None and b.dtype != s.dtype):
+            raise TypeError("hqq_amd: x / scale / zero / bias must share the compute dtype")
+    if outs is None:
+        outs = [torch.empty((M, L[4]), dtype=x.dtype, device=x.device) for L in layers]
+    if M > 0:
+        VP = ctypes.c_void_p * n
+        has_bias = any(L[3] is not None for L in layers)
+        o = _opts(opts)
+        Ns = (ctypes.c_int64 * n)(*[int(L[4]) for L in layers])
+        with torch.cuda.device(x.device):
+            need = int(_C.lib().hqq_hip_gemm_grouped_workspace_bytes(int(nbits), n, Ns, int(M), int(K), int(group_size), _dt(x.dtype), o))
+            ws, ws_bytes = (None, 0)
+            if need:
+                w = reserve_workspace(x.device, need)
+                ws, ws_bytes = w.data_ptr(), w.numel()
+            rc = _C.lib().hqq_hip_gemm_grouped(
+                nbits, n, _p(x2), VP(*[_p(L[0]) for L in layers]), VP(*[_p(L[1]) for L in layers]), VP(*[_p(L[2]) for L in layers]),
+                VP(*[_p(L[3]) for L in layers]) if has_bias else None, VP(*[_p(o_) for o_ in outs]), Ns, M, K, group_size, _dt(x.dtype), o, ws, ws_bytes, _stream())
+        _C.check(rc, "hqq_hip_gemm_grouped")
+    return [o_.reshape(*x.shape[:-1], L[4]) for o_, L in zip(outs, layers)]
+
+
 BLOCK_NORM, BLOCK_RESID, BLOCK_SILU = 1, 2, 4   # HQQ_BLOCK_* (include/hqq_hip.h)
 
 
@@ -533,15 +583,16 @@ def dense_covers(dtype, N, K) -> bool:
     return dtype in (torch.float16, torch.bfloat16) and K % 64 == 0 and K >= 64 and N % 4 == 0
 
 
-# The dense kernel's 256 x 256 tiles leave most CUs idle below a few thousand rows (16 workgroups at 256 rows of a 4096-wide layer: 90 us where the
-# library's small-tile / split-K kernels take 40).  Layers the fused kernels cover never get there (they take the fused GEMM to 2560 rows); for
-# the others — group sizes other than 64, K % 128 != 0 — the composition keeps the library GEMM up to the same row count.
-DENSE_MIN_M = 2561
+# Every composed forward (what the fused kernels do not cover: group sizes other than 64 outside gemm.hip's 4- / 2-bit fp16 tiles, K % 128 != 0, 8-bit / bf16 with
+# other group sizes) runs dequantise kernel + the in-tree MFMA GEMM from 17 rows on — no library GEMM on any fp16 / bf16 axis-1 path (round 6; until then
+# 17..2560 rows of such layers went to torch.matmul).  The dense kernel's 256 x 256 tiles leave CUs idle below ~2000 rows (16 workgroups at 256 rows of a
+# 4096-wide layer: ~90 us where a library's small-tile kernels take ~40): a known cost on shapes outside BASELINE.json's, `library_gemm=True` is the opt-out.
+DENSE_MIN_M = 17
 
 
 def _compose(x, W, bias, out, N, K, library: bool) -> Tensor:
-    """the route after the dequantise kernel: the in-tree MFMA GEMM from DENSE_MIN_M rows on; a library GEMM below (only layers the fused kernels
-    do not cover get there), for shapes the in-tree kernel does not cover (K % 64 != 0, N % 4 != 0), or when asked for (library=True)"""
+    """the route after the dequantise kernel: the in-tree MFMA GEMM from DENSE_MIN_M rows on; torch.matmul — what the reference itself calls — below that
+    (decode-sized residue), for shapes the in-tree kernel does not cover (K % 64 != 0, N % 4 != 0), or when asked for (library=True)"""
     if not library and dense_covers(x.dtype, N, K) and x.numel() // K >= DENSE_MIN_M:
         return gemm_dense(x, W, bias, out=None if out is None else out.reshape(-1, N))
     y = torch.matmul(x.reshape(-1, K), W.t(), out=out)

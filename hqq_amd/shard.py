@@ -312,10 +312,21 @@ class PeerExchange:
         except Exception:   # noqa: BLE001  (interpreter shutdown: the driver reclaims the process's memory anyway)
             pass
 
-    def close(self) -> None:
-        """Give the arena and the peers' IPC mappings back to the runtime.  Collective in spirit: call it on every rank once no rank's kernels
-        can still store into this rank's arena (after a barrier); the object — and every tensor full() / rows handed out — is unusable afterwards."""
-        self._closer()
+    def close(self, group=None) -> None:
+        """Give the arena and the peers' IPC mappings back to the runtime — the ONLY way they are released: garbage collection leaks them on purpose
+        (a peer may still have this arena mapped and be storing into it, and full() hands out views into it; a rank that drops its object early, on
+        an exception path say, must not turn the others' stores into writes to freed memory — advisor, round 5).  COLLECTIVE: every rank calls it; with a
+        process group it first synchronises the device and barriers, so that no rank's kernels can still store into an arena when it goes.  The object —
+        and every tensor full() / rows handed out — is unusable afterwards."""
+        if self._closed:
+            return
+        self._closed = True
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self._collective:   # (built over a process group; local_group()'s in-process ranks share one caller and need no barrier)
+            import torch.distributed as dist
+            dist.barrier(group=self._group if group is None else group)
+        PeerExchange._release(self._raw_ptr, list(self._opened), self.device)
 
     def __init__(self, points, nbits: int, dtype, device, group=None, spin_limit: int = 0, _arenas=None, _rank=None, _world=None, rows: int = 1):
         import torch.distributed as dist
@@ -403,9 +414,9 @@ class PeerExchange:
                 if not all(oks):
                     bad = [p for p, o in enumerate(oks) if not o]
                     raise RuntimeError(f"hqq_amd: PeerExchange: rank(s) {bad} could not map their peers' arenas" + (f" ({type(err).__name__}: {err})" if err else ""))
-        # what this object took from the runtime itself goes back when it dies (or on close()): the peers' IPC mappings, then its own arena
+        # what this object took from the runtime itself (the peers' IPC mappings, its own arena) goes back in close() only — never on garbage collection
         self._opened = [int(a.data_ptr()) for p, a in enumerate(self._arenas) if self._raw_ptr is not None and self.world > 1 and p != self.rank]
-        self._closer = __import__("weakref").finalize(self, PeerExchange._release, self._raw_ptr, list(self._opened), self.device)
+        self._closed = False
         if any(a.numel() < self.arena_bytes for a in self._arenas):
             raise ValueError("hqq_amd: PeerExchange arenas are smaller than the layout (ranks disagree about the points)")
         self._base = [a.data_ptr() for a in self._arenas]

@@ -87,9 +87,23 @@ class GraphedGreedyDecoder:
         self.tok.copy_(self.next_tok)
         self.pos += 1
 
+    def _fingerprint(self):
+        """what the kept state was built from: identity, storage and version of every quantised layer's packed weights and scale, and the forward HQQLinear is
+        bound to (set_backend rebinds it class-wide).  A re-quantised / re-loaded / re-patched model gives another tuple (round-5 advisor: the kept step and
+        graphs silently decoded with stale copies).  In-place edits through .data bypass the version counters: call reset() after those."""
+        from ..core.quantize import HQQLinear
+        fp = [getattr(HQQLinear, "backend", None)]
+        for m in self.model.modules():
+            W, meta = getattr(m, "W_q", None), getattr(m, "meta", None)
+            if isinstance(W, Tensor):
+                sc = meta.get("scale") if isinstance(meta, dict) else getattr(m, "scale", None)
+                ver = lambda t: None if (t is None or t.is_inference()) else t._version   # noqa: E731
+                fp.append((id(m), W.data_ptr(), ver(W), None if sc is None else sc.data_ptr(), ver(sc)))
+        return tuple(fp)
+
     def reset(self) -> None:
-        """drop what generate() keeps between calls (the static cache, the fused step with its re-laid-out layer copies, the captured graphs): call it after the
-        model's weights changed"""
+        """drop what generate() keeps between calls (the static cache, the fused step with its re-laid-out layer copies, the captured graphs).  generate() calls it
+        by itself when the model's quantised layers are no longer the ones the state was built from (_fingerprint)"""
         self.cache = None
         self.step = None
         self.graph = None
@@ -106,6 +120,10 @@ class GraphedGreedyDecoder:
         T = input_ids.shape[1]
         assert T + max_new_tokens <= self.max_cache_len
         ids = input_ids.to(self.device)
+        fp = self._fingerprint()
+        if getattr(self, "_fp", None) != fp:   # other weights / layers / backend than the kept step and graphs were built from
+            self.reset()
+            self._fp = fp
         kept = getattr(self, "cache", None) is not None and getattr(self, "_state", None) is not None
         if kept:
             self.cache.reset()
@@ -259,6 +277,11 @@ class HFGenerator:
         # (the reference also sets model.generation_config.cache_implementation = "static" here: its loop shares the model's own generate() settings.  This loop owns its
         #  StaticCache; the setting would only make every LATER model.generate() call of the caller compile the model — generate_() asks for the static cache itself)
         self.model.config.use_cache = True
+
+    def reset(self) -> None:
+        """drop the decoder's kept static cache, fused step and captured graphs (GraphedGreedyDecoder.reset; generate() also does it by itself when the model's
+        quantised layers changed — call this after an in-place edit of weights that bypasses torch's version counters)"""
+        self.decoder.reset()
 
     def warmup(self, max_samples: int = -1):
         """a few prompts through the loop: the fused step is built and the graphs of the first cache buckets captured before a caller's clock starts"""

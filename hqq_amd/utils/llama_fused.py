@@ -123,6 +123,23 @@ class FusedLlamaStep:
         if glue == "folded" and not can_fold:
             raise ValueError("hqq_amd: glue='folded' needs fp16 / bf16 layers of 4 / 2 bits or the 3-bit stream layout, group_size 64, hidden size <= 8192")
         self.folded = can_fold and glue != "kernels"
+        # The folded step keeps re-laid-out COPIES of q, k (rotary-paired rows) and of gate | up (one paired layer) beside the layers' own tensors: about
+        # +60 % of the decoder's linear-weight bytes (7B at 4 bits: +1.9 GB).  glue="auto" takes them only when they fit with room to spare; a model that filled
+        # the GPU before keeps round 4's separate glue kernels (no copy) instead of running out of memory here (round-5 advisor).  glue="folded" insists.
+        self.extra_weight_bytes = 0
+        if self.folded:
+            def _nbytes(L):
+                return L.W_q.numel() * L.W_q.element_size() + 2 * L.scale.numel() * L.scale.element_size()
+            need = sum(_nbytes(_hip(getattr(b.self_attn, n))) for b in inner.layers for n in ("q_proj", "k_proj")) + \
+                sum(_nbytes(_hip(getattr(b.mlp, n))) for b in inner.layers for n in ("gate_proj", "up_proj"))
+            free_b = torch.cuda.mem_get_info(self.device)[0] if self.device.type == "cuda" else need * 4
+            if glue == "auto" and free_b < need + need // 4 + (1 << 30):
+                import warnings
+                warnings.warn(f"hqq_amd: the folded decode step needs {need / 1e9:.2f} GB for its paired layer copies, {free_b / 1e9:.2f} GB are free: "
+                              "falling back to the separate glue kernels (glue='kernels')")
+                self.folded = False
+            else:
+                self.extra_weight_bytes = need
         self.blocks = []
         dev = self.device
         for li, blk in enumerate(inner.layers):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HQQ_HIP_ABI_VERSION 7
+#define HQQ_HIP_ABI_VERSION 8
 
 /* element types of activations / meta / outputs ("compute_dtype" in the reference) */
 enum { HQQ_F32 = 0, HQQ_F16 = 1, HQQ_BF16 = 2, HQQ_U8 = 3 };
@@ -189,8 +189,8 @@ int hqq_hip_silu_mul(const void* gate, const void* up, void* out, int64_t n, int
 /* The per-token work either side of the decoder blocks (ABI 7; hqq/utils/generation_hf.py:405-540: embedding lookup, the rotary table's row, the causal mask of one query in
  * front; argmax, token hand-over, position increment behind) as ONE launch each — copies and compares only, bit-identical to the torch ops they replace:
  *   hqq_hip_token_prologue  h[H] = embed[*tok_dev]; cos / sin [head_dim] = cos_tab / sin_tab [L, head_dim] row *pos_dev (tables NULL: skipped);
- *                           mask[L] = i <= *pos_dev ? 0 : -inf (mask NULL: skipped).  A token / position outside the tables reads the last row.
- *   hqq_hip_argmax_advance  *next_tok_dev = the FIRST index of the largest of logits[n] (torch.argmax; logits finite); *tok_dev = the same (NULL: skipped); *pos_dev += 1 (NULL: skipped) */
+ *                           mask[L] = i <= *pos_dev ? 0 : -inf (mask NULL: skipped).  A token / position outside the tables is CLAMPED to the last row (torch's index ops would raise; the caller validates).
+ *   hqq_hip_argmax_advance  *next_tok_dev = the FIRST index of the largest of logits[n], a NaN counting as the largest (torch.argmax's order); *tok_dev = the same (NULL: skipped); *pos_dev += 1 (NULL: skipped) */
 int hqq_hip_token_prologue(const int64_t* tok_dev, const int64_t* pos_dev, const void* embed, int64_t vocab, int64_t H, const void* cos_tab, const void* sin_tab, int64_t L,
                            int64_t head_dim, void* h, void* cos, void* sin, void* mask, int dtype, void* stream);
 int hqq_hip_argmax_advance(const void* logits, int64_t n, int dtype, int64_t* next_tok_dev, int64_t* tok_dev, int64_t* pos_dev, void* stream);
@@ -264,6 +264,17 @@ int hqq_hip_forward_prefers_fused(int nbits, int64_t M, int64_t N, int64_t K, in
 int hqq_hip_gemm(int nbits, const void* x, const void* Wq, const void* scale, const void* zero, const void* bias,
                  void* y, int64_t M, int64_t N, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
                  void* stream);
+/* hqq_hip_gemm for a GROUP of 1..HQQ_GEMV_MAX_GROUP layers that read the same x[M, K] (q | k | v, gate | up of a decoder block — hqq/utils/patching.py:82-86 calls them
+ * one by one): ONE launch of the pipelined fused GEMM over the layers' concatenated feature tiles (+ one split-K reduce), y[i][M, N[i]] per layer (ABI 8).
+ * Every layer must be one hqq_hip_gemm serves on the pipelined kernel (hqq_hip_gemm_grouped_covers = 1: fp16 / bf16, nbits 8 / 4 / 2 or the 3-bit stream
+ * layout with HQQ_OPT_W3S, group_size 64, K % 128 == 0, (N / per) % 4 == 0); opts (incl. HQQ_OPT_META_SCALABLE) apply to the whole group.  The K split is chosen
+ * for the group's total width, so a row may differ in the last bit from the same layer launched alone (another association of the same fp32 sums).
+ * Workspace: hqq_hip_gemm_grouped_workspace_bytes (same contract as hqq_hip_forward's). */
+int hqq_hip_gemm_grouped_covers(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts);
+size_t hqq_hip_gemm_grouped_workspace_bytes(int nbits, int n_layers, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts);
+int hqq_hip_gemm_grouped(int nbits, int n_layers, const void* x, const void* const* Wq, const void* const* scale, const void* const* zero, const void* const* bias,
+                         void* const* y, const int64_t* N, int64_t M, int64_t K, int64_t group_size, int dtype, uint32_t opts, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* HQQLinear.matmul on already dequantised weights (quantize.py:880-882: torch.matmul(x, W.t())): y[M,N] = x[M,K] . Wd[N,K]^T (+ bias[N]),
  * fp16 / bf16, fp32 accumulation, one rounding (+ one for the bias add).  The GEMM half of the long-prompt route: hqq_hip_dequantize rebuilds
  * a layer's weights once, this contracts them with any number of tokens (csrc/gemm_dense.hip: 256 x 256 x 64 tiles, all operands by LDS-DMA,

@@ -87,6 +87,33 @@ def test_long_prompt_forward_takes_the_in_tree_gemm_and_matches_the_oracle(ops, 
     torch.testing.assert_close(y.float(), yl.float(), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("nbits,gs,K,M", [(8, 32, 1024, 100), (8, 128, 1024, 17), (4, 64, 960, 300), (2, 64, 1088, 2560)])
+def test_batches_of_layers_the_fused_kernels_do_not_cover_stay_in_tree(ops, oracle, nbits, gs, K, M):
+    """17..2560 rows through a layer the fused GEMMs do not cover (8-bit with another group size; K % 128 != 0): dequantise kernel + the in-tree MFMA GEMM
+    since round 6 — torch.matmul is never reached (missing 3) — and the result is the oracle's"""
+    N = 384
+    g = torch.Generator().manual_seed(nbits * 1000 + gs)
+    R = N * K // gs
+    U = torch.randint(0, 2 ** nbits, (R, gs), generator=g, dtype=torch.uint8)
+    s = (torch.rand(R, 1, generator=g) * 0.004 + 0.001).half()
+    z = (torch.rand(R, 1, generator=g) * (2 ** nbits - 1)).half()
+    P = oracle.pack(nbits, U.numpy())
+    Wd = oracle.dequantize(nbits, P, s.numpy(), z.numpy(), N, K, gs, 1)
+    x = torch.randn(M, K, generator=g).half()
+    bias = torch.randn(N, generator=g).half()
+    assert not ops._C.lib().hqq_hip_forward_prefers_fused(nbits, M, N, K, gs, 1)
+    real_matmul, calls = torch.matmul, []
+    torch.matmul = lambda *a, **k: (calls.append(1), real_matmul(*a, **k))[1]
+    try:
+        y = ops.forward(x.cuda(), torch.from_numpy(P).cuda(), s.cuda(), z.cuda(), bias.cuda(), N, K, gs, nbits)
+    finally:
+        torch.matmul = real_matmul
+    assert not calls, "ops.forward reached torch.matmul"
+    rows = sorted({0, 1, M // 2, M - 1})
+    yo, _ = oracle.matmul(x[rows].numpy(), Wd, bias.numpy(), 1)
+    torch.testing.assert_close(y[rows].float().cpu(), torch.from_numpy(yo.astype(np.float32)), rtol=1e-3, atol=2e-3)
+
+
 def test_configs2_prompt_of_65536_tokens_whole_and_in_chunks(ops, oracle):
     """BASELINE.json configs[2]: 65,536 prefill tokens through a 4-bit 4096 x 4096 layer — in one forward call (weights rebuilt once) and as
     8 chunks of 8192: identical bit for bit (rows are independent), and equal to the oracle on a row sample"""

@@ -257,3 +257,89 @@ def test_routing_workspace_and_variants(ops):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, y)
+
+
+@pytest.mark.parametrize("nbits", [8, 4, 2])
+@pytest.mark.parametrize("M,Ns,K,dt", [(65, (256, 64, 64), 256, "f16"), (128, (200, 264), 512, "f16"), (300, (1024, 128, 128, 72), 1024, "f16"),
+                                        (700, (512, 512), 2048, "bf16"), (130, (264,), 1280, "f16")])
+def test_grouped_pipelined_gemm(ops, oracle, nbits, M, Ns, K, dt):
+    """hqq_hip_gemm_grouped (round 6): layers that read the same x through ONE launch of the pipelined kernel over their concatenated feature tiles
+    (layer widths that are NOT multiples of the tile: a tile never straddles two layers).  Per layer: the oracle's dequantise + fp32-accumulate matmul within
+    the forward tolerance; one-hot rows pick the dequantise kernel's columns EXACTLY (the layer lookup and every offset are right, not just close); within
+    tolerance of the same layer launched alone (another K split for the wider group: another association, not other weights)."""
+    per = 8 // nbits
+    if any(N % per or (N // per) % 4 for N in Ns):
+        pytest.skip("N not packable at this width")
+    cd = torch.float16 if dt == "f16" else torch.bfloat16
+    code = 1 if dt == "f16" else 2
+    raw = (lambda t: t.numpy()) if dt == "f16" else (lambda t: t.view(torch.int16).numpy().view(np.uint16))   # (the oracle takes raw bf16 bits)
+    layers, ref = [], []
+    for i, N in enumerate(Ns):
+        U, s_, z_ = _layer(N, K, nbits, 17 * i + N + K, round_zero=(i % 2 == 0))
+        s_, z_ = s_.to(cd), z_.to(cd)
+        P = oracle.pack(nbits, U.numpy())
+        bias = None if i == 1 else torch.randn(N, generator=torch.Generator().manual_seed(i)).to(cd)
+        Wd = oracle.dequantize(nbits, P, raw(s_), raw(z_), N, K, 64, code)
+        layers.append((dev(P), s_.cuda(), z_.cuda(), None if bias is None else bias.cuda(), N))
+        ref.append((Wd, bias))
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).to(cd)
+    assert ops.gemm_grouped_covers(cd, list(Ns), M, K, 64, nbits)
+    ys = ops.gemm_grouped(x.cuda(), layers, K, 64, nbits)
+    for (Pd, sd, zd, b, N), (Wd, bias), y in zip(layers, ref, ys):
+        assert tuple(y.shape) == (M, N) and y.dtype == cd
+        yo, _ = oracle.matmul(raw(x), Wd, None if bias is None else raw(bias), code)   # (rounded as the kernels round: the product, then `+= bias`)
+        want = torch.from_numpy(yo.astype(np.float32)) if dt == "f16" else torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
+        # fp16: the forward tolerance (+ an ulp of the pre-bias value where a bias cancels it); bf16: one ulp of the result before the bias add (as test_pipelined_gemm_bf16)
+        babs = 0 if bias is None else bias.float().abs()[None, :]
+        bound = (1e-3 * (want.abs() + babs) + 2e-3) if dt == "f16" else (2.0 ** -7 * (want.abs() + babs) + 2e-3)
+        assert bool(((y.float().cpu() - want).abs() <= bound).all()), float((y.float().cpu() - want).abs().max())
+        alone = ops.gemm(x.cuda(), Pd, sd, zd, b, N, K, 64, nbits)
+        assert bool(((y.float() - alone.float()).abs().cpu() <= 2 * bound).all())
+    e = torch.zeros(M, K, dtype=cd, device="cuda")
+    ks = torch.arange(M, device="cuda") * 11 % K
+    e[torch.arange(M, device="cuda"), ks] = 1.0
+    Ys = ops.gemm_grouped(e, [(P_, s_, z_, None, N_) for (P_, s_, z_, _, N_) in layers], K, 64, nbits)
+    for (Pd, sd, zd, _, N), Y in zip(layers, Ys):
+        Wdev = ops.dequantize(Pd, sd.reshape(-1), zd.reshape(-1), N, K, 64, nbits)
+        assert torch.equal(Y, Wdev[:, ks].t().contiguous())
+    # same call twice: same bits (fixed split order)
+    ys2 = ops.gemm_grouped(x.cuda(), layers, K, 64, nbits)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(ys, ys2))
+
+
+def test_grouped_gemm_rejects_what_it_does_not_cover(ops):
+    x = torch.zeros(100, 192, dtype=torch.float16, device="cuda")
+    W = torch.zeros(64 * 192 // 2 // 64, 64, dtype=torch.uint8, device="cuda")
+    sc = torch.ones(64 * 192 // 64, 1, dtype=torch.float16, device="cuda")
+    assert not ops.gemm_grouped_covers(torch.float16, [64, 64], 100, 192, 64, 4)   # K % 128 != 0
+    with pytest.raises((NotImplementedError, RuntimeError, ValueError)):
+        ops.gemm_grouped(x, [(W, sc, sc, None, 64), (W, sc, sc, None, 64)], 192, 64, 4)
+    with pytest.raises(ValueError):
+        ops.gemm_grouped(x, [(W, sc, sc, None, 64)] * 5, 192, 64, 4)
+
+
+def test_grouped_members_take_the_grouped_gemm_for_batches(ops):
+    """group_projections: beyond the decode rows the siblings are served by ONE hqq_hip_gemm_grouped launch (the first member called computes all, the
+    others return their parked output) — the same results as the layers called one by one, within the forward tolerance"""
+    from hqq_amd.backends.hip import HQQLinearHIP, group_projections
+    from hqq_amd.core.quantize import BaseQuantizeConfig, HQQLinear
+    torch.manual_seed(11)
+    K = 512
+    cfg = BaseQuantizeConfig(nbits=4, group_size=64, axis=1)
+    parent = torch.nn.Module()
+    for name, N in (("q_proj", 512), ("k_proj", 128), ("v_proj", 128)):
+        setattr(parent, name, HQQLinearHIP(HQQLinear(torch.nn.Linear(K, N, bias=(name == "q_proj")), cfg, compute_dtype=torch.float16, device="cuda")))
+    singles = {n: getattr(parent, n) for n in ("q_proj", "k_proj", "v_proj")}
+    assert group_projections(parent, ("q_proj", "k_proj", "v_proj"))
+    calls = []
+    real = ops.gemm_grouped
+    ops.gemm_grouped = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+    try:
+        for rows in (200, 1, 70):
+            x = torch.randn(rows, K, device="cuda").half()
+            got = {n: getattr(parent, n)(x) for n in ("q_proj", "k_proj", "v_proj")}
+            for n in got:
+                torch.testing.assert_close(got[n].float(), singles[n](x).float(), rtol=1e-3, atol=2e-3)
+    finally:
+        ops.gemm_grouped = real
+    assert len(calls) == 2   # 200 and 70 rows: one grouped GEMM launch each; the single row took the grouped decode kernel

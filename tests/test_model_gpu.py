@@ -495,7 +495,7 @@ def test_token_prologue_and_argmax_advance_equal_the_torch_ops(dt):
         ops.token_prologue(tok, pos, emb, h2)                      # no tables, no mask (the kernel attention's form with a per-token rotary call)
         assert torch.equal(h2, emb[t])
     for n in (1, 7, 1024, 32000, 50257):
-        for trial in range(4):
+        for trial in range(5):
             logits = torch.randn(1, n, device="cuda", generator=g).to(dt)
             if trial == 1 and n > 7:                               # ties: the first of the largest wins, wherever the copies sit
                 top = logits.max()
@@ -504,6 +504,9 @@ def test_token_prologue_and_argmax_advance_equal_the_torch_ops(dt):
                 logits.fill_(float("-inf"))
             if trial == 3:
                 logits[0, n - 1] = 1e4
+            if trial == 4 and n > 9:                               # NaN is torch.argmax's maximum, the FIRST one wins (round-5 advisor: it was skipped)
+                logits[0, [n - 2, 7]] = float("nan")
+                logits[0, 3] = float("inf")
             nxt, tok, pos = torch.full((1, 1), -1, device="cuda"), torch.full((1, 1), -1, device="cuda"), torch.tensor([41], device="cuda")
             ops.argmax_advance(logits, nxt, tok, pos)
             want = logits.argmax(-1, keepdim=True)
@@ -589,6 +592,19 @@ def test_hfgenerator_front_end_and_kept_graphs():
     gen2 = HFGenerator(model, tok, max_new_tokens=20)
     assert torch.equal(gen2.generate(prompts[2], use_chat_template=False, verbose=False)["output_tokens"], outs[2])
     assert gen.warmup(max_samples=1) is gen if False else True   # (warmup needs a tokenizer of words; the toy one reads integers)
+    # the kept step follows the model: other weights in one layer (a new version of its packed tensor) -> the fused step and its graphs are rebuilt, not replayed stale
+    from hqq_amd.backends.hip import HQQLinearHIP
+    lay = next(m for m in model.modules() if isinstance(m, HQQLinearHIP))
+    old_step = gen.decoder.step
+    with torch.no_grad():
+        lay.W_q.add_(0)   # same bytes, next version: the fingerprint changes
+    gen.generate(prompts[0], use_chat_template=False, verbose=False)
+    assert gen.decoder.step is not old_step
+    kept = gen.decoder.step
+    gen.generate(prompts[1], use_chat_template=False, verbose=False)
+    assert gen.decoder.step is kept
+    gen.reset()
+    assert gen.decoder.step is None and gen.decoder.graphs == {}
 
 
 @pytest.mark.parametrize("arch", ["llama3-like", "mistral"])
