@@ -289,9 +289,11 @@ def test_grouped_pipelined_gemm(ops, oracle, nbits, M, Ns, K, dt):
         assert tuple(y.shape) == (M, N) and y.dtype == cd
         yo, _ = oracle.matmul(raw(x), Wd, None if bias is None else raw(bias), code)   # (rounded as the kernels round: the product, then `+= bias`)
         want = torch.from_numpy(yo.astype(np.float32)) if dt == "f16" else torch.from_numpy(yo.view(np.int16).copy()).view(torch.bfloat16).float()
-        # fp16: the forward tolerance (+ an ulp of the pre-bias value where a bias cancels it); bf16: one ulp of the result before the bias add (as test_pipelined_gemm_bf16)
+        # fp16: two roundings (the product, then `+= bias`) against the oracle's double-accumulated two: up to two ulps = 2^-9 of the pre-bias magnitude in ~1e-5 of
+        # 400 k outputs (another fp32 summation order flips the first rounding, the add rounds again); bf16: one ulp of the result before the bias add (as test_pipelined_gemm_bf16)
         babs = 0 if bias is None else bias.float().abs()[None, :]
-        bound = (1e-3 * (want.abs() + babs) + 2e-3) if dt == "f16" else (2.0 ** -7 * (want.abs() + babs) + 2e-3)
+        bound = (2e-3 * (want.abs() + babs) + 2e-3) if dt == "f16" else (2.0 ** -7 * (want.abs() + babs) + 2e-3)
+        assert float(((y.float().cpu() - want).abs() > 1e-3 * (want.abs() + babs) + 2e-3).float().mean()) < 1e-3   # ... and beyond ONE ulp almost nowhere
         assert bool(((y.float().cpu() - want).abs() <= bound).all()), float((y.float().cpu() - want).abs().max())
         alone = ops.gemm(x.cuda(), Pd, sd, zd, b, N, K, 64, nbits)
         assert bool(((y.float() - alone.float()).abs().cpu() <= 2 * bound).all())
