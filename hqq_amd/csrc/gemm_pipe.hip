@@ -35,8 +35,14 @@ namespace hqq {
 constexpr int gd_per(int nbits) { return nbits == 3 ? 2 : 8 / nbits; }
 constexpr int GD_K = 64;   // k per step.  Waves per workgroup NW (4 or 8: 16 NW packed rows per tile) and tokens per tile BM (128 or 256) are template parameters
 constexpr int GD_MAX_KS = 16;
+#ifndef GD_DX_NARROW
+#define GD_DX_NARROW 4   // x stages of the 4-wave x 128-token tile
+#endif
 template <int NW, int BM> struct GdCfg {   // LDS rings: x stages / steps ahead, packed-weight slots / steps ahead (odd), (zero, scale) slots of two steps
-  static constexpr int DX = BM == 128 ? 4 : 3, PX = DX - 1;
+  // (Round 6: the x ring of the 4-wave x 128-token tile 6 and 7 stages deep — as deep as the LDS allows, 5-6 steps ahead — changed nothing at 128..1024 rows on any
+  //  7B launch: 130.9 / 136.0 / 131.9 us per block at 128 rows with 4 / 6 / 7 stages, 465 / 461 / 462 at 1024 (tools/r6/bs128.py).  A step of that tile is not bound by how
+  //  much x it has in flight; at 128 rows the launch is bound by the 32 MB of fp32 partial tiles its 8 K splits park and re-read around 8.4 MB of weights.)
+  static constexpr int DX = BM == 128 ? (NW == 4 ? GD_DX_NARROW : 4) : 3, PX = DX - 1;
   static constexpr int DW = BM == 128 ? 8 : 4, PW = BM == 128 ? 5 : 3;
   static constexpr int DM = BM == 128 ? 4 : 2;
   static constexpr int XSTAGE = BM * GD_K * 2;
@@ -59,6 +65,12 @@ struct GdArgs {
   int M, K, G, n_tiles, m_tiles, KS, kps;
   int full;        // the first `full` tiles run whole (no split); the remaining tiles x KS splits follow (full = 0: every tile is split, or KS = 1)
 };
+// DMA instructions of the `back` iterations before iteration parity `par`: 1 weight piece + xp x pieces each, + ni constant pieces in the iterations that fetch them
+constexpr int gd_n_out(int back, int par, int pw, int xp, int ni) {
+  int n = 0;
+  for (int d = 1; d <= back; ++d) n += 1 + xp + ((((par ^ (d & 1)) + pw) & 1) == 0 ? ni : 0);
+  return n;
+}
 struct GdLayer { const uint8_t* Wq; const half_t* scale; const half_t* zero; const half_t* bias; half_t* y; int N, nt; };
 // the layer of feature tile `nt` and the tile's index inside it (wave-uniform: scalar selects over the argument arrays)
 __device__ __forceinline__ GdLayer gd_layer(const GdArgs& a, int nt) {
@@ -334,10 +346,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     for (int j = 0; j < GD_MT; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: the issue order of the steady state (weights PW steps ahead, then x PX steps ahead), everything drained once ----
+  constexpr int GD_PMAX = GD_PW > GD_PX ? GD_PW : GD_PX;
 #pragma unroll
-  for (int v = -GD_PW; v < 0; ++v) {
-    issue_w(v + GD_PW);
-    if (((v + GD_PW) & 1) == 0) issue_m(v + GD_PW);
+  for (int v = -GD_PMAX; v < 0; ++v) {
+    if (v + GD_PW >= 0) {
+      issue_w(v + GD_PW);
+      if (((v + GD_PW) & 1) == 0) issue_m(v + GD_PW);
+    }
     if (v + GD_PX >= 0) issue_x(v + GD_PX);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -384,7 +399,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
   // DMA instructions issued after the ones the next step needs: the groups of the PX - 2 iterations in between
   auto iter = [&](int i, auto parity, u32x4 (&ca0)[PER], u32x4 (&ca1)[PER], u32x4 (&na0)[PER], u32x4 (&na1)[PER]) {
     constexpr int par = decltype(parity)::value;   // i & 1
-    constexpr int N_OUT = GD_PX == 3 ? 1 + XP + (((par + GD_PW) & 1) ? MD::NI : 0) : 0;   // PX = 3: what iteration i - 1 issued; PX = 2: nothing
+    // what may stay in flight across the barrier: x and the weights of step i + 1 were issued min(PX, PW) - 1 iterations ago, so the groups of the
+    // min(PX, PW) - 2 iterations since (one weight piece, XP x pieces, and the constants every other iteration) need not have landed
+    constexpr int N_BACK = (GD_PX < GD_PW ? GD_PX : GD_PW) - 2;
+    constexpr int N_OUT = gd_n_out(N_BACK, par, GD_PW, XP, MD::NI);
 #pragma unroll
     for (int q = 1; q < NQ; ++q) {
       if (q & 1) read_b(i, q, bB0, bB1); else read_b(i, q, bA0, bA1);
