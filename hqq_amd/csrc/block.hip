@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(uint16_t* __restrict__
         u32x4 ov;
         uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r(E::f(hp[j]) * r));
+        for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r_prod(E::f(hp[j]), r));
         *reinterpret_cast<u32x4*>(xr + i) = ov;
       }
     }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_kernel(uint16_t* __restrict__
       u32x4 ov;
       uint16_t* op = reinterpret_cast<uint16_t*>(&ov);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r(E::f(hp[j]) * r));
+      for (int j = 0; j < 8; ++j) op[j] = E::mul(wp[j], E::r_prod(E::f(hp[j]), r));
       *reinterpret_cast<u32x4*>(xr + i) = ov;
     }
   }

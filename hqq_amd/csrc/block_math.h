@@ -26,6 +26,15 @@ struct El {
     else { const half_t s = __builtin_bit_cast(half_t, a) * __builtin_bit_cast(half_t, b); return __builtin_bit_cast(uint16_t, s); }
   }
   static __device__ __forceinline__ uint16_t neg(uint16_t a) { return static_cast<uint16_t>(a ^ 0x8000u); }
+  // T(a * b) for an fp32 product the way torch's two ops round it: the product is an fp32 VALUE first (one rounding), the cast rounds it again.  Written
+  // as `r(a * b)` hipcc folds the pair into ONE v_fma_mixlo_f16 where it can (not under SLP vectorisation, which takes v_pk_mul_f32 + v_cvt_pk_f16_f32): the
+  // same source then rounds differently from one build to the next (round 6: -fno-slp-vectorize moved 1 normalised activation in ~16,000 by an ulp and a
+  // tiny model's 27th greedy token with it).  The empty asm makes the product opaque: v_mul_f32, then the conversion.
+  static __device__ __forceinline__ uint16_t r_prod(float a, float b) {
+    float p = a * b;
+    asm("" : "+v"(p));
+    return r(p);
+  }
 };
 
 // q_embed = (q * cos) + (rotate_half(q) * sin), rotate_half = cat(-x2, x1): every product and the sum round to T

@@ -114,15 +114,22 @@ struct OutCtx {
   int N, row0;
 };
 __device__ __forceinline__ OutCtx select_out(const GvIn& a, const GvOut& o, int prow) {
-  int li = 0, row0 = 0, N = a.N[0];
+  int row0 = 0, N = a.N[0];
 #pragma unroll
   for (int i = 1; i < GV_MAXL; ++i) {
     const bool in = prow >= a.prow_end[i - 1];
-    li = pick(in, i, li);   // (scalar selects: a sum of the comparisons was computed on the vector side and read back with v_readfirstlane)
     row0 = pick(in, a.prow_end[i - 1], row0);
     N = pick(in, a.N[i], N);
   }
-  return OutCtx{o.bias[li], o.y[li], N, row0};
+  // the layer's index on the SCALAR side: written in C++ (a sum, or a chain of selects, of the three comparisons) the compiler computed it with
+  // v_cndmask / v_addc and read it back with v_readfirstlane at every row end.  (The pointers are then read with an indexed SCALAR load; pointer arithmetic on
+  // the argument struct instead made them a vector load + v_readfirstlane whose vmcnt wait also waited for the next units' weights.)
+  int li;
+  asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_i32 %1, %3\n\ts_cselect_b32 %0, 2, %0\n\ts_cmp_ge_i32 %1, %4\n\ts_cselect_b32 %0, 3, %0"
+      : "=&s"(li) : "s"(prow), "s"(a.prow_end[0]), "s"(a.prow_end[1]), "s"(a.prow_end[2]) : "scc");
+  const half_t* bias = o.bias[li];
+  half_t* y = o.y[li];
+  return OutCtx{bias, y, N, row0};
 }
 
 // (zero, scale) of a group as fetched — two 2-byte loads — as ONE dword z | sc << 16.  Written as the build of a two-element 16-bit vector:

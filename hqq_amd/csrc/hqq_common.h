@@ -74,6 +74,27 @@ __device__ __forceinline__ float diag_sum(const f32x4& t) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// The same sum, valid in LANE 63 ONLY, without leaving the vector side (round 6): the quad fold towards the quad's lane 3, everything but the four diagonal
+// quads masked to zero, two row shifts bring a row's value to its lane 15, row_bcast:15 / row_bcast:31 add the rows into lane 63.  8 VALU and no
+// v_readlane (diag_sum: 3 DPP adds + 4 v_readlane + 5 VALU).  Same association — ((d0 + d1) + (d2 + d3)) per quad, (q0 + q1) + (q2 + q3) across, with the
+// operands of each addition swapped — hence the same bits; the zeros added on the way are exact (an accumulator that starts at +0 never holds -0).
+__device__ __forceinline__ float diag_sum63(const f32x4& t, bool diag_lane /* lane == 3, 23, 43, 63 */) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rows)::value, 0xF, true));
+  };
+  using R = std::integral_constant<int, 0xF>;
+  const float a = t[1] + dpp(t[0], std::integral_constant<int, 0x00>{}, R{});   // quad_perm [0,0,0,0]: lane 1 of the quad: reg1 + lane 0's reg0
+  const float b = t[3] + dpp(t[2], std::integral_constant<int, 0xAA>{}, R{});   // quad_perm [2,2,2,2]: lane 3: reg3 + lane 2's reg2
+  const float w = b + dpp(a, std::integral_constant<int, 0x55>{}, R{});         // quad_perm [1,1,1,1]: lane 3: b + lane 1's a
+  const float wm = diag_lane ? w : 0.f;
+  const float s1 = wm + dpp(wm, std::integral_constant<int, 0x114>{}, R{});     // row_shr:4
+  const float s2 = s1 + dpp(s1, std::integral_constant<int, 0x118>{}, R{});     // row_shr:8 -> lane 15 of a row: its diagonal quad's sum
+  // (every row enabled: rows without a source add the zero bound_ctrl supplies; what the other lanes end up with does not matter — and the compiler can fuse the
+  //  move into the add, which it cannot when some rows must keep an old value)
+  const float c1 = s2 + dpp(s2, std::integral_constant<int, 0x142>{}, R{});   // row_bcast:15: row r += lane 15 of row r - 1
+  return c1 + dpp(c1, std::integral_constant<int, 0x143>{}, R{});              // row_bcast:31: rows 2, 3 += lane 31: lane 63 = (q3 + q2) + (q1 + q0)
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(static_cast<uint32_t>(h) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
   uint32_t x = __float_as_uint(f);

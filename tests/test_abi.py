@@ -89,3 +89,26 @@ def test_ops_refuse_cpu_tensors():
     from hqq_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.pack(4, torch.zeros(8, 8, dtype=torch.uint8))
+
+
+def test_no_single_rounding_fp16_products_in_the_norm_kernels():
+    """`T(float(h) * rinv)` must round twice (fp32 product, then fp16), as HF's LlamaRMSNorm does.  hipcc folds the pair into v_fma_mixlo_f16 — ONE rounding
+    (tools/r6/mixlo_probe.hip: 996 of 16.7 M products differ) — unless the product is made opaque (block_math.h El::r_prod).  The shipped code objects of the
+    kernels that normalise (block.hip, gemv_block.hip) must not contain the fused form."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from hqq_amd import _C
+    bundler, objdump = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    objs = [o for o in glob.glob(os.path.join(_C.CSRC, "build", "*.o")) if os.path.basename(o).startswith(("block.", "gemv_block_"))]
+    if not (objs and os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        import pytest
+        pytest.skip("needs the built objects and the ROCm LLVM tools")
+    for o in objs:
+        with tempfile.TemporaryDirectory() as d:
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, f"{d}/fb.bin"])
+            subprocess.check_call([bundler, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={d}/fb.bin", f"--output={d}/co.co", "--unbundle"])
+            dis = subprocess.run([objdump, "-d", f"{d}/co.co"], capture_output=True, text=True, check=True).stdout
+        assert "v_fma_mixlo_f16" not in dis and "v_fma_mixhi_f16" not in dis, os.path.basename(o)
