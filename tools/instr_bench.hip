@@ -44,6 +44,34 @@
 #define B_BFE(i) asm volatile("v_bfe_u32 %0, %0, 4, 4" : "+v"(a##i));
 #define B_MOVDPP(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1" : "+v"(a##i));
 
+// the decode loop's own forms (round 6): constants in SGPRs / literals, op_sel and neg modifiers
+#define B_PKFMA_S(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(a##i) : "s"(sc), "v"(c));
+#define B_PKFMA_V(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(a##i) : "v"(b), "v"(c));
+#define B_PKMUL_OS(i) asm volatile("v_pk_mul_f16 %0, %1, %0 op_sel:[1,0]" : "+v"(a##i) : "v"(c));
+#define B_AND_LIT(i) asm volatile("v_and_b32 %0, 0xf000f0, %0" : "+v"(a##i));
+#define B_AND_S(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a##i) : "s"(sc));
+#define B_MUL16(i) asm volatile("v_mul_f16 %0, %1, %0" : "+v"(a##i) : "v"(c));
+#define B_FMA16(i) asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(k_pkfma_s, uint32_t sc = __builtin_amdgcn_readfirstlane(seed | 0x78007800u);, R8(B_PKFMA_S))
+KERNEL(k_pkfma_v, , R8(B_PKFMA_V))
+KERNEL(k_pkmul_os, , R8(B_PKMUL_OS))
+#define B_PKMUL_OSH(i) asm volatile("v_pk_mul_f16 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(a##i) : "v"(c));
+#define B_PKFMA_OS2(i) asm volatile("v_pk_fma_f16 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(a##i) : "s"(sc), "v"(c));
+#define B_PKMUL_S(i) asm volatile("v_pk_mul_f16 %0, %1, %0 op_sel_hi:[0,1]" : "+v"(a##i) : "s"(sc));
+KERNEL(k_pkmul_osh, , R8(B_PKMUL_OSH))
+KERNEL(k_pkfma_os2, uint32_t sc = __builtin_amdgcn_readfirstlane(seed | 0x78007800u);, R8(B_PKFMA_OS2))
+KERNEL(k_pkmul_s, uint32_t sc = __builtin_amdgcn_readfirstlane(seed | 0x3c003c00u);, R8(B_PKMUL_S))
+KERNEL(k_and_lit, , R8(B_AND_LIT))
+KERNEL(k_and_s, uint32_t sc = __builtin_amdgcn_readfirstlane(seed | 0x00f000f0u);, R8(B_AND_S))
+KERNEL(k_mul16, , R8(B_MUL16))
+KERNEL(k_fma16, , R8(B_FMA16))
+// the rebuild's own mix: per dword 1 shift + 4 and + 4 pk_fma + 4 pk_mul (13 instructions), dependent as in the kernel
+#define B_MIX(i) asm volatile("v_lshrrev_b32 %1, 8, %0\n v_and_b32 %2, 0xf000f0, %0\n v_and_b32 %3, 0xf000f0, %1\n v_and_b32 %4, 0xf000f, %0\n v_and_b32 %1, 0xf000f, %1\n" \
+  "v_pk_fma_f16 %2, %2, %5, %6 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n v_pk_fma_f16 %3, %3, %5, %6 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n" \
+  "v_pk_fma_f16 %4, %4, %5, %6 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n v_pk_fma_f16 %1, %1, %5, %6 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n" \
+  "v_pk_mul_f16 %2, %6, %2 op_sel:[1,0]\n v_pk_mul_f16 %3, %6, %3 op_sel:[1,0]\n v_pk_mul_f16 %4, %6, %4 op_sel:[1,0]\n v_pk_mul_f16 %1, %6, %1 op_sel:[1,0]\n v_xor_b32 %0, %2, %3\n v_xor_b32 %0, %0, %4\n v_xor_b32 %0, %0, %1" \
+  : "+v"(a##i), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "s"(sc), "v"(c));
+KERNEL(k_mix, uint32_t sc = __builtin_amdgcn_readfirstlane(seed | 0x78007800u); uint32_t t0 = 0 ; uint32_t t1 = 0 ; uint32_t t2 = 0 ; uint32_t t3 = 0;, R8(B_MIX))
 KERNEL(k_pkfma, , R8(B_PKFMA))
 KERNEL(k_pkadd, , R8(B_PKADD))
 KERNEL(k_pkmul, , R8(B_PKMUL))
@@ -97,6 +125,17 @@ int main() {
   run("v_fma_f32", k_fma32, d, cus, ghz);
   run("v_pk_fma_f32", k_pkfma32, d, cus, ghz);
   run("v_pk_fma_f16", k_pkfma, d, cus, ghz);
+  run("pk_fma sgpr+mods", k_pkfma_s, d, cus, ghz);
+  run("pk_fma vgpr+mods", k_pkfma_v, d, cus, ghz);
+  run("pk_mul op_sel", k_pkmul_os, d, cus, ghz);
+  run("pk_mul op_sel_hi0", k_pkmul_osh, d, cus, ghz);
+  run("pk_fma src2 hi->both", k_pkfma_os2, d, cus, ghz);
+  run("pk_mul sgpr", k_pkmul_s, d, cus, ghz);
+  run("v_and literal", k_and_lit, d, cus, ghz);
+  run("v_and sgpr", k_and_s, d, cus, ghz);
+  run("v_mul_f16", k_mul16, d, cus, ghz);
+  run("v_fma_f16", k_fma16, d, cus, ghz);
+  run("rebuild mix/16", k_mix, d, cus, ghz);
   run("v_pk_add_f16", k_pkadd, d, cus, ghz);
   run("v_pk_mul_f16", k_pkmul, d, cus, ghz);
   run("v_dot2c_f16", k_dot2c, d, cus, ghz);

@@ -6,7 +6,7 @@
 
 #include <type_traits>
 
-#include "../../include/hqq_hip.h"
+#include "../../../include/hqq_hip.h"
 
 namespace hqq {
 
