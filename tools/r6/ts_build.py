@@ -20,7 +20,7 @@ k = splice(k, "  issue(ring[0], lc, cp, cu, live0);", "  TS(1);")
 k = k.replace("  __syncthreads();\n\n  // FACTORED: one fp32 partial per", "  TS(2);\n  __syncthreads();\n  TS(3);\n\n  // FACTORED: one fp32 partial per")
 k = k.replace("        if (rp[f] < total) consume(ring[f], rp[f], ru[f]);", "        if (rp[f] < total) { TS(4); consume(ring[f], rp[f], ru[f]); TS(5); ++n_cons; t_[6] = __builtin_amdgcn_s_memrealtime(); }")
 # the end: after the loop
-k = k.replace("    } while (more);\n  }\n}", "    } while (more);\n  }\n  t_[7] = __builtin_amdgcn_s_memrealtime();\n  if (lane == 0 && g_lab_ts_dev) { unsigned long long* q = g_lab_ts_dev + (static_cast<size_t>(blockIdx.x) * WPG + wave) * 9; for (int i = 0; i < 8; ++i) q[i] = t_[i]; q[8] = n_cons; }\n}")
+k = k.replace("    } while (more);\n  }\n}", "    } while (more);\n  }\n  t_[7] = __builtin_amdgcn_s_memrealtime();\n  if (lane == 0 && g_lab_ts_dev) { unsigned long long* q = g_lab_ts_dev + (static_cast<size_t>(blockIdx.x) * WPG + wave) * 11; for (int i = 0; i < 8; ++i) q[i] = t_[i]; q[8] = n_cons; q[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15; q[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4); }\n}")
 open(os.path.join(dst, "gemv_kernel.inc"), "w").write(k)
 g = open(os.path.join(dst, "gemv.hip")).read()
 g = g.replace('#include "w3s.h"\n', '#include "w3s.h"\n__device__ unsigned long long* g_lab_ts_dev = nullptr;\nextern "C" int hqq_lab_set_ts(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lab_ts_dev), &p, sizeof(p)); }\n', 1)
