@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0, help="decoder blocks (default: 32 for the 7B stack, 80 for the 70B one)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-group", action="store_true", help="one launch per layer instead of one per exchange group (q/k/v, o, gate/up, down)")
+    ap.add_argument("--plan", default=os.environ.get("HQQ_BENCH_PLAN", "sharded"), choices=["sharded", "adaptive"],
+                    help="N > 1, 70B strong scaling: sharded = every exchange group column-sharded (4 exchanges per block); adaptive = "
+                         "hqq_amd.shard.plan_exchange_groups: a group too small to shard is held and computed WHOLE by every rank, no exchange behind it")
     ap.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1, 70B strong scaling: skip timing the unsharded stack on rank 0 alone")
     ap.add_argument("--prefill-route", default="auto", choices=["auto", "fused", "dense", "library"],
                     help="prefill: auto = ops.forward's own choice per layer (the product path); fused = the fused MFMA dequant-GEMM (gemm_pipe.hip); "
@@ -348,6 +351,14 @@ def main():
         for _, N, _ in BLOCK:
             assert N % (per * world) == 0, f"column shard: N={N} must divide by {per} * {world} (hqq_amd/shard.py)"
 
+    # the shard plan (strong scaling only): which exchange groups are column-sharded — and exchange — and which every rank holds whole
+    plan = ["sharded"] * len(EXCHANGE_GROUPS)
+    if strong and a.plan == "adaptive":
+        from hqq_amd import shard as _shard_plan
+        plan = _shard_plan.plan_exchange_groups([sum(wq_bytes(N, K, nbits) for name, N, K in BLOCK if name in grp) for grp in EXCHANGE_GROUPS], world)
+    whole = {n: (pl != "sharded") for grp, pl in zip(EXCHANGE_GROUPS, plan) for n in grp}
+    XGROUPS = [grp for grp, pl in zip(EXCHANGE_GROUPS, plan) if pl == "sharded"]   # the groups with an exchange behind them
+
     # ---- the resident stack: every layer distinct in HBM ----
     t_setup = time.perf_counter()
     blocks = []
@@ -357,9 +368,9 @@ def main():
             # strong scaling: rank r holds N / P output columns of the layer (as a layer of its own: the shard of a packed-row
             # block of the reference layout is exactly the reference layout of a layer with N / P rows — hqq_amd/shard.py —
             # so a synthetic shard is quantised directly; tests/test_shard.py proves the slicing against whole layers)
-            n_loc = N // world if strong else N
-            blk[name] = make_layer(ops, name, n_loc, K, nbits, dev, seed=(1000 * rank if not strong else 7919 * rank) + 16 * b + i,
-                                   random_codes=a.random_codes, cd=cd)
+            n_loc = N // world if (strong and not whole[name]) else N
+            blk[name] = make_layer(ops, name, n_loc, K, nbits, dev, seed=(1000 * rank if not strong else (0 if whole[name] else 7919 * rank)) + 16 * b + i,
+                                   random_codes=a.random_codes, cd=cd)   # (a replicated layer is the same layer on every rank: same seed)
         blocks.append(blk)
     gx = torch.Generator(device=dev).manual_seed(1)       # x is replicated: same seed on every rank
     xs = {K: torch.randn(M, K, device=dev, generator=gx).to(cd) for K in sorted({K for _, _, K in BLOCK})}
@@ -368,7 +379,7 @@ def main():
     out_local = {grp: [torch.empty(M, dimN[n], device=dev, dtype=cd) for n in grp] for grp in EXCHANGE_GROUPS}
     out_flat, out_gath, out_full = {}, {}, {}
     if world > 1:
-        for grp in EXCHANGE_GROUPS:
+        for grp in XGROUPS:
             tot = sum(dimN[n] for n in grp)
             out_flat[grp] = torch.empty(M * tot, device=dev, dtype=cd)            # this rank's outputs of the group, back to back
             out_gath[grp] = torch.empty(world * M * tot, device=dev, dtype=cd)    # rank-major concatenation
@@ -423,7 +434,7 @@ def main():
         the function tests/test_shard.py checks against whole layers, writing into a preallocated buffer here)"""
         from hqq_amd import shard
         if xmode.get("peer") is not None:   # one kernel: slices stored straight into every rank's full rows over peer memory
-            xmode["peer"].run(EXCHANGE_GROUPS.index(grp), out_local[grp])
+            xmode["peer"].run(XGROUPS.index(grp), out_local[grp])
             return
         if M == 1 and xmode.get("rows1"):
             exchange_rows1(grp, xmode["coalesced"])
@@ -479,7 +490,7 @@ def main():
                             for c0 in range(0, M, PREFILL_CHUNK):
                                 ops.forward(X[L.K][c0:c0 + PREFILL_CHUNK], L.Wq, L.scale, L.zero, None, L.N, L.K, 64, nbits, out=OL[grp][j][c0:c0 + PREFILL_CHUNK],
                                             opts=group_opts([L]), **route_kw)
-                if world > 1 and bs_x is None:
+                if world > 1 and bs_x is None and not whole[grp[0]]:
                     exchange(grp)
 
     # auto (default): the collective — coalesced per-slab gathers on RCCL, else the shard-wide gather.  peer: the peer-memory kernel
@@ -492,7 +503,7 @@ def main():
         from hqq_amd import shard as _shard
         ok, why, px = 1.0, "", None
         try:   # (collective, and consistent: either every rank gets its object or every rank raises — hqq_amd/shard.py)
-            px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in EXCHANGE_GROUPS], nbits, cd, dev, rows=M)
+            px = _shard.PeerExchange([[world * dimN[n] for n in grp] for grp in XGROUPS], nbits, cd, dev, rows=M)
         except Exception as e:   # noqa: BLE001
             ok, why = 0.0, f"{type(e).__name__}: {e}"
         if px is not None:
@@ -500,16 +511,16 @@ def main():
             alive = True   # (a rank whose peer path raised keeps taking part in the collectives of the remaining rounds)
             for rnd in range(3):
                 # the collectives first, all of them, outside any try: a rank whose peer path fails below must not leave the others in one
-                for grp in EXCHANGE_GROUPS:
+                for grp in XGROUPS:
                     for t in out_local[grp]:
                         t.copy_(torch.randn(t.shape, device=dev, generator=gv).to(cd))
                     exchange(grp)                       # the collective (xmode holds no peer object yet) -> out_full
-                want = {grp: [t.clone() for t in out_full[grp]] for grp in EXCHANGE_GROUPS}
+                want = {grp: [t.clone() for t in out_full[grp]] for grp in XGROUPS}
                 torch.cuda.synchronize()
                 if not alive:
                     continue
                 try:   # the peer path: no collective inside, waits bounded
-                    for e, grp in enumerate(EXCHANGE_GROUPS):
+                    for e, grp in enumerate(XGROUPS):
                         px.run(e, out_local[grp])
                         torch.cuda.synchronize()
                         for j in range(len(grp)):
@@ -523,7 +534,7 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if float(okt) > 0:
             xmode["peer"] = px
-            for e, grp in enumerate(EXCHANGE_GROUPS):
+            for e, grp in enumerate(XGROUPS):
                 out_full[grp] = [px.full(e, j) for j in range(len(grp))]
         elif why:
             print(f"[bench] rank {rank}: peer-memory exchange not used: {why}", file=sys.stderr)
@@ -532,7 +543,7 @@ def main():
         # issued one by one it is `per` times as many collectives as the shard-wide gather
         for coalesce in ((True,) if dist.get_backend() == "nccl" else ((False,) if xenv == "rows1" else ())):
             try:
-                for grp in EXCHANGE_GROUPS:
+                for grp in XGROUPS:
                     exchange_rows1(grp, coalesce)
                 torch.cuda.synchronize()
                 ok = torch.ones(1, device=dev)
@@ -564,7 +575,10 @@ def main():
     }
     model = "llama2-70b" if big else "llama2-7b"
     if decode:
-        gbs = world * bytes_per_step_rank / sec_per_step / 1e9
+        # whole-job algorithmic bytes: a sharded layer's shards add up to the layer; a replicated layer counts ONCE (every rank streaming it is
+        # redundant work the plan chose, not throughput)
+        job_bytes = nblocks * sum((1 if (strong and whole[n]) else world) * gemv_bytes(dimN[n], K, nbits, M) for n, _, K in BLOCK)
+        gbs = job_bytes / sec_per_step / 1e9
         n_scal = sum(1 for blk in blocks for L in blk.values() if L.opts & ops.OPT_META_SCALABLE)
         out.update({
             "metric": f"int{nbits} gs=64 dequant-GEMV decode throughput, {model} linear stack bs={M} (algorithmic GB/s; tok/s alongside)",
@@ -581,6 +595,10 @@ def main():
                        "gemv_mode": mode_name, "layers_with_three_op_rebuild": f"{n_scal}/{nblocks * len(BLOCK)}",
                        "bytes_per_step_per_gpu": bytes_per_step_rank, "setup_s": round(t_setup, 2)},
         })
+        if strong:
+            out["plan"] = {"name": a.plan, "groups": dict(zip(["|".join(g_) for g_ in EXCHANGE_GROUPS], plan)), "exchange_points_per_block": len(XGROUPS),
+                           "job_bytes_per_step": job_bytes,
+                           "note": "hqq_amd.shard.plan_exchange_groups; a replicated-small group is computed whole by every rank (counted once in `value`), no exchange behind it"}
         unit_launches = stages_per_step   # the unit the roofline is quoted per: one dependent stage (= one launch on the launch path)
         avg_launch_s = dev_sec_per_step / unit_launches
         ach = (bytes_per_step_rank / unit_launches) / avg_launch_s / 1e9
@@ -598,18 +616,21 @@ def main():
             xs_, _ = _timed(xrun, max(5, a.steps // 2), 3, dist, dev)
             rows1 = bool(M == 1 and xmode.get("rows1"))
             peer = xmode.get("peer") is not None
-            n_slab_gathers = nblocks * len(BLOCK) * per_slab
+            x_points = nblocks * len(XGROUPS)                              # exchange points per step under the plan
+            x_layers = nblocks * sum(len(g_) for g_ in XGROUPS)
+            n_slab_gathers = x_layers * per_slab
             out["exchange"] = {"ms_per_step": round(xs_ * 1e3, 5),
                                "mode": ("peer-memory stores (hqq_hip_exchange): one kernel per exchange point writes the rank's slices into every rank's full rows in the reference's column order and waits for the others' flags; validated against the collective at start-up"
                                         if peer else
                                         ("per-slab all-gathers straight into the reference's column order" + (", one coalesced RCCL launch per exchange point" if xmode["coalesced"] else ", issued one by one")) if rows1 else "one all-gather of the shard outputs per exchange point + un-permute copies"),
-                               "exchange_kernels_per_step": stages_per_step if peer else 0,
+                               "points_per_step": x_points, "us_per_point": round(xs_ * 1e6 / max(1, x_points), 3),
+                               "exchange_kernels_per_step": x_points if peer else 0,
                                "peer_status": xmode["peer"].status() if peer else None,
                                "peer_memory": xmode["peer"].memory_kind if peer else None,
-                               "collective_launches_per_step": 0 if peer else ((stages_per_step if xmode["coalesced"] else n_slab_gathers) if rows1 else stages_per_step),
-                               "all_gathers_per_step": 0 if peer else (n_slab_gathers if rows1 else stages_per_step),
-                               "unpermute_kernels_per_step": 0 if (rows1 or peer) else nblocks * len(BLOCK),
-                               "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK),
+                               "collective_launches_per_step": 0 if peer else ((x_points if xmode["coalesced"] else n_slab_gathers) if rows1 else x_points),
+                               "all_gathers_per_step": 0 if peer else (n_slab_gathers if rows1 else x_points),
+                               "unpermute_kernels_per_step": 0 if (rows1 or peer) else x_layers,
+                               "bytes_sent_per_rank_per_step": 2 * M * nblocks * sum(dimN[n] for n, _, _ in BLOCK if not whole[n]),
                                "note": "the exchange of every exchange point, timed without the GEMV launches"}
             if strong and not a.no_single_gpu_reference:
                 # the SAME fixed stack on ONE GPU (rank 0 alone, the others wait): the single-GPU time a strong-scaling figure refers to

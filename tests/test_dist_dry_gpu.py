@@ -23,14 +23,14 @@ def _free_port():
     return p
 
 
-def _run(mode, bs):
+def _run(mode, bs, plan="sharded"):
     env = dict(os.environ, HQQ_BENCH_ONE_GPU="1", HQQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     if mode == "auto":
         env.pop("HQQ_BENCH_EXCHANGE", None)
     else:
         env["HQQ_BENCH_EXCHANGE"] = mode
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bs", str(bs), "--blocks", "2", "--steps", "3", "--warmup", "1", "--random-codes", "--no-single-gpu-reference"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bs", str(bs), "--blocks", "2", "--steps", "3", "--warmup", "1", "--random-codes", "--no-single-gpu-reference", "--plan", plan]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
@@ -53,3 +53,23 @@ def test_two_rank_bench_dry_run_on_one_gpu(mode, bs):
         assert x["collective_launches_per_step"] > 0
         if bs == 1 and mode == "rows1":   # one activation row: per-slab gathers straight into the reference's column order, no un-permute (gloo: issued one by one)
             assert x["unpermute_kernels_per_step"] == 0
+
+
+@pytest.mark.parametrize("mode,bs", [("auto", 1), ("peer", 1), ("gather", 32)])
+def test_two_rank_bench_dry_run_with_the_adaptive_plan(mode, bs):
+    """--plan adaptive (hqq_amd.shard.plan_exchange_groups): at two ranks the 70B block's q|k|v (42 MB) and o (34 MB) are below the replicate threshold
+    (62 MB) -> held whole by both ranks, no exchange behind them; gate|up and down stay sharded: 2 exchange points per block instead of 4."""
+    from hqq_amd import shard
+    d, err = _run(mode, bs, plan="adaptive")
+    pl = d["plan"]
+    assert pl["name"] == "adaptive"
+    assert pl["groups"] == {"q|k|v": "replicated-small", "o": "replicated-small", "gate|up": "sharded", "down": "sharded"}, pl
+    assert pl["exchange_points_per_block"] == 2
+    assert 41e6 < shard.replicate_below_bytes(2) < 80e6
+    x = d["exchange"]
+    assert x["points_per_step"] == 2 * 2 and x["us_per_point"] > 0
+    if mode == "peer":
+        assert x["exchange_kernels_per_step"] == 4 and x["peer_status"] == 0, (x, err[-800:])
+    # `value` counts a replicated layer once: the job's bytes are below world x one rank's bytes
+    assert pl["job_bytes_per_step"] < 2 * d["config"]["bytes_per_step_per_gpu"]
+    assert abs(d["value"] - pl["job_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.01 * d["value"]

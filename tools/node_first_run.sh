@@ -14,7 +14,7 @@ NG=$(python -c "import torch; print(torch.cuda.device_count())")
 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 for N in 2 4 8; do
   [ $N -le $NG ] || continue
-  for MODE in auto rows1 gather; do
+  for MODE in auto peer rows1 gather; do
     HQQ_BENCH_EXCHANGE=$MODE timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + N)) \
       bench.py --gpus $N --steps 20 --warmup 5 > $OUT/bench_n${N}_${MODE}.json 2> $OUT/bench_n${N}_${MODE}.err
     python - <<PY
@@ -27,6 +27,23 @@ except Exception as e:
     print("N=$N mode=$MODE: no result (", e, ") — see $OUT/bench_n${N}_${MODE}.err")
 PY
   done
+  # the adaptive plan (hqq_amd.shard.plan_exchange_groups): groups too small to shard are computed whole by every rank; compare `value` with the auto line above
+  timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29700 + N)) \
+    bench.py --gpus $N --steps 20 --warmup 5 --plan adaptive --no-single-gpu-reference > $OUT/bench_n${N}_adaptive.json 2> $OUT/bench_n${N}_adaptive.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/bench_n${N}_adaptive.json").read().strip().split("\n")[-1])
+    print("N=$N plan=adaptive:", d["ms_per_step"], "ms/token,", d["value"], d["unit"], "| groups", d["plan"]["groups"], "| exchange us per point", d["exchange"]["us_per_point"])
+except Exception as e:
+    print("N=$N plan=adaptive: no result (", e, ")")
+PY
+  for BS in 32; do
+    timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29800 + N)) \
+      bench.py --gpus $N --bs $BS --steps 20 --warmup 5 --no-single-gpu-reference > $OUT/bench_n${N}_bs${BS}.json 2> $OUT/bench_n${N}_bs${BS}.err
+  done
+  timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29900 + N)) \
+    bench.py --gpus $N --workload decode --steps 20 --warmup 5 > $OUT/bench_n${N}_weak.json 2> $OUT/bench_n${N}_weak.err
 done
 if [ 2 -le $NG ]; then
   export TMPDIR=/tmp
