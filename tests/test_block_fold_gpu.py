@@ -207,3 +207,67 @@ def test_rotary_epilogue_equals_rope_cache_on_the_same_projections(ops, dt, nbit
         assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), pos_v
         if not 0 <= pos_v < L:
             assert bool((kc2 == 7.0).all()) and bool((vc2 == 5.0).all())
+
+
+@pytest.mark.parametrize("nbits", [4, 3, 2])
+def test_folded_launches_against_the_oracles_own_weights(ops, oracle, nbits):
+    """The tests above contract with weights rebuilt by the HIP dequantise kernel (itself pinned to the goldens); here the whole chain goes through the CPU
+    oracle instead: levels packed by oracle.pack, weights by oracle.dequantize (Quantizer.dequantize restated, hqq/core/quantize.py:183-199),
+    contraction by oracle.matmul (double accumulation) — for the RMSNorm prologue (q|k|v form), the SiLU * up epilogue and the residual epilogue, fp16."""
+    dt, K, eps = torch.float16, 2048, 1e-5
+    g = torch.Generator().manual_seed(40 + nbits)
+
+    def olayer(N, seed):
+        gg = torch.Generator().manual_seed(seed)
+        R = N * K // 64
+        U = torch.randint(0, 2 ** nbits, (R, 64), generator=gg, dtype=torch.uint8)
+        sc = (torch.rand(R, 1, generator=gg) * 0.004 + 0.001).to(dt)
+        z = (torch.rand(R, 1, generator=gg) * (2 ** nbits - 1)).float().clamp_min(0.0625).to(dt)
+        P = oracle.pack(nbits, U.numpy())                                                         # BitPack.pack_* restated (hqq/core/bitpack.py)
+        Wd = oracle.dequantize(nbits, P, sc.numpy(), z.numpy(), N, K, 64, 1)                      # [N, K] fp16, the reference's two roundings
+        Wq = torch.from_numpy(P).cuda()
+        sd, zd = sc.cuda(), z.cuda()
+        opts = 0
+        if nbits == 3:
+            Wq = ops.w3s_pack(Wq, N, K)
+            opts = ops.OPT_W3S | (ops.OPT_META_SCALABLE if ops.w3s_meta_scalable(sd, zd, N, K) else 0)
+        elif ops.meta_scalable(sd, zd, N, K, 64, nbits):
+            opts = ops.OPT_META_SCALABLE
+        return (Wq, sd, zd, N), opts, Wd
+
+    h = (torch.randn(1, K, generator=g) * 1.3).to(dt)
+    w = (1 + 0.1 * torch.randn(K, generator=g)).to(dt)
+    xn = _rmsnorm_hf(h, w, eps)                                                                   # LlamaRMSNorm with its roundings, on the CPU
+    # RMSNorm prologue, three layers in one launch
+    Ls, Wds, opts = [], [], None
+    for i, N in enumerate((512, 128, 128)):
+        L, o, Wd = olayer(N, 900 + 10 * nbits + i)
+        Ls.append(L); Wds.append(Wd)
+        opts = o if opts is None else (opts & o) | (o & ops.OPT_W3S)
+    outs = [torch.full((1, L[3]), float("nan"), dtype=dt, device="cuda") for L in Ls]
+    ops.gemv_block(h.cuda(), w.cuda(), eps, Ls, K, 64, nbits, outs, ops.BLOCK_NORM, opts=opts)
+    for y, Wd in zip(outs, Wds):
+        _, y32 = oracle.matmul(xn.numpy(), Wd, None, 1)
+        np.testing.assert_allclose(y.float().cpu().numpy(), y32, rtol=1e-3, atol=1e-3)
+    # SiLU * up epilogue on the paired layer
+    I = 256
+    gate, og, Wg = olayer(I, 950 + nbits)
+    up, ou, Wu = olayer(I, 960 + nbits)
+    pair = ops.pair_layers(gate, up, K, 64, nbits, w3s=(nbits == 3))
+    po = (ops.OPT_W3S if nbits == 3 else 0) | ((ops.OPT_META_SCALABLE) if (ops.w3s_meta_scalable(pair[1], pair[2], 2 * I, K) if nbits == 3 else ops.meta_scalable(pair[1], pair[2], 2 * I, K, 64, nbits)) else 0)
+    a = torch.full((1, I), float("nan"), dtype=dt, device="cuda")
+    ops.gemv_block(h.cuda(), w.cuda(), eps, [pair], K, 64, nbits, [a], ops.BLOCK_NORM | ops.BLOCK_SILU, opts=po)
+    yg, _ = oracle.matmul(xn.numpy(), Wg, None, 1)                                               # T(gate_proj(x)), T(up_proj(x)): the linears' own outputs
+    yu, _ = oracle.matmul(xn.numpy(), Wu, None, 1)
+    tg, tu = torch.from_numpy(yg.astype(np.float16)), torch.from_numpy(yu.astype(np.float16))
+    want = (torch.nn.functional.silu(tg.float()).to(dt) * tu).float()                            # LlamaMLP: act_fn(gate) * up with its roundings
+    assert bool(_near(a.cpu(), want.to(dt), ulps=4.0).all())                                      # (an ulp of the fp32-accumulated gate / up moves the product by up to two)
+    # residual epilogue
+    Lr, orr, Wr = olayer(384, 970 + nbits)
+    x = torch.randn(1, K, generator=g).to(dt)
+    hres = (torch.randn(1, 384, generator=g) * 3).to(dt)
+    yr, y32 = oracle.matmul(x.numpy(), Wr, None, 1)
+    hd = hres.cuda()
+    ops.gemv_block(x.cuda(), None, 0.0, [Lr], K, 64, nbits, [hd], ops.BLOCK_RESID, opts=orr)
+    want_h = hres.float() + torch.from_numpy(y32)                                                 # h + y in exact arithmetic: the kernel rounds y to T, then the sum to T
+    np.testing.assert_allclose(hd.float().cpu().numpy(), want_h.numpy(), rtol=2e-3, atol=4e-3)
