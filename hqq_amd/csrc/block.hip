@@ -147,7 +147,6 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const uint16_t* __restr
 // ---- out = T(silu(gate)) * up ----
 template <bool BF>
 __global__ __launch_bounds__(256) void silu_mul_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ u, uint16_t* __restrict__ out, int64_t n) {
-  using E = El<BF>;
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 8;
   if (i >= n) return;
   const u32x4 gv = *reinterpret_cast<const u32x4*>(g + i);
