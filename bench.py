@@ -216,6 +216,11 @@ def cpu_baseline(nbits):
     nb = gemv_bytes(N, K, nbits)
     stack_calls = sum(gemv_bytes(n, k, nbits) for _, n, k in LLAMA2_7B_BLOCK) * N_BLOCKS_7B / nb
     out = {"unit": "GB/s", "cores": cores, "threads": cores, "host_cores": cores, "kind": "port"}
+    try:   # (name the CPU the baseline ran on)
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), None)
+    except OSError:
+        out["cpu_model"] = None
     # ---- (1) torch eager ----
     if nbits in (8, 4, 2):
         g = torch.Generator().manual_seed(0)
