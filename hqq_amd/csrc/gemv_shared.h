@@ -126,7 +126,7 @@ __device__ __forceinline__ OutCtx select_out(const GvIn& a, const GvOut& o, int 
   // the argument struct instead made them a vector load + v_readfirstlane whose vmcnt wait also waited for the next units' weights.)
   int li;
   asm("s_cmp_ge_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0\n\ts_cmp_ge_i32 %1, %3\n\ts_cselect_b32 %0, 2, %0\n\ts_cmp_ge_i32 %1, %4\n\ts_cselect_b32 %0, 3, %0"
-      : "=&s"(li) : "s"(prow), "s"(a.prow_end[0]), "s"(a.prow_end[1]), "s"(a.prow_end[2]) : "scc");
+      : "=&s"(li) : "s"(__builtin_amdgcn_readfirstlane(prow)), "s"(a.prow_end[0]), "s"(a.prow_end[1]), "s"(a.prow_end[2]) : "scc");
   const half_t* bias = o.bias[li];
   half_t* y = o.y[li];
   return OutCtx{bias, y, N, row0};
