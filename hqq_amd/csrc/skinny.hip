@@ -446,8 +446,13 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   constexpr int NPASS = NRC / (SK_T / 4);       // 2 PER
   constexpr int NROUND = SK_MAX_CPS / 4;
   u32x2 mv[NROUND][NPASS];
+  // (a round covers four chunks: the rounds past the split's chunks are skipped — a workgroup-uniform branch; what counts for the waits below is the
+  //  number of loads issued AFTER a round, which is the same on both paths.  With 2-8 chunks per split they were 4-12 of the 16 + 6 vector-memory
+  //  instructions a wave issues before its first consume: -1 % per step at 32 rows on two boxes.  2-bit layers — four slabs, twice the passes — lost 0.8 % with it
+  //  on both and keep every round)
 #pragma unroll
   for (int rd = 0; rd < NROUND; ++rd)
+    if (NBITS == 2 || rd * 4 < c1 - c0)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int id = pass * (SK_T / 4) + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(SK_T) void skinny_f16_kernel(const SkArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int rd = 0; rd < NROUND; ++rd)
+    if (NBITS == 2 || rd * 4 < c1 - c0)
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int id = pass * (SK_T / 4) + (tid >> 2), row = id / (2 * PER), q = id % (2 * PER), s = q >> 1, hi = q & 1;
