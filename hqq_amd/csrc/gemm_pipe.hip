@@ -71,6 +71,24 @@ constexpr int gd_n_out(int back, int par, int pw, int xp, int ni) {
   for (int d = 1; d <= back; ++d) n += 1 + xp + ((((par ^ (d & 1)) + pw) & 1) == 0 ? ni : 0);
   return n;
 }
+// DMA instructions a wave issues in the prologue AFTER the last one of step 0 (the prologue's issue order: per v = -max(pw, px) .. -1: weights of step v + pw
+// [+ ni constant pieces on even steps], then xp x pieces of step v + px): what may still be in flight when step 0 is rebuilt and contracted
+constexpr int gd_prologue_after_step0(int pw, int px, int xp, int ni) {
+  const int pmax = pw > px ? pw : px;
+  int total = 0, last0 = 0;
+  for (int v = -pmax; v < 0; ++v) {
+    if (v + pw >= 0) {
+      total += 1;
+      if (((v + pw) & 1) == 0) total += ni;
+      if (v + pw == 0) last0 = total;
+    }
+    if (v + px >= 0) {
+      total += xp;
+      if (v + px == 0) last0 = total;
+    }
+  }
+  return total - last0;
+}
 struct GdLayer { const uint8_t* Wq; const half_t* scale; const half_t* zero; const half_t* bias; half_t* y; int N, nt; };
 // the layer of feature tile `nt` and the tile's index inside it (wave-uniform: scalar selects over the argument arrays)
 __device__ __forceinline__ GdLayer gd_layer(const GdArgs& a, int nt) {
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
 #pragma unroll
     for (int j = 0; j < GD_MT; ++j) acc[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: the issue order of the steady state (weights PW steps ahead, then x PX steps ahead), everything drained once ----
+  // ---- prologue: the issue order of the steady state (weights PW steps ahead, then x PX steps ahead); step 0 waited for ----
   constexpr int GD_PMAX = GD_PW > GD_PX ? GD_PW : GD_PX;
 #pragma unroll
   for (int v = -GD_PMAX; v < 0; ++v) {
@@ -355,7 +373,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && !(NBITS == 2 && GD_2BIT_ONE_WA
     }
     if (v + GD_PX >= 0) issue_x(v + GD_PX);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    // only step 0 has to have landed: the steps behind it stay in flight across the barrier and the loop's own counted waits take over from iteration 0
+    // (until round 6 everything was drained here: at 128 rows — 8-16 steps per workgroup — that was 4 % of a launch; 2 % at 256, nothing from 1024 on)
+    constexpr int K0 = gd_prologue_after_step0(GD_PW, GD_PX, XP, MD::NI);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K0) : "memory");
+  }
   __builtin_amdgcn_s_barrier();
   u32x4 a0[2][PER], a1[2][PER];   // A fragments of the current / next step (8 fp16 / bf16 values each)
   fetch_meta(0);
